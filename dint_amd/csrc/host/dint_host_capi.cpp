@@ -1,0 +1,275 @@
+// C ABI of the offline CPU half (see include/dint_host.h).
+#include "dint_host.h"
+
+#include <cstring>
+#include <exception>
+#include <string>
+#include <vector>
+
+#include "dint/dictionaries.hpp"
+#include "dint/encoders.hpp"
+#include "dint/statistics.hpp"
+#include "dint/synthetic.hpp"
+#include "dint/vroom_stream.hpp"
+
+struct dinth_blob {
+    std::vector<uint8_t> bytes;
+};
+
+namespace {
+
+thread_local std::string g_error;
+
+template <typename Fn>
+int guarded(Fn&& fn) {
+    try {
+        g_error.clear();
+        return fn();
+    } catch (std::bad_alloc const&) {
+        g_error = "out of memory";
+        return DINT_ERR_NOMEM;
+    } catch (std::exception const& e) {
+        g_error = e.what();
+        return DINT_ERR_FORMAT;
+    }
+}
+
+template <typename T>
+dinth_blob* blob_of(std::vector<T> const& v) {
+    auto b = new dinth_blob;
+    auto p = reinterpret_cast<uint8_t const*>(v.data());
+    b->bytes.assign(p, p + v.size() * sizeof(T));
+    return b;
+}
+
+dint::synth_params to_params(dinth_synth_params const& c) {
+    dint::synth_params p;
+    p.seed = c.seed;
+    p.universe = c.universe;
+    p.alpha = c.alpha;
+    p.min_len = c.min_len;
+    p.max_len = c.max_len;
+    p.stay_cluster = c.stay_cluster;
+    p.stay_sparse = c.stay_sparse;
+    p.p_cluster_min = c.p_cluster_min;
+    p.p_cluster_max = c.p_cluster_max;
+    return p;
+}
+
+template <typename Builder>
+int build_dictionary(bool multi, uint32_t const* gaps, uint32_t const* lens, uint64_t n_lists,
+                     uint64_t max_sample_ints, int threads, dinth_blob** out) {
+    using namespace dint;
+    // sample = prefix of the collection
+    uint64_t n_sample_lists = 0, ints = 0;
+    for (; n_sample_lists != n_lists; ++n_sample_lists) {
+        if (max_sample_ints && n_sample_lists && ints + lens[n_sample_lists] > max_sample_ints) break;
+        ints += lens[n_sample_lists];
+    }
+    std::vector<uint64_t> starts(n_sample_lists + 1, 0);
+    for (uint64_t i = 0; i != n_sample_lists; ++i) starts[i + 1] = starts[i] + lens[i];
+    uint32_t contexts = multi ? kNumSelectors : 1;
+    int workers = std::max(1, threads);
+    std::vector<ngram_statistics> partial(workers, ngram_statistics(contexts));
+    std::atomic<uint64_t> next{0};
+    std::vector<std::thread> pool;
+    for (int w = 0; w != workers; ++w) {
+        pool.emplace_back([&, w] {
+            for (uint64_t i; (i = next.fetch_add(1)) < n_sample_lists;) {
+                if (lens[i] == 0) continue;  // constants::min_size = 0: n > 0 only
+                if (multi) partial[w].collect_multi(gaps + starts[i], lens[i]);
+                else partial[w].collect_single(gaps + starts[i], lens[i]);
+            }
+        });
+    }
+    for (auto& t : pool) t.join();
+    for (int w = 1; w < workers; ++w) {
+        partial[0].merge(partial[w]);
+        partial[w] = ngram_statistics(contexts);
+    }
+    Builder builder;
+    build_dsf(builder, partial[0]);
+    auto b = new dinth_blob;
+    builder.write(b->bytes);
+    *out = b;
+    return DINT_OK;
+}
+
+template <typename Encoder, typename Builder>
+int encode_with(void const* dict_file, size_t dict_len, uint32_t const* gaps, uint32_t const* lens,
+                uint64_t n_lists, uint32_t unit_ints, int threads, dinth_blob** enc, dinth_blob** units) {
+    Builder builder;
+    builder.load(static_cast<uint8_t const*>(dict_file), dict_len);
+    builder.prepare_for_encoding();
+    auto out = dint::encode_vroom<Encoder>(builder, gaps, lens, n_lists, unit_ints, threads);
+    auto e = new dinth_blob;
+    e->bytes.swap(out.bytes);
+    *enc = e;
+    if (units) *units = blob_of(out.units);
+    return DINT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const void* dinth_blob_data(const dinth_blob* b) { return b ? b->bytes.data() : nullptr; }
+size_t dinth_blob_size(const dinth_blob* b) { return b ? b->bytes.size() : 0; }
+void dinth_blob_free(dinth_blob* b) { delete b; }
+const char* dinth_last_error(void) { return g_error.c_str(); }
+
+void dinth_synth_defaults(dinth_synth_params* c) {
+    if (!c) return;
+    dint::synth_params p;
+    c->seed = p.seed;
+    c->universe = p.universe;
+    c->min_len = p.min_len;
+    c->max_len = p.max_len;
+    c->reserved = 0;
+    c->alpha = p.alpha;
+    c->stay_cluster = p.stay_cluster;
+    c->stay_sparse = p.stay_sparse;
+    c->p_cluster_min = p.p_cluster_min;
+    c->p_cluster_max = p.p_cluster_max;
+}
+
+int dinth_synth_lengths(const dinth_synth_params* p, uint64_t target_postings, dinth_blob** lens) {
+    if (!p || !lens || p->universe == 0) return DINT_ERR_ARG;
+    return guarded([&] {
+        *lens = blob_of(dint::synth_lengths(to_params(*p), target_postings));
+        return DINT_OK;
+    });
+}
+
+int dinth_synth_gaps(const dinth_synth_params* p, const uint32_t* lens, uint64_t n_lists, uint64_t first_list_id,
+                     uint32_t* gaps_out, int threads) {
+    if (!p || (!lens && n_lists) || (!gaps_out && n_lists) || p->universe == 0) return DINT_ERR_ARG;
+    return guarded([&] {
+        auto params = to_params(*p);
+        std::vector<uint64_t> starts(n_lists + 1, 0);
+        for (uint64_t i = 0; i != n_lists; ++i) starts[i + 1] = starts[i] + lens[i];
+        const uint64_t group = 256;
+        dint::parallel_for((n_lists + group - 1) / group, threads, [&](size_t g) {
+            uint64_t end = std::min<uint64_t>(n_lists, (g + 1) * group);
+            for (uint64_t i = g * group; i != end; ++i)
+                dint::synth_gaps(params, first_list_id + i, lens[i], gaps_out + starts[i]);
+        });
+        return DINT_OK;
+    });
+}
+
+int dinth_build_dictionary(int kind, const uint32_t* gaps, const uint32_t* lens, uint64_t n_lists,
+                           uint64_t max_sample_ints, int threads, dinth_blob** dict_file) {
+    if (!dict_file || (n_lists && (!gaps || !lens))) return DINT_ERR_ARG;
+    return guarded([&] {
+        switch (kind) {
+            case DINT_DICT_RECTANGULAR:
+                return build_dictionary<dint::rectangular_builder>(false, gaps, lens, n_lists, max_sample_ints,
+                                                                   threads, dict_file);
+            case DINT_DICT_SINGLE_PACKED:
+                return build_dictionary<dint::single_packed_builder>(false, gaps, lens, n_lists, max_sample_ints,
+                                                                     threads, dict_file);
+            case DINT_DICT_MULTI_PACKED:
+                return build_dictionary<dint::multi_packed_builder>(true, gaps, lens, n_lists, max_sample_ints,
+                                                                    threads, dict_file);
+            default:
+                return int(DINT_ERR_ARG);
+        }
+    });
+}
+
+int dinth_encode_vroom(int kind, int greedy, const void* dict_file, size_t dict_len, const uint32_t* gaps,
+                       const uint32_t* lens, uint64_t n_lists, uint32_t unit_ints, int threads, dinth_blob** enc,
+                       dinth_blob** units) {
+    if (!dict_file || !enc || (n_lists && (!gaps || !lens))) return DINT_ERR_ARG;
+    return guarded([&] {
+        using namespace dint;
+        switch (kind) {
+            case DINT_DICT_RECTANGULAR:
+                return greedy ? encode_with<single_greedy_dint, rectangular_builder>(dict_file, dict_len, gaps, lens,
+                                                                                     n_lists, unit_ints, threads, enc,
+                                                                                     units)
+                              : encode_with<single_opt_dint, rectangular_builder>(dict_file, dict_len, gaps, lens,
+                                                                                  n_lists, unit_ints, threads, enc,
+                                                                                  units);
+            case DINT_DICT_SINGLE_PACKED:
+                return greedy ? encode_with<single_greedy_dint, single_packed_builder>(dict_file, dict_len, gaps, lens,
+                                                                                       n_lists, unit_ints, threads,
+                                                                                       enc, units)
+                              : encode_with<single_opt_dint, single_packed_builder>(dict_file, dict_len, gaps, lens,
+                                                                                    n_lists, unit_ints, threads, enc,
+                                                                                    units);
+            case DINT_DICT_MULTI_PACKED:
+                return encode_with<multi_opt_dint, multi_packed_builder>(dict_file, dict_len, gaps, lens, n_lists,
+                                                                         unit_ints, threads, enc, units);
+            default:
+                return int(DINT_ERR_ARG);
+        }
+    });
+}
+
+uint64_t dinth_hash_u32s(const uint32_t* p, size_t n) { return dint::hash_u32s(p, n); }
+
+int dinth_dict_num_entries(int kind, const void* dict_file, size_t dict_len, uint32_t d, uint32_t* n_out) {
+    if (!dict_file || !n_out) return DINT_ERR_ARG;
+    return guarded([&] {
+        auto bytes = static_cast<uint8_t const*>(dict_file);
+        if (kind == DINT_DICT_RECTANGULAR) {
+            dint::rectangular_builder b;
+            b.load(bytes, dict_len);
+            *n_out = b.size();
+        } else if (kind == DINT_DICT_SINGLE_PACKED) {
+            dint::single_packed_builder b;
+            b.load(bytes, dict_len);
+            *n_out = b.size();
+        } else if (kind == DINT_DICT_MULTI_PACKED) {
+            dint::multi_packed_builder b;
+            b.load(bytes, dict_len);
+            if (d >= dint::kNumSelectors) return int(DINT_ERR_ARG);
+            *n_out = b.slots(d);
+        } else {
+            return int(DINT_ERR_ARG);
+        }
+        return int(DINT_OK);
+    });
+}
+
+int dinth_dict_entry(int kind, const void* dict_file, size_t dict_len, uint32_t d, uint32_t index, uint32_t* size_out,
+                     uint32_t* words16_out) {
+    if (!dict_file || !size_out || !words16_out) return DINT_ERR_ARG;
+    return guarded([&] {
+        auto bytes = static_cast<uint8_t const*>(dict_file);
+        uint32_t size = 0;
+        uint32_t const* p = nullptr;
+        uint32_t avail = 0;
+        dint::rectangular_builder rb;
+        dint::single_packed_builder sb;
+        dint::multi_packed_builder mb;
+        if (kind == DINT_DICT_RECTANGULAR) {
+            rb.load(bytes, dict_len);
+            if (index >= dint::kNumEntries) return int(DINT_ERR_ARG);
+            size = rb.size(index);
+            p = rb.get(index);
+            avail = dint::kMaxEntrySize;
+        } else if (kind == DINT_DICT_SINGLE_PACKED) {
+            sb.load(bytes, dict_len);
+            if (index >= sb.offsets().size()) return int(DINT_ERR_ARG);
+            size = sb.size(index);
+            p = sb.get(index);
+            avail = uint32_t(sb.table().size() - sb.offset(index));
+        } else if (kind == DINT_DICT_MULTI_PACKED) {
+            mb.load(bytes, dict_len);
+            if (d >= dint::kNumSelectors || index >= mb.slots(d)) return int(DINT_ERR_ARG);
+            size = mb.size(d, index);
+            p = mb.get(d, index);
+            avail = uint32_t(mb.table().size() - mb.offset(d, index));
+        } else {
+            return int(DINT_ERR_ARG);
+        }
+        *size_out = size;
+        for (uint32_t k = 0; k != dint::kMaxEntrySize; ++k) words16_out[k] = k < avail ? p[k] : 0;
+        return int(DINT_OK);
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,207 @@
+"""ctypes binding of the offline CPU half (include/dint_host.h).
+
+Synthetic collections, DSF dictionary construction and the vroom encoder: the
+producers of the decode path's inputs. In the reference these are CPU C++ too
+(vroom_env/encode.cpp, include/dint/dictionary_builders.hpp). Nothing in this
+module decodes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+RECTANGULAR, SINGLE_PACKED, MULTI_PACKED = 0, 1, 2
+KIND_BY_TYPE = {
+    # reference type strings, vroom_env/decode.cpp:236-244
+    "single_rect_dint": RECTANGULAR,
+    "single_packed_dint": SINGLE_PACKED,
+    "multi_packed_dint": MULTI_PACKED,
+}
+
+UNIT_DTYPE = np.dtype(
+    [("in_off", "<u8"), ("out_off", "<u8"), ("n", "<u4"), ("list", "<u4")], align=False
+)
+assert UNIT_DTYPE.itemsize == 24
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libdint_host.so")
+
+
+class SynthParams(C.Structure):
+    _fields_ = [
+        ("seed", C.c_uint64),
+        ("universe", C.c_uint32),
+        ("min_len", C.c_uint32),
+        ("max_len", C.c_uint32),
+        ("reserved", C.c_uint32),
+        ("alpha", C.c_double),
+        ("stay_cluster", C.c_double),
+        ("stay_sparse", C.c_double),
+        ("p_cluster_min", C.c_double),
+        ("p_cluster_max", C.c_double),
+    ]
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(
+            f"{_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C dint_amd/csrc`) first"
+        )
+    lib = C.CDLL(_LIB_PATH)
+    vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+    lib.dinth_blob_data.restype = vp
+    lib.dinth_blob_data.argtypes = [vp]
+    lib.dinth_blob_size.restype = C.c_size_t
+    lib.dinth_blob_size.argtypes = [vp]
+    lib.dinth_blob_free.restype = None
+    lib.dinth_blob_free.argtypes = [vp]
+    lib.dinth_last_error.restype = C.c_char_p
+    lib.dinth_synth_defaults.restype = None
+    lib.dinth_synth_defaults.argtypes = [C.POINTER(SynthParams)]
+    lib.dinth_synth_lengths.argtypes = [C.POINTER(SynthParams), u64, C.POINTER(vp)]
+    lib.dinth_synth_gaps.argtypes = [C.POINTER(SynthParams), vp, u64, u64, vp, i32]
+    lib.dinth_build_dictionary.argtypes = [i32, vp, vp, u64, u64, i32, C.POINTER(vp)]
+    lib.dinth_encode_vroom.argtypes = [i32, i32, vp, C.c_size_t, vp, vp, u64, u32, i32,
+                                       C.POINTER(vp), C.POINTER(vp)]
+    lib.dinth_hash_u32s.restype = u64
+    lib.dinth_hash_u32s.argtypes = [vp, C.c_size_t]
+    lib.dinth_dict_entry.argtypes = [i32, vp, C.c_size_t, u32, u32, C.POINTER(u32), vp]
+    lib.dinth_dict_num_entries.argtypes = [i32, vp, C.c_size_t, u32, C.POINTER(u32)]
+    return lib
+
+
+_lib = _load()
+
+
+class HostError(RuntimeError):
+    pass
+
+
+def _check(status: int) -> None:
+    if status != 0:
+        raise HostError(f"dint host call failed ({status}): {_lib.dinth_last_error().decode()}")
+
+
+def _take_blob(handle, dtype) -> np.ndarray:
+    """Copy a dinth_blob into a numpy array and free the blob."""
+    try:
+        size = _lib.dinth_blob_size(handle)
+        arr = np.empty(size // np.dtype(dtype).itemsize, dtype=dtype)
+        if size:
+            C.memmove(arr.ctypes.data, _lib.dinth_blob_data(handle), size)
+        return arr
+    finally:
+        _lib.dinth_blob_free(handle)
+
+
+def _u32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def default_threads() -> int:
+    return max(1, len(os.sched_getaffinity(0)))
+
+
+def synth_params(**overrides) -> SynthParams:
+    p = SynthParams()
+    _lib.dinth_synth_defaults(C.byref(p))
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise TypeError(f"unknown synthetic parameter {k!r}")
+        setattr(p, k, v)
+    return p
+
+
+def synth_lengths(params: SynthParams, target_postings: int) -> np.ndarray:
+    h = C.c_void_p()
+    _check(_lib.dinth_synth_lengths(C.byref(params), target_postings, C.byref(h)))
+    return _take_blob(h, np.uint32)
+
+
+def synth_gaps(params: SynthParams, lens: np.ndarray, first_list_id: int = 0,
+               threads: int | None = None) -> np.ndarray:
+    lens = _u32(lens)
+    gaps = np.empty(int(lens.sum(dtype=np.uint64)), dtype=np.uint32)
+    _check(_lib.dinth_synth_gaps(C.byref(params), lens.ctypes.data, len(lens), first_list_id,
+                                 gaps.ctypes.data, threads or default_threads()))
+    return gaps
+
+
+@dataclass
+class Collection:
+    """Posting lists as d-gaps minus one (what the encoders consume), back to back."""
+    gaps: np.ndarray  # u32
+    lens: np.ndarray  # u32, one per list
+
+    @property
+    def num_postings(self) -> int:
+        return int(self.gaps.size)
+
+    def list_bounds(self) -> np.ndarray:
+        b = np.zeros(len(self.lens) + 1, dtype=np.uint64)
+        np.cumsum(self.lens, dtype=np.uint64, out=b[1:])
+        return b
+
+
+def synth_collection(target_postings: int, threads: int | None = None, **params) -> Collection:
+    p = synth_params(**params)
+    lens = synth_lengths(p, target_postings)
+    return Collection(synth_gaps(p, lens, 0, threads), lens)
+
+
+def docids_to_gaps(docids: np.ndarray) -> np.ndarray:
+    """gap[i] = doc[i] - doc[i-1] - 1 with doc[-1] = -1 (vroom_env/jobs.hpp:74-84)."""
+    d = np.asarray(docids, dtype=np.uint32)
+    g = np.empty_like(d)
+    if d.size:
+        g[0] = d[0]
+        g[1:] = d[1:] - d[:-1] - np.uint32(1)
+    return g
+
+
+def build_dictionary(kind: int, coll: Collection, max_sample_ints: int = 0,
+                     threads: int | None = None) -> bytes:
+    """DSF-65536-16 dictionary file image for `kind`, built from (a prefix sample of) coll."""
+    h = C.c_void_p()
+    gaps, lens = _u32(coll.gaps), _u32(coll.lens)
+    _check(_lib.dinth_build_dictionary(kind, gaps.ctypes.data, lens.ctypes.data, len(lens),
+                                       max_sample_ints, threads or default_threads(), C.byref(h)))
+    return _take_blob(h, np.uint8).tobytes()
+
+
+def encode_vroom(kind: int, dict_file: bytes, coll: Collection, unit_ints: int = 4096,
+                 greedy: bool = False, threads: int | None = None):
+    """-> (encoded stream u8[], unit table UNIT_DTYPE[])"""
+    enc, units = C.c_void_p(), C.c_void_p()
+    gaps, lens = _u32(coll.gaps), _u32(coll.lens)
+    buf = (C.c_char * len(dict_file)).from_buffer_copy(dict_file)
+    _check(_lib.dinth_encode_vroom(kind, int(greedy), C.addressof(buf), len(dict_file),
+                                   gaps.ctypes.data, lens.ctypes.data, len(lens), unit_ints,
+                                   threads or default_threads(), C.byref(enc), C.byref(units)))
+    return _take_blob(enc, np.uint8), _take_blob(units, UNIT_DTYPE)
+
+
+def hash_u32s(words) -> int:
+    w = _u32(words)
+    return int(_lib.dinth_hash_u32s(w.ctypes.data, w.size))
+
+
+def dict_num_entries(kind: int, dict_file: bytes, d: int = 0) -> int:
+    n = C.c_uint32()
+    buf = (C.c_char * len(dict_file)).from_buffer_copy(dict_file)
+    _check(_lib.dinth_dict_num_entries(kind, C.addressof(buf), len(dict_file), d, C.byref(n)))
+    return n.value
+
+
+def dict_entry(kind: int, dict_file: bytes, index: int, d: int = 0):
+    """-> (size, first 16 payload words)"""
+    size = C.c_uint32()
+    words = np.zeros(16, dtype=np.uint32)
+    buf = (C.c_char * len(dict_file)).from_buffer_copy(dict_file)
+    _check(_lib.dinth_dict_entry(kind, C.addressof(buf), len(dict_file), d, index, C.byref(size),
+                                 words.ctypes.data))
+    return size.value, words

@@ -1,0 +1,127 @@
+/*
+ * dint_hip.h — C ABI of the MI355X (gfx950) DINT decode path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch
+ * types. Each entry point names the reference interface (jermp/dint) it
+ * replaces; the C++ adaptors that give these calls the reference's static
+ * `Coder::decode(dict, in, out, sum, n) -> in_end` shape live in
+ * dint_amd/csrc/host/dint/coders.hpp, and INTEGRATION.md shows the
+ * reference-side binding.
+ *
+ * Threading: a dint_dict is immutable after creation and may be used from
+ * several host threads with distinct streams. One dint_dict lives on one
+ * device; multi-GPU = one dint_dict per device (the dictionary is replicated,
+ * posting lists are partitioned, there is no data-path collective).
+ *
+ * All functions return DINT_OK (0) or a negative dint_status; none throws.
+ */
+#ifndef DINT_HIP_H
+#define DINT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DINT_ABI_VERSION 1
+
+typedef enum dint_status {
+    DINT_OK = 0,
+    DINT_ERR_ARG = -1,       /* null pointer, bad enum, capacity too small          */
+    DINT_ERR_FORMAT = -2,    /* dictionary file or encoded stream is malformed      */
+    DINT_ERR_HIP = -3,       /* a HIP runtime call failed (see dint_last_hip_error) */
+    DINT_ERR_NO_DEVICE = -4, /* no gfx950 device / device index out of range        */
+    DINT_ERR_NOMEM = -5
+} dint_status;
+
+/* Dictionary flavours of the decode path (reference include/dint/dictionary_types.hpp:8-21). */
+typedef enum dint_dict_kind {
+    DINT_DICT_RECTANGULAR = 0,   /* single_rect_dint   */
+    DINT_DICT_SINGLE_PACKED = 1, /* single_packed_dint */
+    DINT_DICT_MULTI_PACKED = 2   /* multi_packed_dint  */
+} dint_dict_kind;
+
+/* Opaque device-resident dictionary.
+ * Replaces: Dictionary::builder::load + builder.build(dict)
+ *           (vroom_env/decode.cpp:116-123; single_dictionary.hpp:88-107,177-181;
+ *            rectangular_dictionary.hpp:79-92; multi_dictionary.hpp:93-121). */
+typedef struct dint_dict dint_dict;
+
+/* One unit of decode work: a run of codewords that starts on a codeword
+ * boundary and decodes to exactly `n` integers. The vroom stream has no sync
+ * points (lists are `vbyte(n) vbyte(universe) payload` back to back,
+ * vroom_env/jobs.hpp:89-91), so this table is the sidecar that makes the
+ * stream parallel; it is produced by dint_index_stream() or by the encoder. */
+typedef struct dint_unit {
+    uint64_t in_off;  /* byte offset of the unit's first codeword in the encoded buffer */
+    uint64_t out_off; /* index of the unit's first integer in the output buffer         */
+    uint32_t n;       /* integers this unit decodes to (> 0)                             */
+    uint32_t list;    /* ordinal of the posting list the unit belongs to                 */
+} dint_unit;
+
+typedef struct dint_dict_info {
+    int32_t kind;           /* dint_dict_kind                                  */
+    int32_t device;         /* HIP device ordinal                              */
+    uint32_t num_dicts;     /* 1, or 6 for multi                               */
+    uint32_t entries;       /* m_size of the file                              */
+    uint32_t hot_entries;   /* codewords whose payload is staged in LDS        */
+    uint32_t lds_bytes;     /* LDS image size in bytes                         */
+    uint32_t table_words;   /* device table size in u32                        */
+    uint32_t compute_units; /* CUs of the device the kernels are sized for     */
+} dint_dict_info;
+
+int dint_abi_version(void);
+const char* dint_strerror(int status);
+/* text of the last HIP error seen by the calling thread ("" if none) */
+const char* dint_last_hip_error(void);
+int dint_device_count(int* count);
+
+/* Parse a dictionary file image (the bytes the reference's builder::write
+ * produced) and stage it on `device`. */
+int dint_dict_create(int kind, const void* file_bytes, size_t len, int device, dint_dict** out);
+void dint_dict_destroy(dint_dict* dict);
+int dint_dict_info_get(const dint_dict* dict, dint_dict_info* info);
+
+/* Untimed host pre-pass over a whole vroom stream in host memory: reads every
+ * list header, walks the codewords WITHOUT copying dictionary payloads, and
+ * cuts each list into units of about `unit_ints` integers at codeword
+ * boundaries (multi: at 256-integer block boundaries).
+ * Replaces: the per-list framing loop of vroom_env/decode.cpp:139-150.
+ * `*units` is malloc'ed; release with dint_free. */
+int dint_index_stream(const dint_dict* dict, const uint8_t* enc, size_t enc_bytes,
+                      uint32_t unit_ints, dint_unit** units, size_t* n_units,
+                      uint64_t* total_ints, uint64_t* n_lists);
+void dint_free(void* p);
+
+/* Decode `n_units` units. All pointers except `dict` are DEVICE pointers on the
+ * dictionary's device; `stream` is a hipStream_t (NULL = default stream). The
+ * call is asynchronous. Exactly unit.n integers are written at
+ * d_out[unit.out_off ...]; nothing else is touched (no pre-zeroed output, no
+ * overflow area — unlike the reference, dint_codecs.hpp:11). If d_end_off is
+ * not NULL, d_end_off[u] receives the byte offset one past unit u's last
+ * consumed byte (the reference's returned `in` pointer).
+ * Replaces: single_dint::decode / multi_opt_dint::decode
+ *           (vroom_env/dint_codecs.hpp:37-107, :521-619). */
+int dint_decode_units(const dint_dict* dict, const uint8_t* d_enc, size_t enc_bytes,
+                      const dint_unit* d_units, size_t n_units, uint32_t* d_out,
+                      size_t out_capacity, uint64_t* d_end_off, void* stream);
+
+/* Host-pointer convenience with the reference's call shape: decode ONE
+ * sequence of n integers starting at in[0]; *consumed = bytes read. Uploads,
+ * runs one unit on the device, downloads, synchronises. Correct for any n but
+ * a single wavefront wide: batch through dint_decode_units for throughput.
+ * Replaces: Coder::decode(dict, in, out, universe, n) at vroom_env/decode.cpp:143. */
+int dint_decode_list_host(const dint_dict* dict, const uint8_t* in, size_t in_bytes,
+                          uint32_t* out, size_t n, size_t* consumed);
+
+/* Sum of per-kernel device time (ms) between the two events the library
+ * records around the decode kernel of the most recent dint_decode_units on
+ * this dictionary; valid after the stream has been synchronised. */
+int dint_last_kernel_ms(const dint_dict* dict, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DINT_HIP_H */

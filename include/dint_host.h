@@ -1,0 +1,79 @@
+/*
+ * dint_host.h — C ABI of the CPU-side (offline) half of the DINT path:
+ * synthetic collections, dictionary construction and the vroom encoder.
+ *
+ * These are the producers of the decode path's inputs. In the reference they
+ * are CPU C++ as well (vroom_env/encode.cpp, include/dint/dictionary_builders.hpp,
+ * src/create_freq_index.cpp); nothing here runs on the device and nothing here
+ * decodes. Python (bench.py, tests) binds this header with ctypes.
+ */
+#ifndef DINT_HOST_H
+#define DINT_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "dint_hip.h" /* dint_unit, dint_dict_kind, dint_status */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Owned byte buffer returned by the functions below. */
+typedef struct dinth_blob dinth_blob;
+const void* dinth_blob_data(const dinth_blob* b);
+size_t dinth_blob_size(const dinth_blob* b);
+void dinth_blob_free(dinth_blob* b);
+
+/* text of the last error raised on the calling thread */
+const char* dinth_last_error(void);
+
+typedef struct dinth_synth_params {
+    uint64_t seed;
+    uint32_t universe;
+    uint32_t min_len;
+    uint32_t max_len; /* 0 = universe / 3 */
+    uint32_t reserved;
+    double alpha;
+    double stay_cluster;
+    double stay_sparse;
+    double p_cluster_min;
+    double p_cluster_max;
+} dinth_synth_params;
+
+void dinth_synth_defaults(dinth_synth_params* p);
+/* u32 list lengths summing exactly to target_postings */
+int dinth_synth_lengths(const dinth_synth_params* p, uint64_t target_postings, dinth_blob** lens);
+/* gaps_out must hold sum(lens) u32; list i of the collection has id first_list_id + i */
+int dinth_synth_gaps(const dinth_synth_params* p, const uint32_t* lens, uint64_t n_lists,
+                     uint64_t first_list_id, uint32_t* gaps_out, int threads);
+
+/* Block statistics + DSF-65536-16 (reference dictionary_builders.hpp:40-76) over
+ * the first lists whose lengths sum to <= max_sample_ints (0 = all lists).
+ * Returns the dictionary FILE image (reference builder::write format). */
+int dinth_build_dictionary(int kind, const uint32_t* gaps, const uint32_t* lens, uint64_t n_lists,
+                           uint64_t max_sample_ints, int threads, dinth_blob** dict_file);
+
+/* Encode lists into one vroom stream (reference vroom_env/encode.cpp:133-191).
+ * kind selects the dictionary type of dict_file; greedy != 0 selects
+ * single_greedy_dint instead of single_opt_dint (ignored for multi).
+ * *units receives a dint_unit[] table cut every ~unit_ints integers
+ * (0 = one unit per list). */
+int dinth_encode_vroom(int kind, int greedy, const void* dict_file, size_t dict_len,
+                       const uint32_t* gaps, const uint32_t* lens, uint64_t n_lists,
+                       uint32_t unit_ints, int threads, dinth_blob** enc, dinth_blob** units);
+
+/* MurmurHash64A(seed 0) of n u32 words (reference include/dint/hash_utils.hpp:7-80). */
+uint64_t dinth_hash_u32s(const uint32_t* p, size_t n);
+
+/* Dictionary file introspection for tests: writes up to cap (size, first
+ * payload words) — returns number of entries of dictionary `d`. */
+int dinth_dict_entry(int kind, const void* dict_file, size_t dict_len, uint32_t d, uint32_t index,
+                     uint32_t* size_out, uint32_t* words16_out);
+int dinth_dict_num_entries(int kind, const void* dict_file, size_t dict_len, uint32_t d,
+                           uint32_t* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DINT_HOST_H */

@@ -1,0 +1,335 @@
+/*
+ * dint_oracle.c — see dint_oracle.h (TEST INFRASTRUCTURE; PARITY UNPINNED).
+ * Plain C11. Citations are relative to /root/reference.
+ */
+#define _POSIX_C_SOURCE 200809L
+#include "dint_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#define ENTRIES 65536u     /* include/dint/dint_configuration.hpp:27 */
+#define MAX_ENTRY 16u      /* :25 */
+#define NUM_SELECTORS 6u   /* :20 */
+#define EXCEPTIONS_ 2u     /* :6  */
+#define BLOCK 256u         /* include/util.hpp:35 */
+#define MAX_LIST 50000000u /* include/util.hpp:34 */
+
+struct oracle_dict {
+    int kind;
+    /* rect: table = 65536 rows x 17 words (rectangular_dictionary.hpp:43-56) */
+    /* packed: offsets[] + table[] (single_dictionary.hpp:230-238) */
+    /* multi: start_offsets[6] + offsets[] + table[] (multi_dictionary.hpp:293-304) */
+    uint32_t size;
+    uint32_t* start_offsets;
+    uint32_t n_start;
+    uint32_t* offsets;
+    uint32_t n_offsets;
+    uint32_t* table;
+    size_t n_table; /* including the padding added on load */
+};
+
+static int rd_u32(const uint8_t** p, const uint8_t* end, uint32_t* v) {
+    if (end - *p < 4) return 0;
+    memcpy(v, *p, 4);
+    *p += 4;
+    return 1;
+}
+
+static uint32_t* rd_u32s(const uint8_t** p, const uint8_t* end, size_t n, size_t pad) {
+    if ((size_t)(end - *p) < n * 4) return NULL;
+    uint32_t* v = (uint32_t*)calloc(n + pad + 1, 4);
+    if (!v) return NULL;
+    memcpy(v, *p, n * 4);
+    *p += n * 4;
+    return v;
+}
+
+oracle_dict* oracle_dict_load(int kind, const void* file_bytes, size_t len) {
+    const uint8_t* p = (const uint8_t*)file_bytes;
+    const uint8_t* end = p + len;
+    oracle_dict* d = (oracle_dict*)calloc(1, sizeof *d);
+    if (!d) return NULL;
+    d->kind = kind;
+    if (kind == ORACLE_RECT) {
+        /* builder::load, rectangular_dictionary.hpp:79-92: init() presets the
+         * reserved rows (sizes 1,1,256,128,64,32,16), then m_size rows are read
+         * over the start of the table. */
+        uint32_t size;
+        if (!rd_u32(&p, end, &size) || size > ENTRIES) goto fail;
+        d->size = size;
+        d->n_table = (size_t)ENTRIES * (MAX_ENTRY + 1);
+        d->table = (uint32_t*)calloc(d->n_table, 4);
+        if (!d->table) goto fail;
+        for (uint32_t i = 0; i < EXCEPTIONS_; ++i) d->table[i * 17 + 16] = 1;
+        for (uint32_t i = 0, s = 256; i < 5; ++i, s /= 2) d->table[(EXCEPTIONS_ + i) * 17 + 16] = s;
+        size_t bytes = (size_t)size * 17 * 4;
+        if ((size_t)(end - p) < bytes) goto fail;
+        memcpy(d->table, p, bytes);
+    } else if (kind == ORACLE_SINGLE_PACKED) {
+        /* builder::load, single_dictionary.hpp:88-107. The reference does not
+         * pad the table and copy() may read 15 words past it; here the
+         * allocation is padded so the same 64-byte memcpy stays in bounds. */
+        uint32_t n_off, n_tab;
+        if (!rd_u32(&p, end, &d->size) || !rd_u32(&p, end, &n_off) || !rd_u32(&p, end, &n_tab)) goto fail;
+        d->n_offsets = n_off;
+        d->offsets = rd_u32s(&p, end, n_off, 0);
+        d->table = rd_u32s(&p, end, n_tab, MAX_ENTRY);
+        d->n_table = (size_t)n_tab + MAX_ENTRY;
+        if (!d->offsets || !d->table) goto fail;
+    } else if (kind == ORACLE_MULTI_PACKED) {
+        /* builder::load, multi_dictionary.hpp:93-121 (table padded by 16, :108) */
+        uint32_t n_start, n_off, n_tab;
+        if (!rd_u32(&p, end, &d->size) || !rd_u32(&p, end, &n_start) || !rd_u32(&p, end, &n_off) ||
+            !rd_u32(&p, end, &n_tab))
+            goto fail;
+        if (n_start != NUM_SELECTORS) goto fail;
+        d->n_start = n_start;
+        d->n_offsets = n_off;
+        d->start_offsets = rd_u32s(&p, end, n_start, 0);
+        d->offsets = rd_u32s(&p, end, n_off, 0);
+        d->table = rd_u32s(&p, end, n_tab, MAX_ENTRY);
+        d->n_table = (size_t)n_tab + MAX_ENTRY;
+        if (!d->start_offsets || !d->offsets || !d->table) goto fail;
+    } else {
+        goto fail;
+    }
+    return d;
+fail:
+    oracle_dict_free(d);
+    return NULL;
+}
+
+void oracle_dict_free(oracle_dict* d) {
+    if (!d) return;
+    free(d->start_offsets);
+    free(d->offsets);
+    free(d->table);
+    free(d);
+}
+
+/* rectangular_dictionary::copy, rectangular_dictionary.hpp:206-213 */
+static inline uint32_t copy_rect(const oracle_dict* d, uint32_t i, uint32_t* out) {
+    const uint32_t* ptr = &d->table[(size_t)i * (MAX_ENTRY + 1)];
+    memcpy(out, ptr, MAX_ENTRY * sizeof(uint32_t));
+    return ptr[MAX_ENTRY];
+}
+
+/* single_dictionary::copy, single_dictionary.hpp:230-238 */
+static inline uint32_t copy_packed(const oracle_dict* d, uint32_t i, uint32_t* out) {
+    uint32_t size_and_offset = d->offsets[i];
+    uint32_t offset = size_and_offset & 0xFFFFFF;
+    uint32_t size = (size_and_offset >> 24) + 1;
+    memcpy(out, &d->table[offset], MAX_ENTRY * sizeof(uint32_t));
+    return size;
+}
+
+/* multi_dictionary::copy, multi_dictionary.hpp:293-304 */
+static inline uint32_t copy_multi(const oracle_dict* d, uint32_t dict_id, uint32_t i, uint32_t* out) {
+    uint32_t size_and_offset = d->offsets[d->start_offsets[dict_id] + i];
+    uint32_t offset = size_and_offset & 0xFFFFFF;
+    uint32_t size = (size_and_offset >> 24) + 1;
+    memcpy(out, &d->table[offset], MAX_ENTRY * sizeof(uint32_t));
+    return size;
+}
+
+uint32_t oracle_dict_copy(const oracle_dict* d, uint32_t dict_id, uint32_t i, uint32_t* out) {
+    switch (d->kind) {
+        case ORACLE_RECT: return copy_rect(d, i, out);
+        case ORACLE_SINGLE_PACKED: return copy_packed(d, i, out);
+        default: return copy_multi(d, dict_id, i, out);
+    }
+}
+
+/* TightVariableByte::decode, vroom_env/codecs.hpp:93-107 (n = 1) */
+const uint8_t* oracle_vbyte_read(const uint8_t* in, uint32_t* val) {
+    uint32_t v = 0;
+    for (unsigned shift = 0;; shift += 7) {
+        uint8_t c = *in++;
+        v += (uint32_t)(c & 127) << shift;
+        if (c & 128) {
+            *val = v;
+            return in;
+        }
+    }
+}
+
+/* header::read, vroom_env/codecs.hpp:117-123 */
+const uint8_t* oracle_header_read(const uint8_t* in, uint32_t* n, uint32_t* universe) {
+    in = oracle_vbyte_read(in, n);
+    return oracle_vbyte_read(in, universe);
+}
+
+static inline uint16_t ld16(const uint8_t* p) {
+    uint16_t v;
+    memcpy(&v, p, 2);
+    return v;
+}
+static inline uint32_t ld32(const uint8_t* p) {
+    uint32_t v;
+    memcpy(&v, p, 4);
+    return v;
+}
+
+/* single_dint::decode, vroom_env/dint_codecs.hpp:37-107. One body per
+ * dictionary type so the copy() is inlined as the template instantiation is. */
+#define SINGLE_BODY(COPY)                                                        \
+    const uint8_t* ptr = in;                                                     \
+    for (size_t i = 0; i != n; ptr += 2) {                                       \
+        uint32_t index = ld16(ptr);                                              \
+        uint32_t decoded_ints = 1;                                               \
+        if (__builtin_expect(index > EXCEPTIONS_ - 1, 1)) {                      \
+            decoded_ints = COPY(d, index, out);                                  \
+        } else if (index == 1) { /* 4-byte exception: 3 slots in all */          \
+            ptr += 2;                                                            \
+            *out = ld32(ptr);                                                    \
+            ptr += 2;                                                            \
+        } else { /* 2-byte exception: 2 slots in all */                          \
+            ptr += 2;                                                            \
+            *out = ld16(ptr);                                                    \
+        }                                                                        \
+        out += decoded_ints;                                                     \
+        i += decoded_ints;                                                       \
+    }                                                                            \
+    return ptr;
+
+static const uint8_t* decode_single_rect(const oracle_dict* d, const uint8_t* in, uint32_t* out, size_t n) {
+    SINGLE_BODY(copy_rect)
+}
+static const uint8_t* decode_single_packed(const oracle_dict* d, const uint8_t* in, uint32_t* out, size_t n) {
+    SINGLE_BODY(copy_packed)
+}
+
+const uint8_t* oracle_decode_single(const oracle_dict* d, const uint8_t* in, uint32_t* out, size_t n) {
+    return d->kind == ORACLE_RECT ? decode_single_rect(d, in, out, n) : decode_single_packed(d, in, out, n);
+}
+
+/* multi_opt_dint::decode, vroom_env/dint_codecs.hpp:521-619 */
+const uint8_t* oracle_decode_multi(const oracle_dict* d, const uint8_t* in, uint32_t* out, size_t n) {
+    size_t num_blocks = (n + BLOCK - 1) / BLOCK;
+    size_t tail = n - (n / BLOCK * BLOCK);
+    for (size_t b = 0; b != num_blocks; ++b) {
+        size_t size = BLOCK;
+        if (b == num_blocks - 1 && tail != 0) size = tail;
+        uint8_t selector_code = *in;
+        if (selector_code < NUM_SELECTORS) {
+            const uint8_t* ptr = in + 1;
+            for (size_t i = 0; i != size; ptr += 2) {
+                uint32_t index = ld16(ptr);
+                uint32_t decoded_ints = 1;
+                if (__builtin_expect(index > EXCEPTIONS_ - 1, 1)) {
+                    decoded_ints = copy_multi(d, selector_code, index, out);
+                } else if (index == 1) {
+                    ptr += 2;
+                    *out = ld32(ptr);
+                    ptr += 2;
+                } else {
+                    ptr += 2;
+                    *out = ld16(ptr);
+                }
+                out += decoded_ints;
+                i += decoded_ints;
+            }
+            in = ptr;
+        } else {
+            selector_code -= NUM_SELECTORS;
+            const uint8_t* ptr = in + 1;
+            for (size_t i = 0; i != size; ++ptr) {
+                uint32_t index = *ptr;
+                uint32_t decoded_ints = 1;
+                if (__builtin_expect(index > EXCEPTIONS_ - 1, 1)) {
+                    decoded_ints = copy_multi(d, selector_code, index, out);
+                } else if (index == 1) { /* 1 + 4 bytes */
+                    ++ptr;
+                    *out = ld32(ptr);
+                    ptr += 3;
+                } else { /* 1 + 2 bytes */
+                    ++ptr;
+                    *out = ld16(ptr);
+                    ptr += 1;
+                }
+                out += decoded_ints;
+                i += decoded_ints;
+            }
+            in = ptr;
+        }
+    }
+    return in;
+}
+
+const uint8_t* oracle_decode_list(const oracle_dict* d, const uint8_t* in, uint32_t* out, size_t n) {
+    return d->kind == ORACLE_MULTI_PACKED ? oracle_decode_multi(d, in, out, n) : oracle_decode_single(d, in, out, n);
+}
+
+/* vroom_env/decode.cpp:139-150 framing + check_encoded_data.cpp:104-109 zeroing */
+uint64_t oracle_decode_stream(const oracle_dict* d, const uint8_t* enc, size_t enc_bytes, uint32_t* out,
+                              uint64_t out_cap, uint64_t* n_lists) {
+    const uint8_t* begin = enc;
+    const uint8_t* end = enc + enc_bytes;
+    uint64_t total = 0, lists = 0;
+    uint32_t* buf = NULL;
+    size_t buf_cap = 0;
+    while (begin != end) {
+        uint32_t n, universe;
+        begin = oracle_header_read(begin, &n, &universe);
+        size_t need = (size_t)n + BLOCK + MAX_ENTRY;
+        if (need > buf_cap) {
+            free(buf);
+            buf_cap = need * 2;
+            buf = (uint32_t*)malloc(buf_cap * 4);
+            if (!buf) return (uint64_t)-1;
+        }
+        memset(buf, 0, need * 4);
+        begin = oracle_decode_list(d, begin, buf, n);
+        if (out) {
+            if (total + n > out_cap) {
+                free(buf);
+                return (uint64_t)-1;
+            }
+            memcpy(out + total, buf, (size_t)n * 4);
+        }
+        total += n;
+        ++lists;
+        if (begin > end) break;
+    }
+    free(buf);
+    if (n_lists) *n_lists = lists;
+    return total;
+}
+
+static double now_sec(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* vroom_env/decode.cpp:125-155 */
+double oracle_time_stream(const oracle_dict* d, const uint8_t* enc, size_t enc_bytes, uint64_t max_lists,
+                          double max_seconds, uint64_t* ints_decoded, uint64_t* lists_decoded) {
+    const uint8_t* begin = enc;
+    const uint8_t* end = enc + enc_bytes;
+    uint32_t* decoded = (uint32_t*)calloc((size_t)MAX_LIST + BLOCK + MAX_ENTRY, 4); /* zeroed ONCE, :128-129 */
+    if (!decoded) return -1.0;
+    double elapsed = 0.0;
+    uint64_t ints = 0, lists = 0;
+    while (begin != end) {
+        uint32_t n, universe;
+        begin = oracle_header_read(begin, &n, &universe);
+        double t0 = now_sec();
+        begin = oracle_decode_list(d, begin, decoded, n);
+        double t1 = now_sec();
+        elapsed += t1 - t0;
+        ints += n;
+        ++lists;
+        if (max_lists && lists >= max_lists) break;
+        if (max_seconds > 0 && elapsed >= max_seconds) break;
+    }
+    /* keep the result observable */
+    volatile uint32_t sink = decoded[0];
+    (void)sink;
+    free(decoded);
+    if (ints_decoded) *ints_decoded = ints;
+    if (lists_decoded) *lists_decoded = lists;
+    return elapsed;
+}

@@ -1,0 +1,76 @@
+/*
+ * dint_oracle.h — CPU restatement of the reference's DINT decode path.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT. Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library, and only as the checker
+ * (or, in bench.py, as the timed CPU baseline). The product path
+ * (dint_amd/, include/dint_hip.h) never links, imports or calls it.
+ *
+ * PARITY UNPINNED. The reference (jermp/dint) cannot be built in this image:
+ * its hot-path headers include <succinct/mappable_vector.hpp>,
+ * <succinct/broadword.hpp> and Boost, whose submodules/packages are absent
+ * (external/ is empty, /usr/include/boost does not exist), and writing
+ * stand-ins for them is not allowed. The reference also ships no golden
+ * vectors or tests for DINT (test/ covers the inherited ds2i codecs only).
+ * This file is therefore a line-by-line restatement from reading the source;
+ * every function cites the reference lines it follows. What IS checked:
+ * hand-assembled known-answer streams built from the byte format
+ * (tests/golden/), round trips encode -> decode == input (the reference's own
+ * correctness contract, vroom_env/check_encoded_data.cpp:76-113), and the
+ * MurmurHash64A key function against the one reference file that does compile
+ * stand-alone (oracle/_ref, include/dint/hash_utils.hpp).
+ */
+#ifndef DINT_ORACLE_H
+#define DINT_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORACLE_RECT = 0, ORACLE_SINGLE_PACKED = 1, ORACLE_MULTI_PACKED = 2 };
+
+typedef struct oracle_dict oracle_dict;
+
+/* Parse a dictionary file image as the reference's builder::load does, then
+ * "build(dict)" (steal the vectors). Returns NULL on a malformed image. */
+oracle_dict* oracle_dict_load(int kind, const void* file_bytes, size_t len);
+void oracle_dict_free(oracle_dict* d);
+/* Dictionary::copy(i, out) / copy(dict_id, i, out): always writes 16 words,
+ * returns the logical size. */
+uint32_t oracle_dict_copy(const oracle_dict* d, uint32_t dict_id, uint32_t i, uint32_t* out);
+
+/* TightVariableByte::decode of one value; returns the advanced pointer. */
+const uint8_t* oracle_vbyte_read(const uint8_t* in, uint32_t* val);
+/* header::read */
+const uint8_t* oracle_header_read(const uint8_t* in, uint32_t* n, uint32_t* universe);
+
+/* single_dint::decode (rect and single_packed dictionaries) and
+ * multi_opt_dint::decode. `out` must be zero on entry and have room for
+ * n + 256 words (the reference's overflow area). Return the advanced input
+ * pointer. */
+const uint8_t* oracle_decode_single(const oracle_dict* d, const uint8_t* in, uint32_t* out, size_t n);
+const uint8_t* oracle_decode_multi(const oracle_dict* d, const uint8_t* in, uint32_t* out, size_t n);
+/* dispatch on the dictionary kind */
+const uint8_t* oracle_decode_list(const oracle_dict* d, const uint8_t* in, uint32_t* out, size_t n);
+
+/* The decode.cpp loop over a whole vroom stream, with the output buffer
+ * re-zeroed before every list as check_encoded_data.cpp does.
+ * out (may be NULL) receives all lists back to back: capacity out_cap words.
+ * Returns the number of integers decoded, or (uint64_t)-1 on overrun. */
+uint64_t oracle_decode_stream(const oracle_dict* d, const uint8_t* enc, size_t enc_bytes, uint32_t* out,
+                              uint64_t out_cap, uint64_t* n_lists);
+
+/* The reference benchmark (vroom_env/decode.cpp:125-155): ONE output buffer of
+ * max_size words zeroed once and reused, per-list steady-clock time around the
+ * decode call only, summed. Stops after max_lists lists (0 = all) or when
+ * max_seconds of summed decode time is exceeded (0 = no limit). */
+double oracle_time_stream(const oracle_dict* d, const uint8_t* enc, size_t enc_bytes, uint64_t max_lists,
+                          double max_seconds, uint64_t* ints_decoded, uint64_t* lists_decoded);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

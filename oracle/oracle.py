@@ -1,0 +1,109 @@
+"""ctypes binding of oracle/liboracle.so (see oracle/dint_oracle.h).
+
+TEST INFRASTRUCTURE. Importable only from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg; the product package (dint_amd/) never imports it.
+PARITY UNPINNED: the reference cannot be built here (see dint_oracle.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+
+RECT, SINGLE_PACKED, MULTI_PACKED = 0, 1, 2
+
+
+def build(quiet: bool = True) -> None:
+    subprocess.run(["make", "-C", _HERE, "all"], check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+
+
+def _load():
+    if not os.path.exists(_LIB):
+        build()
+    lib = C.CDLL(_LIB)
+    vp = C.c_void_p
+    lib.oracle_dict_load.restype = vp
+    lib.oracle_dict_load.argtypes = [C.c_int, vp, C.c_size_t]
+    lib.oracle_dict_free.restype = None
+    lib.oracle_dict_free.argtypes = [vp]
+    lib.oracle_dict_copy.restype = C.c_uint32
+    lib.oracle_dict_copy.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+    lib.oracle_decode_list.restype = vp
+    lib.oracle_decode_list.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.oracle_header_read.restype = vp
+    lib.oracle_header_read.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.oracle_decode_stream.restype = C.c_uint64
+    lib.oracle_decode_stream.argtypes = [vp, vp, C.c_size_t, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.oracle_time_stream.restype = C.c_double
+    lib.oracle_time_stream.argtypes = [vp, vp, C.c_size_t, C.c_uint64, C.c_double,
+                                       C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    return lib
+
+
+_lib = _load()
+
+
+class OracleDict:
+    def __init__(self, kind: int, file_bytes: bytes):
+        self.kind = kind
+        self._buf = (C.c_char * len(file_bytes)).from_buffer_copy(file_bytes)
+        self._h = _lib.oracle_dict_load(kind, C.addressof(self._buf), len(file_bytes))
+        if not self._h:
+            raise ValueError("oracle: malformed dictionary file")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.oracle_dict_free(h)
+
+    def copy(self, index: int, dict_id: int = 0):
+        """Dictionary::copy — (logical size, the 16 words it writes)."""
+        out = np.zeros(16, dtype=np.uint32)
+        size = _lib.oracle_dict_copy(self._h, dict_id, index, out.ctypes.data)
+        return int(size), out
+
+    def decode_list(self, enc: np.ndarray, offset: int, n: int):
+        """Decoder::decode(dict, in, out, universe, n) -> (out[0:n], bytes consumed)."""
+        enc = np.ascontiguousarray(enc, dtype=np.uint8)
+        out = np.zeros(n + 256 + 16, dtype=np.uint32)  # zeroed, with the overflow area
+        base = enc.ctypes.data + offset
+        end = _lib.oracle_decode_list(self._h, base, out.ctypes.data, n)
+        return out[:n].copy(), int(end - base)
+
+    def decode_stream(self, enc: np.ndarray, total_ints: int | None = None):
+        """vroom_env/decode.cpp loop -> (all lists' integers back to back, number of lists)."""
+        enc = np.ascontiguousarray(enc, dtype=np.uint8)
+        if total_ints is None:
+            total_ints = int(_lib.oracle_decode_stream(self._h, enc.ctypes.data, enc.size, None, 0, None))
+        out = np.empty(total_ints, dtype=np.uint32)
+        lists = C.c_uint64()
+        got = _lib.oracle_decode_stream(self._h, enc.ctypes.data, enc.size, out.ctypes.data, out.size,
+                                        C.byref(lists))
+        if got != total_ints:
+            raise ValueError(f"oracle: decoded {got} integers, expected {total_ints}")
+        return out, lists.value
+
+    def time_stream(self, enc: np.ndarray, max_lists: int = 0, max_seconds: float = 0.0):
+        """Reference benchmark loop -> (summed decode seconds, ints, lists)."""
+        enc = np.ascontiguousarray(enc, dtype=np.uint8)
+        ints, lists = C.c_uint64(), C.c_uint64()
+        sec = _lib.oracle_time_stream(self._h, enc.ctypes.data, enc.size, max_lists, max_seconds,
+                                      C.byref(ints), C.byref(lists))
+        if sec < 0:
+            raise MemoryError("oracle: could not allocate the 50M-int decode buffer")
+        return sec, ints.value, lists.value
+
+
+def header_read(enc: np.ndarray, offset: int):
+    """header::read -> (n, universe, offset of the payload)."""
+    enc = np.ascontiguousarray(enc, dtype=np.uint8)
+    n, u = C.c_uint32(), C.c_uint32()
+    base = enc.ctypes.data
+    end = _lib.oracle_header_read(base + offset, C.byref(n), C.byref(u))
+    return n.value, u.value, int(end - base)
