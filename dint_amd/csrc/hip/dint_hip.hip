@@ -1,0 +1,528 @@
+// C ABI of the device decode path (include/dint_hip.h): dictionary staging,
+// the host indexing pre-pass, and the kernel launches.
+#include "dint_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "dint_kernels.hpp"
+
+namespace {
+
+using namespace dint_dev;
+
+constexpr uint32_t kEntries = 65536;   // reference dint_configuration.hpp:27
+constexpr uint32_t kMaxEntry = 16;     // :25
+constexpr uint32_t kSelectors = 6;     // :20
+constexpr uint32_t kReserved = 7;      // EXCEPTIONS + 5 run codewords
+constexpr uint32_t kBlock = 256;       // util.hpp:35
+
+thread_local std::string g_hip_error;
+
+bool hip_ok(hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    g_hip_error = std::string(what) + ": " + hipGetErrorString(e);
+    return false;
+}
+#define HIP_TRY(call)                                  \
+    do {                                               \
+        if (!hip_ok((call), #call)) return DINT_ERR_HIP; \
+    } while (0)
+
+struct reader {
+    const uint8_t* p;
+    const uint8_t* end;
+    bool u32(uint32_t* v) {
+        if (end - p < 4) return false;
+        std::memcpy(v, p, 4);
+        p += 4;
+        return true;
+    }
+    bool u32s(std::vector<uint32_t>& dst, size_t n) {
+        if (size_t(end - p) < n * 4) return false;
+        dst.resize(n);
+        if (n) std::memcpy(dst.data(), p, n * 4);
+        p += n * 4;
+        return true;
+    }
+};
+
+// Host-side normal form shared by the three file formats: per dictionary a list
+// of (size, payload pointer) in codeword order.
+struct parsed_dict {
+    uint32_t num_dicts = 1;
+    uint32_t entries = 0;                    // m_size of the file
+    std::vector<uint32_t> start;             // first meta slot of each dictionary (+ end)
+    std::vector<uint32_t> size;              // per meta slot
+    std::vector<uint32_t> off;               // per meta slot: word offset into `table`
+    std::vector<uint32_t> table;             // payload words
+};
+
+bool parse_rectangular(reader r, parsed_dict& d) {
+    // u32 m_size, u32 table[m_size * 17]   (rectangular_dictionary.hpp:72-92)
+    uint32_t m_size;
+    if (!r.u32(&m_size) || m_size > kEntries) return false;
+    std::vector<uint32_t> rows;
+    if (!r.u32s(rows, size_t(m_size) * (kMaxEntry + 1))) return false;
+    d.num_dicts = 1;
+    d.entries = m_size;
+    d.start = {0, kEntries};
+    d.size.assign(kEntries, 1);
+    d.off.assign(kEntries, 0);
+    d.table.assign(kMaxEntry, 0);
+    // builder::init() presets the reserved rows; the file then overwrites them
+    for (uint32_t i = 2; i != kReserved; ++i) d.size[i] = 256u >> (i - 2);
+    for (uint32_t i = 0; i != m_size; ++i) {
+        const uint32_t* row = &rows[size_t(i) * (kMaxEntry + 1)];
+        uint32_t s = row[kMaxEntry];
+        if (s == 0 || s > 256) return false;
+        d.size[i] = s;
+        if (s <= kMaxEntry && i >= kReserved) {
+            d.off[i] = uint32_t(d.table.size());
+            d.table.insert(d.table.end(), row, row + s);
+        } else {
+            d.off[i] = 0;  // runs copy zeros
+        }
+    }
+    return true;
+}
+
+bool parse_packed(reader r, bool multi, parsed_dict& d) {
+    // single: u32 m_size, n_off, n_tab, offsets[], table[]          (single_dictionary.hpp:72-107)
+    // multi : u32 m_size, n_start, n_off, n_tab, start[], offsets[], table[] (multi_dictionary.hpp:70-121)
+    uint32_t m_size, n_start = 0, n_off, n_tab;
+    if (!r.u32(&m_size)) return false;
+    if (multi && !r.u32(&n_start)) return false;
+    if (!r.u32(&n_off) || !r.u32(&n_tab)) return false;
+    std::vector<uint32_t> starts, offsets;
+    if (multi && (n_start != kSelectors || !r.u32s(starts, n_start))) return false;
+    if (!r.u32s(offsets, n_off) || !r.u32s(d.table, n_tab)) return false;
+    d.entries = m_size;
+    if (multi) {
+        d.num_dicts = kSelectors;
+        d.start = starts;
+        d.start.push_back(n_off);
+        for (uint32_t k = 0; k != kSelectors; ++k)
+            if (d.start[k] > d.start[k + 1]) return false;
+    } else {
+        d.num_dicts = 1;
+        d.start = {0, std::max(n_off, kEntries)};
+    }
+    size_t slots = d.start.back();
+    d.size.assign(slots, 1);
+    d.off.assign(slots, 0);
+    for (uint32_t i = 0; i != n_off; ++i) {
+        uint32_t s = (offsets[i] >> 24) + 1, o = offsets[i] & 0xFFFFFF;
+        d.size[i] = s;
+        d.off[i] = o;
+        // a copy() of entry i reads `s` words (runs: only ever zeros at offset 0)
+        if (s <= kMaxEntry && size_t(o) + s > d.table.size()) return false;
+        if (s > kMaxEntry && o != 0) return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+struct dint_dict {
+    int kind = 0;
+    int device = 0;
+    uint32_t num_dicts = 1;
+    uint32_t entries = 0;
+    uint32_t compute_units = 0;
+    // host copies used by dint_index_stream
+    std::vector<uint32_t> h_start;  // per dictionary first meta slot (+ end)
+    std::vector<uint32_t> h_size;   // per meta slot
+    // device buffers
+    uint32_t* d_gmeta = nullptr;
+    uint32_t* d_gtable = nullptr;
+    uint32_t* d_image = nullptr;
+    dint_dev::dict_view view{};
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+};
+
+namespace {
+
+// Build the device layout:
+//   gtable = [256 zeros][file payload words]; gmeta[slot] = (size-1)<<24 | offset
+//   LDS image = [hot meta: hot_k words][256 zeros][hot payload], hot = codewords
+//   < hot_k of the (single) dictionary — the DSF builder appends entries in
+//   decreasing corpus frequency (dictionary_builders.hpp:61-72), so "index < K"
+//   is the hotness test.
+int stage_dictionary(dint_dict& dd, parsed_dict const& pd) {
+    const size_t slots = pd.size.size();
+    std::vector<uint32_t> gmeta(slots);
+    std::vector<uint32_t> gtable(kZeroWords, 0);
+    gtable.insert(gtable.end(), pd.table.begin(), pd.table.end());
+    if (gtable.size() >= kColdBase) return DINT_ERR_FORMAT;
+    for (size_t i = 0; i != slots; ++i) {
+        uint32_t s = pd.size[i];
+        uint32_t o = s > kMaxEntry ? 0 : pd.off[i] + kZeroWords;
+        gmeta[i] = ((s - 1) << 24) | o;
+    }
+
+    // hot set of dictionary 0 (single kinds); multi keeps everything cold for now
+    uint32_t hot_k = 0;
+    std::vector<uint32_t> image;
+    if (pd.num_dicts == 1) {
+        const uint32_t limit = std::min<uint32_t>(uint32_t(slots), kEntries);
+        uint64_t payload = 0;
+        uint32_t k = 0;
+        for (; k != limit; ++k) {
+            uint32_t s = pd.size[k];
+            uint64_t add = (k >= kReserved && s <= kMaxEntry) ? s : 0;
+            if (uint64_t(k + 1) + kZeroWords + payload + add + 3 > kHotImageWords) break;
+            payload += add;
+        }
+        hot_k = k;
+        image.assign(hot_k, 0);
+        image.resize(size_t(hot_k) + kZeroWords, 0);
+        const uint32_t zero_off = hot_k;
+        for (uint32_t i = 0; i != hot_k; ++i) {
+            uint32_t s = pd.size[i];
+            uint32_t o = zero_off;
+            if (i >= kReserved && s <= kMaxEntry) {
+                o = uint32_t(image.size());
+                for (uint32_t w = 0; w != s; ++w) image.push_back(pd.table[pd.off[i] + w]);
+            }
+            image[i] = ((s - 1) << 24) | o;
+        }
+    }
+    while (image.size() % 4) image.push_back(0);
+    if (image.size() > kHotImageWords) return DINT_ERR_FORMAT;
+
+    HIP_TRY(hipSetDevice(dd.device));
+    HIP_TRY(hipMalloc(&dd.d_gmeta, gmeta.size() * 4));
+    HIP_TRY(hipMalloc(&dd.d_gtable, gtable.size() * 4));
+    HIP_TRY(hipMalloc(&dd.d_image, std::max<size_t>(16, image.size() * 4)));
+    HIP_TRY(hipMemcpy(dd.d_gmeta, gmeta.data(), gmeta.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dd.d_gtable, gtable.data(), gtable.size() * 4, hipMemcpyHostToDevice));
+    if (!image.empty()) HIP_TRY(hipMemcpy(dd.d_image, image.data(), image.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipEventCreate(&dd.ev_start));
+    HIP_TRY(hipEventCreate(&dd.ev_stop));
+    dd.view.gmeta = dd.d_gmeta;
+    dd.view.gtable = dd.d_gtable;
+    dd.view.lds_image = dd.d_image;
+    dd.view.gtable_words = uint32_t(gtable.size());
+    dd.view.hot_words = uint32_t(image.size());
+    dd.view.hot_k = hot_k;
+    return DINT_OK;
+}
+
+inline uint16_t ld16(const uint8_t* p) {
+    uint16_t v;
+    std::memcpy(&v, p, 2);
+    return v;
+}
+
+const uint8_t* read_vbyte(const uint8_t* in, const uint8_t* end, uint32_t* val) {
+    uint32_t v = 0;
+    for (unsigned shift = 0; in != end; shift += 7) {
+        uint8_t c = *in++;
+        v += uint32_t(c & 127) << (shift & 31);
+        if (c & 128) {
+            *val = v;
+            return in;
+        }
+    }
+    return nullptr;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dint_abi_version(void) { return DINT_ABI_VERSION; }
+
+const char* dint_strerror(int status) {
+    switch (status) {
+        case DINT_OK: return "ok";
+        case DINT_ERR_ARG: return "bad argument";
+        case DINT_ERR_FORMAT: return "malformed dictionary or stream";
+        case DINT_ERR_HIP: return "HIP runtime error";
+        case DINT_ERR_NO_DEVICE: return "no such device";
+        case DINT_ERR_NOMEM: return "out of memory";
+        default: return "unknown status";
+    }
+}
+
+const char* dint_last_hip_error(void) { return g_hip_error.c_str(); }
+
+int dint_device_count(int* count) {
+    if (!count) return DINT_ERR_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return DINT_OK;
+}
+
+int dint_dict_create(int kind, const void* file_bytes, size_t len, int device, dint_dict** out) {
+    if (!file_bytes || !out) return DINT_ERR_ARG;
+    *out = nullptr;
+    parsed_dict pd;
+    reader r{static_cast<const uint8_t*>(file_bytes), static_cast<const uint8_t*>(file_bytes) + len};
+    bool ok;
+    switch (kind) {
+        case DINT_DICT_RECTANGULAR: ok = parse_rectangular(r, pd); break;
+        case DINT_DICT_SINGLE_PACKED: ok = parse_packed(r, false, pd); break;
+        case DINT_DICT_MULTI_PACKED: ok = parse_packed(r, true, pd); break;
+        default: return DINT_ERR_ARG;
+    }
+    if (!ok) return DINT_ERR_FORMAT;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        (void)hipGetLastError();
+        return DINT_ERR_NO_DEVICE;
+    }
+    dint_dict* dd = new (std::nothrow) dint_dict;
+    if (!dd) return DINT_ERR_NOMEM;
+    dd->kind = kind;
+    dd->device = device;
+    dd->num_dicts = pd.num_dicts;
+    dd->entries = pd.entries;
+    dd->h_start = pd.start;
+    dd->h_size = pd.size;
+    hipDeviceProp_t prop;
+    if (!hip_ok(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties")) {
+        delete dd;
+        return DINT_ERR_HIP;
+    }
+    dd->compute_units = uint32_t(prop.multiProcessorCount);
+    int st = stage_dictionary(*dd, pd);
+    if (st != DINT_OK) {
+        dint_dict_destroy(dd);
+        return st;
+    }
+    // the kernel needs the whole 160 KiB of LDS
+    if (!hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_single_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsWords * 4)),
+                "hipFuncSetAttribute")) {
+        dint_dict_destroy(dd);
+        return DINT_ERR_HIP;
+    }
+    *out = dd;
+    return DINT_OK;
+}
+
+void dint_dict_destroy(dint_dict* dd) {
+    if (!dd) return;
+    (void)hipSetDevice(dd->device);
+    if (dd->d_gmeta) (void)hipFree(dd->d_gmeta);
+    if (dd->d_gtable) (void)hipFree(dd->d_gtable);
+    if (dd->d_image) (void)hipFree(dd->d_image);
+    if (dd->ev_start) (void)hipEventDestroy(dd->ev_start);
+    if (dd->ev_stop) (void)hipEventDestroy(dd->ev_stop);
+    delete dd;
+}
+
+int dint_dict_info_get(const dint_dict* dd, dint_dict_info* info) {
+    if (!dd || !info) return DINT_ERR_ARG;
+    info->kind = dd->kind;
+    info->device = dd->device;
+    info->num_dicts = dd->num_dicts;
+    info->entries = dd->entries;
+    info->hot_entries = dd->view.hot_k;
+    info->lds_bytes = dd->view.hot_words * 4;
+    info->table_words = dd->view.gtable_words;
+    info->compute_units = dd->compute_units;
+    return DINT_OK;
+}
+
+void dint_free(void* p) { std::free(p); }
+
+int dint_index_stream(const dint_dict* dd, const uint8_t* enc, size_t enc_bytes, uint32_t unit_ints,
+                      dint_unit** units_out, size_t* n_units, uint64_t* total_ints, uint64_t* n_lists) {
+    if (!dd || (!enc && enc_bytes) || !units_out || !n_units) return DINT_ERR_ARG;
+    std::vector<dint_unit> units;
+    const uint8_t* p = enc;
+    const uint8_t* end = enc + enc_bytes;
+    uint64_t out_pos = 0, lists = 0;
+    const bool multi = dd->kind == DINT_DICT_MULTI_PACKED;
+    const uint32_t cut = unit_ints ? unit_ints : ~0u;
+    while (p != end) {
+        uint32_t n, universe;
+        p = read_vbyte(p, end, &n);
+        if (p) p = read_vbyte(p, end, &universe);
+        if (!p) return DINT_ERR_FORMAT;
+        uint32_t unit_start_int = 0;
+        const uint8_t* unit_start = p;
+        auto close_unit = [&](const uint8_t* at, uint32_t upto) {
+            if (upto == unit_start_int) return;
+            units.push_back({uint64_t(unit_start - enc), out_pos + unit_start_int, upto - unit_start_int,
+                             uint32_t(lists)});
+            unit_start = at;
+            unit_start_int = upto;
+        };
+        if (!multi) {
+            const uint32_t* size = dd->h_size.data();
+            uint32_t i = 0;
+            while (i < n) {
+                if (i - unit_start_int >= cut) close_unit(p, i);
+                if (end - p < 2) return DINT_ERR_FORMAT;
+                uint32_t idx = ld16(p);
+                if (idx >= 2) {
+                    i += size[idx];
+                    p += 2;
+                } else {
+                    i += 1;
+                    p += idx == 1 ? 6 : 4;
+                }
+                if (p > end) return DINT_ERR_FORMAT;
+            }
+            if (i != n) return DINT_ERR_FORMAT;
+            close_unit(p, n);
+        } else {
+            // one selector byte per 256 integers (vroom_env/dint_codecs.hpp:521-619)
+            uint32_t done = 0;
+            const uint32_t blocks_per_unit = unit_ints ? std::max<uint32_t>(1, (unit_ints + kBlock - 1) / kBlock) : ~0u;
+            uint32_t blocks_in_unit = 0;
+            while (done < n) {
+                if (blocks_in_unit == blocks_per_unit) {
+                    close_unit(p, done);
+                    blocks_in_unit = 0;
+                }
+                uint32_t bsize = std::min<uint32_t>(kBlock, n - done);
+                if (p == end) return DINT_ERR_FORMAT;
+                uint32_t sc = *p++;
+                if (sc >= 2 * kSelectors) return DINT_ERR_FORMAT;
+                const bool narrow = sc >= kSelectors;
+                const uint32_t dsel = narrow ? sc - kSelectors : sc;
+                const uint32_t base = dd->h_start[dsel];
+                const uint32_t limit = dd->h_start[dsel + 1] - base;
+                uint32_t i = 0;
+                while (i < bsize) {
+                    if (end - p < (narrow ? 1 : 2)) return DINT_ERR_FORMAT;
+                    uint32_t idx = narrow ? *p : ld16(p);
+                    if (idx >= 2) {
+                        if (idx >= limit) return DINT_ERR_FORMAT;
+                        i += dd->h_size[base + idx];
+                        p += narrow ? 1 : 2;
+                    } else {
+                        i += 1;
+                        p += (narrow ? 1 : 2) + (idx == 1 ? 4 : 2);
+                    }
+                    if (p > end) return DINT_ERR_FORMAT;
+                }
+                if (i != bsize) return DINT_ERR_FORMAT;
+                done += bsize;
+                ++blocks_in_unit;
+            }
+            close_unit(p, n);
+        }
+        out_pos += n;
+        ++lists;
+    }
+    dint_unit* mem = static_cast<dint_unit*>(std::malloc(std::max<size_t>(1, units.size()) * sizeof(dint_unit)));
+    if (!mem) return DINT_ERR_NOMEM;
+    if (!units.empty()) std::memcpy(mem, units.data(), units.size() * sizeof(dint_unit));
+    *units_out = mem;
+    *n_units = units.size();
+    if (total_ints) *total_ints = out_pos;
+    if (n_lists) *n_lists = lists;
+    return DINT_OK;
+}
+
+int dint_decode_units(const dint_dict* dd, const uint8_t* d_enc, size_t enc_bytes, const dint_unit* d_units,
+                      size_t n_units, uint32_t* d_out, size_t out_capacity, uint64_t* d_end_off, void* stream) {
+    if (!dd) return DINT_ERR_ARG;
+    if (n_units == 0) return DINT_OK;
+    if (!d_enc || !d_units || !d_out || enc_bytes < 2) return DINT_ERR_ARG;
+    if (dd->kind == DINT_DICT_MULTI_PACKED) return DINT_ERR_ARG;  // multi kernel: see decode_multi (next)
+    HIP_TRY(hipSetDevice(dd->device));
+    decode_args a{};
+    a.dict = dd->view;
+    a.enc = d_enc;
+    a.enc_bytes = enc_bytes;
+    a.units = d_units;
+    a.n_units = n_units;
+    a.out = d_out;
+    a.out_capacity = out_capacity;
+    a.end_off = d_end_off;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint64_t blocks_needed = (uint64_t(n_units) + kWavesPerBlock - 1) / kWavesPerBlock;
+    const uint32_t grid = uint32_t(std::min<uint64_t>(blocks_needed, std::max<uint32_t>(1, dd->compute_units)));
+    const size_t lds_bytes = (size_t(dd->view.hot_words) + kWavesPerBlock * kScratchWords) * 4;
+    dint_dict* mut = const_cast<dint_dict*>(dd);
+    HIP_TRY(hipEventRecord(mut->ev_start, s));
+    hipLaunchKernelGGL(decode_single_kernel, dim3(grid), dim3(kBlockThreads), lds_bytes, s, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(mut->ev_stop, s));
+    mut->timed = true;
+    return DINT_OK;
+}
+
+int dint_last_kernel_ms(const dint_dict* dd, float* ms) {
+    if (!dd || !ms || !dd->timed) return DINT_ERR_ARG;
+    HIP_TRY(hipEventSynchronize(dd->ev_stop));
+    HIP_TRY(hipEventElapsedTime(ms, dd->ev_start, dd->ev_stop));
+    return DINT_OK;
+}
+
+int dint_decode_list_host(const dint_dict* dd, const uint8_t* in, size_t in_bytes, uint32_t* out, size_t n,
+                          size_t* consumed) {
+    if (!dd || (!in && in_bytes) || (!out && n)) return DINT_ERR_ARG;
+    if (consumed) *consumed = 0;
+    if (n == 0) return DINT_OK;
+    if (in_bytes < 2 || n > 0xFFFFFFFFull) return DINT_ERR_ARG;
+    HIP_TRY(hipSetDevice(dd->device));
+    uint8_t* d_enc = nullptr;
+    uint32_t* d_out = nullptr;
+    dint_unit* d_unit = nullptr;
+    uint64_t* d_end = nullptr;
+    int st = DINT_OK;
+    auto cleanup = [&] {
+        if (d_enc) (void)hipFree(d_enc);
+        if (d_out) (void)hipFree(d_out);
+        if (d_unit) (void)hipFree(d_unit);
+        if (d_end) (void)hipFree(d_end);
+    };
+#define TRY_OR_CLEAN(call)                 \
+    do {                                   \
+        if (!hip_ok((call), #call)) {      \
+            cleanup();                     \
+            return DINT_ERR_HIP;           \
+        }                                  \
+    } while (0)
+    TRY_OR_CLEAN(hipMalloc(&d_enc, in_bytes));
+    TRY_OR_CLEAN(hipMalloc(&d_out, n * 4));
+    TRY_OR_CLEAN(hipMalloc(&d_unit, sizeof(dint_unit)));
+    TRY_OR_CLEAN(hipMalloc(&d_end, 8));
+    dint_unit u{0, 0, uint32_t(n), 0};
+    TRY_OR_CLEAN(hipMemcpy(d_enc, in, in_bytes, hipMemcpyHostToDevice));
+    TRY_OR_CLEAN(hipMemcpy(d_unit, &u, sizeof u, hipMemcpyHostToDevice));
+    st = dint_decode_units(dd, d_enc, in_bytes, d_unit, 1, d_out, n, d_end, nullptr);
+    if (st == DINT_OK) {
+        TRY_OR_CLEAN(hipDeviceSynchronize());
+        uint64_t end_off = 0;
+        TRY_OR_CLEAN(hipMemcpy(out, d_out, n * 4, hipMemcpyDeviceToHost));
+        TRY_OR_CLEAN(hipMemcpy(&end_off, d_end, 8, hipMemcpyDeviceToHost));
+        if (consumed) *consumed = size_t(end_off);
+    }
+#undef TRY_OR_CLEAN
+    cleanup();
+    return st;
+}
+
+// Test hook (not part of the decode ABI): inclusive wave prefix sum of 64 host words.
+int dint_debug_wave_scan(const uint32_t* in64, uint32_t* out64) {
+    if (!in64 || !out64) return DINT_ERR_ARG;
+    uint32_t *d_in = nullptr, *d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_in, 256));
+    HIP_TRY(hipMalloc(&d_out, 256));
+    HIP_TRY(hipMemcpy(d_in, in64, 256, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(debug_wave_scan_kernel, dim3(1), dim3(64), 0, nullptr, d_in, d_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out64, d_out, 256, hipMemcpyDeviceToHost));
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return DINT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,192 @@
+"""ctypes binding of the device decode path (include/dint_hip.h).
+
+torch is used for what it is good at here — owning device memory and streams;
+every decode goes through the C ABI into the hand-written HIP kernels. There is
+no CPU fallback: if libdint_hip.so is missing the import fails, and a decode
+without a GPU fails with DINT_ERR_NO_DEVICE.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .host import UNIT_DTYPE, KIND_BY_TYPE, RECTANGULAR, SINGLE_PACKED, MULTI_PACKED  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libdint_hip.so")
+
+#: every symbol include/dint_hip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = (
+    "dint_abi_version", "dint_strerror", "dint_last_hip_error", "dint_device_count",
+    "dint_dict_create", "dint_dict_destroy", "dint_dict_info_get", "dint_index_stream", "dint_free",
+    "dint_decode_units", "dint_decode_list_host", "dint_last_kernel_ms",
+)
+
+
+class DictInfo(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("device", C.c_int32), ("num_dicts", C.c_uint32),
+        ("entries", C.c_uint32), ("hot_entries", C.c_uint32), ("lds_bytes", C.c_uint32),
+        ("table_words", C.c_uint32), ("compute_units", C.c_uint32),
+    ]
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(
+            f"{_LIB_PATH} is missing — the HIP extension has not been built "
+            "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback."
+        )
+    lib = C.CDLL(_LIB_PATH)
+    vp, sz, u32, u64 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64
+    lib.dint_abi_version.restype = C.c_int
+    lib.dint_strerror.restype = C.c_char_p
+    lib.dint_strerror.argtypes = [C.c_int]
+    lib.dint_last_hip_error.restype = C.c_char_p
+    lib.dint_device_count.argtypes = [C.POINTER(C.c_int)]
+    lib.dint_dict_create.argtypes = [C.c_int, vp, sz, C.c_int, C.POINTER(vp)]
+    lib.dint_dict_destroy.restype = None
+    lib.dint_dict_destroy.argtypes = [vp]
+    lib.dint_dict_info_get.argtypes = [vp, C.POINTER(DictInfo)]
+    lib.dint_index_stream.argtypes = [vp, vp, sz, u32, C.POINTER(vp), C.POINTER(sz), C.POINTER(u64),
+                                      C.POINTER(u64)]
+    lib.dint_free.restype = None
+    lib.dint_free.argtypes = [vp]
+    lib.dint_decode_units.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, vp]
+    lib.dint_decode_list_host.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
+    lib.dint_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.dint_debug_wave_scan.argtypes = [vp, vp]
+    return lib
+
+
+_lib = _load()
+
+
+class DintError(RuntimeError):
+    def __init__(self, status: int, where: str):
+        self.status = status
+        detail = _lib.dint_last_hip_error().decode()
+        super().__init__(f"{where}: {_lib.dint_strerror(status).decode()} ({status})"
+                         + (f" — {detail}" if detail and status == -3 else ""))
+
+
+def _check(status: int, where: str) -> None:
+    if status != 0:
+        raise DintError(status, where)
+
+
+def abi_version() -> int:
+    return _lib.dint_abi_version()
+
+
+def device_count() -> int:
+    n = C.c_int()
+    _check(_lib.dint_device_count(C.byref(n)), "dint_device_count")
+    return n.value
+
+
+class Dictionary:
+    """Device-resident dictionary (reference: Dictionary::builder::load + build(dict))."""
+
+    def __init__(self, kind: int, file_bytes: bytes, device: int = 0):
+        self.kind = kind
+        self._h = C.c_void_p()
+        buf = (C.c_char * len(file_bytes)).from_buffer_copy(file_bytes)
+        _check(_lib.dint_dict_create(kind, C.addressof(buf), len(file_bytes), device, C.byref(self._h)),
+               "dint_dict_create")
+        self.device = device
+
+    def close(self) -> None:
+        h, self._h = self._h, C.c_void_p()
+        if h:
+            _lib.dint_dict_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self) -> DictInfo:
+        info = DictInfo()
+        _check(_lib.dint_dict_info_get(self._h, C.byref(info)), "dint_dict_info_get")
+        return info
+
+    # -- H3: sidecar ---------------------------------------------------------
+    def index_stream(self, enc: np.ndarray, unit_ints: int = 4096):
+        """Host pre-pass over a vroom stream -> (unit table, total ints, number of lists)."""
+        enc = np.ascontiguousarray(enc, dtype=np.uint8)
+        units, n_units = C.c_void_p(), C.c_size_t()
+        total, lists = C.c_uint64(), C.c_uint64()
+        _check(_lib.dint_index_stream(self._h, enc.ctypes.data, enc.size, unit_ints, C.byref(units),
+                                      C.byref(n_units), C.byref(total), C.byref(lists)), "dint_index_stream")
+        try:
+            arr = np.empty(n_units.value, dtype=UNIT_DTYPE)
+            if n_units.value:
+                C.memmove(arr.ctypes.data, units, arr.nbytes)
+        finally:
+            _lib.dint_free(units)
+        return arr, total.value, lists.value
+
+    # -- decode ----------------------------------------------------------------
+    def decode_units(self, enc_dev, units_dev, n_units: int, out_dev, end_off_dev=None, stream=None) -> None:
+        """Asynchronous batched decode. All tensors are torch CUDA tensors on this
+        dictionary's device: enc_dev uint8, units_dev the raw bytes of a UNIT_DTYPE
+        table, out_dev int32/uint32 storage, end_off_dev (optional) int64[n_units]."""
+        import torch
+
+        if stream is None:
+            stream = torch.cuda.current_stream(enc_dev.device).cuda_stream
+        _check(_lib.dint_decode_units(
+            self._h, enc_dev.data_ptr(), enc_dev.numel() * enc_dev.element_size(), units_dev.data_ptr(), n_units,
+            out_dev.data_ptr(), out_dev.numel(), end_off_dev.data_ptr() if end_off_dev is not None else None,
+            stream), "dint_decode_units")
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        _check(_lib.dint_last_kernel_ms(self._h, C.byref(ms)), "dint_last_kernel_ms")
+        return ms.value
+
+    def decode_list(self, enc: np.ndarray, offset: int, n: int):
+        """The reference's Decoder::decode(dict, in, out, universe, n) call shape on host
+        memory -> (out[0:n], bytes consumed). One wavefront wide: for tests and small lists."""
+        enc = np.ascontiguousarray(enc, dtype=np.uint8)
+        out = np.empty(n, dtype=np.uint32)
+        consumed = C.c_size_t()
+        _check(_lib.dint_decode_list_host(self._h, enc.ctypes.data + offset, enc.size - offset, out.ctypes.data, n,
+                                          C.byref(consumed)), "dint_decode_list_host")
+        return out, consumed.value
+
+
+def units_to_device(units: np.ndarray, device):
+    """Upload a UNIT_DTYPE table as raw bytes."""
+    import torch
+
+    raw = np.ascontiguousarray(units).view(np.uint8)
+    return torch.from_numpy(raw.copy()).to(device)
+
+
+def decode_stream(dictionary: Dictionary, enc: np.ndarray, units: np.ndarray, total_ints: int):
+    """Upload, decode every unit, download. -> (integers, end offsets, kernel ms)"""
+    import torch
+
+    dev = torch.device("cuda", dictionary.device)
+    enc_dev = torch.from_numpy(np.ascontiguousarray(enc, dtype=np.uint8)).to(dev)
+    units_dev = units_to_device(units, dev)
+    out_dev = torch.empty(max(1, total_ints), dtype=torch.int32, device=dev)
+    end_dev = torch.zeros(max(1, len(units)), dtype=torch.int64, device=dev)
+    dictionary.decode_units(enc_dev, units_dev, len(units), out_dev, end_dev)
+    torch.cuda.synchronize(dev)
+    ms = dictionary.last_kernel_ms() if len(units) else 0.0
+    out = out_dev.cpu().numpy().view(np.uint32)[:total_ints]
+    return out, end_dev.cpu().numpy().view(np.uint64)[: len(units)], ms
+
+
+def debug_wave_scan(values) -> np.ndarray:
+    v = np.ascontiguousarray(values, dtype=np.uint32)
+    assert v.size == 64
+    out = np.empty(64, dtype=np.uint32)
+    _check(_lib.dint_debug_wave_scan(v.ctypes.data, out.ctypes.data), "dint_debug_wave_scan")
+    return out
