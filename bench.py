@@ -42,7 +42,7 @@ def parse_args():
     ap.add_argument("--replicate", type=int, default=1,
                     help="device-side copies of the encoded shard at distinct addresses (scale knob)")
     ap.add_argument("--universe", type=int, default=25_000_000, help="documents (Gov2-shaped: 25M)")
-    ap.add_argument("--unit-ints", type=int, default=4096)
+    ap.add_argument("--unit-ints", type=int, default=8192)
     ap.add_argument("--dict-sample", type=float, default=2.0e7,
                     help="postings the DSF dictionary statistics are collected from")
     ap.add_argument("--seed", type=int, default=12345)

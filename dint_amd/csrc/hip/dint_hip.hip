@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -146,29 +148,40 @@ struct dint_dict {
     dint_dev::dict_view view{};
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool timed = false;
+    // work-queue counters: one slot per in-flight launch, recycled round-robin
+    // behind the event of the launch that used the slot last
+    static constexpr uint32_t kQueueSlots = 32;
+    uint32_t* d_queues = nullptr;
+    hipEvent_t slot_done[kQueueSlots] = {};
+    bool slot_used[kQueueSlots] = {};
+    std::atomic<uint32_t> next_slot{0};
+    std::mutex launch_mutex;
 };
 
 namespace {
 
 // Build the device layout:
-//   gtable = [256 zeros][file payload words]; gmeta[slot] = (size-1)<<24 | offset
-//   LDS image = [hot meta: hot_k words][256 zeros][hot payload], hot = codewords
-//   < hot_k of the (single) dictionary — the DSF builder appends entries in
-//   decreasing corpus frequency (dictionary_builders.hpp:61-72), so "index < K"
-//   is the hotness test.
+//   gtable   = [256 zeros][the file's payload words][16 words of padding];
+//   gmeta[i] = (size-1) << 24 | word offset into gtable (runs -> offset 0);
+//   LDS image = [hot meta: hot_k words][256 zeros][hot payloads], hot meta[i] =
+//               (size-1) << 24 | word offset inside the image (runs -> the zeros).
+// Hot = codewords below hot_k: the DSF builder appends entries in decreasing corpus
+// frequency (dictionary_builders.hpp:61-72), so "index < K" is the hotness test.
 int stage_dictionary(dint_dict& dd, parsed_dict const& pd) {
     const size_t slots = pd.size.size();
     std::vector<uint32_t> gmeta(slots);
     std::vector<uint32_t> gtable(kZeroWords, 0);
     gtable.insert(gtable.end(), pd.table.begin(), pd.table.end());
+    gtable.resize(gtable.size() + kMaxEntry, 0);
     if (gtable.size() >= kColdBase) return DINT_ERR_FORMAT;
     for (size_t i = 0; i != slots; ++i) {
-        uint32_t s = pd.size[i];
-        uint32_t o = s > kMaxEntry ? 0 : pd.off[i] + kZeroWords;
-        gmeta[i] = ((s - 1) << 24) | o;
+        const uint32_t sz = pd.size[i];
+        if (sz == 0 || sz > 256) return DINT_ERR_FORMAT;
+        const uint32_t o = sz > kMaxEntry ? 0 : pd.off[i] + kZeroWords;
+        gmeta[i] = ((sz - 1) << 24) | o;
     }
 
-    // hot set of dictionary 0 (single kinds); multi keeps everything cold for now
+    // hot set of dictionary 0 (single kinds)
     uint32_t hot_k = 0;
     std::vector<uint32_t> image;
     if (pd.num_dicts == 1) {
@@ -176,23 +189,22 @@ int stage_dictionary(dint_dict& dd, parsed_dict const& pd) {
         uint64_t payload = 0;
         uint32_t k = 0;
         for (; k != limit; ++k) {
-            uint32_t s = pd.size[k];
-            uint64_t add = (k >= kReserved && s <= kMaxEntry) ? s : 0;
+            const uint32_t sz = pd.size[k];
+            const uint64_t add = (k >= kReserved && sz <= kMaxEntry) ? sz : 0;
             if (uint64_t(k + 1) + kZeroWords + payload + add + 3 > kHotImageWords) break;
             payload += add;
         }
         hot_k = k;
-        image.assign(hot_k, 0);
-        image.resize(size_t(hot_k) + kZeroWords, 0);
+        image.assign(size_t(hot_k) + kZeroWords, 0);
         const uint32_t zero_off = hot_k;
         for (uint32_t i = 0; i != hot_k; ++i) {
-            uint32_t s = pd.size[i];
+            const uint32_t sz = pd.size[i];
             uint32_t o = zero_off;
-            if (i >= kReserved && s <= kMaxEntry) {
+            if (i >= kReserved && sz <= kMaxEntry) {
                 o = uint32_t(image.size());
-                for (uint32_t w = 0; w != s; ++w) image.push_back(pd.table[pd.off[i] + w]);
+                for (uint32_t w = 0; w != sz; ++w) image.push_back(pd.table[pd.off[i] + w]);
             }
-            image[i] = ((s - 1) << 24) | o;
+            image[i] = ((sz - 1) << 24) | o;
         }
     }
     while (image.size() % 4) image.push_back(0);
@@ -207,6 +219,9 @@ int stage_dictionary(dint_dict& dd, parsed_dict const& pd) {
     if (!image.empty()) HIP_TRY(hipMemcpy(dd.d_image, image.data(), image.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipEventCreate(&dd.ev_start));
     HIP_TRY(hipEventCreate(&dd.ev_stop));
+    HIP_TRY(hipMalloc(&dd.d_queues, size_t(dint_dict::kQueueSlots) * kQueueShards * kQueueStride * 4));
+    for (uint32_t i = 0; i != dint_dict::kQueueSlots; ++i)
+        HIP_TRY(hipEventCreateWithFlags(&dd.slot_done[i], hipEventDisableTiming));
     dd.view.gmeta = dd.d_gmeta;
     dd.view.gtable = dd.d_gtable;
     dd.view.lds_image = dd.d_image;
@@ -319,6 +334,9 @@ void dint_dict_destroy(dint_dict* dd) {
     if (dd->d_image) (void)hipFree(dd->d_image);
     if (dd->ev_start) (void)hipEventDestroy(dd->ev_start);
     if (dd->ev_stop) (void)hipEventDestroy(dd->ev_stop);
+    if (dd->d_queues) (void)hipFree(dd->d_queues);
+    for (auto e : dd->slot_done)
+        if (e) (void)hipEventDestroy(e);
     delete dd;
 }
 
@@ -433,7 +451,7 @@ int dint_decode_units(const dint_dict* dd, const uint8_t* d_enc, size_t enc_byte
                       size_t n_units, uint32_t* d_out, size_t out_capacity, uint64_t* d_end_off, void* stream) {
     if (!dd) return DINT_ERR_ARG;
     if (n_units == 0) return DINT_OK;
-    if (!d_enc || !d_units || !d_out || enc_bytes < 2) return DINT_ERR_ARG;
+    if (!d_enc || !d_units || !d_out || enc_bytes < 2 * kSPL) return DINT_ERR_ARG;  // slots are fetched 2*kSPL bytes at a time
     if (dd->kind == DINT_DICT_MULTI_PACKED) return DINT_ERR_ARG;  // multi kernel: see decode_multi (next)
     HIP_TRY(hipSetDevice(dd->device));
     decode_args a{};
@@ -447,13 +465,21 @@ int dint_decode_units(const dint_dict* dd, const uint8_t* d_enc, size_t enc_byte
     a.end_off = d_end_off;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint64_t blocks_needed = (uint64_t(n_units) + kWavesPerBlock - 1) / kWavesPerBlock;
-    const uint32_t grid = uint32_t(std::min<uint64_t>(blocks_needed, std::max<uint32_t>(1, dd->compute_units)));
+    const uint32_t grid = uint32_t(std::min<uint64_t>(blocks_needed, std::max<uint32_t>(1, dd->compute_units) * kBlocksPerCU));
     const size_t lds_bytes = (size_t(dd->view.hot_words) + kWavesPerBlock * kScratchWords) * 4;
     dint_dict* mut = const_cast<dint_dict*>(dd);
+    std::lock_guard<std::mutex> lock(mut->launch_mutex);
+    const uint32_t slot = mut->next_slot.fetch_add(1) % dint_dict::kQueueSlots;
+    if (mut->slot_used[slot]) HIP_TRY(hipEventSynchronize(mut->slot_done[slot]));  // normally long complete
+    a.queue = mut->d_queues + size_t(slot) * kQueueShards * kQueueStride;
+    a.n_shards = std::min<uint32_t>(kQueueShards, grid);
+    HIP_TRY(hipMemsetAsync(a.queue, 0, size_t(kQueueShards) * kQueueStride * 4, s));
     HIP_TRY(hipEventRecord(mut->ev_start, s));
     hipLaunchKernelGGL(decode_single_kernel, dim3(grid), dim3(kBlockThreads), lds_bytes, s, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(mut->ev_stop, s));
+    HIP_TRY(hipEventRecord(mut->slot_done[slot], s));
+    mut->slot_used[slot] = true;
     mut->timed = true;
     return DINT_OK;
 }
@@ -471,6 +497,7 @@ int dint_decode_list_host(const dint_dict* dd, const uint8_t* in, size_t in_byte
     if (consumed) *consumed = 0;
     if (n == 0) return DINT_OK;
     if (in_bytes < 2 || n > 0xFFFFFFFFull) return DINT_ERR_ARG;
+    const size_t padded = in_bytes < 8 ? 8 : in_bytes;
     HIP_TRY(hipSetDevice(dd->device));
     uint8_t* d_enc = nullptr;
     uint32_t* d_out = nullptr;
@@ -490,14 +517,15 @@ int dint_decode_list_host(const dint_dict* dd, const uint8_t* in, size_t in_byte
             return DINT_ERR_HIP;           \
         }                                  \
     } while (0)
-    TRY_OR_CLEAN(hipMalloc(&d_enc, in_bytes));
+    TRY_OR_CLEAN(hipMalloc(&d_enc, padded));
+    TRY_OR_CLEAN(hipMemset(d_enc, 0, padded));
     TRY_OR_CLEAN(hipMalloc(&d_out, n * 4));
     TRY_OR_CLEAN(hipMalloc(&d_unit, sizeof(dint_unit)));
     TRY_OR_CLEAN(hipMalloc(&d_end, 8));
     dint_unit u{0, 0, uint32_t(n), 0};
     TRY_OR_CLEAN(hipMemcpy(d_enc, in, in_bytes, hipMemcpyHostToDevice));
     TRY_OR_CLEAN(hipMemcpy(d_unit, &u, sizeof u, hipMemcpyHostToDevice));
-    st = dint_decode_units(dd, d_enc, in_bytes, d_unit, 1, d_out, n, d_end, nullptr);
+    st = dint_decode_units(dd, d_enc, padded, d_unit, 1, d_out, n, d_end, nullptr);
     if (st == DINT_OK) {
         TRY_OR_CLEAN(hipDeviceSynchronize());
         uint64_t end_off = 0;

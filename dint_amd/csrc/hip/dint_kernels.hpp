@@ -1,32 +1,33 @@
 // CDNA4 (gfx950) decode kernels for the DINT codeword streams.
 //
-// What is computed is the reference's single_dint::decode / multi_opt_dint::
-// decode (vroom_env/dint_codecs.hpp:37-107, :521-619); how is unrelated to its
-// one-codeword-at-a-time loop:
+// What is computed is the reference's single_dint::decode
+// (vroom_env/dint_codecs.hpp:37-107); how is unrelated to its one-codeword-at-a-
+// time loop:
 //
-//  * one 64-lane wavefront walks one unit (include/dint_hip.h) 64 codeword
-//    SLOTS at a time, lane l owning slot l;
-//  * which slots are codeword headers and which are exception payloads is a
-//    3-state machine over the slots; it is resolved on the scalar unit from two
-//    `__ballot` masks (slot == 0, slot == 1) — one scalar iteration per
-//    exception, none in the common all-dictionary chunk;
-//  * header lanes look up (size, source offset) — LDS for the hot codewords,
-//    L2 for the cold ones — and a DPP wave prefix sum turns sizes into output
-//    offsets;
-//  * expansion is OUTPUT-centric: each header lane drops a flag byte at its
-//    first output position and its (source − position) delta into a compact
-//    table; then for every 64 consecutive output integers the wave reads 64 flag
-//    bytes, `__ballot`s them into a bitmap, ranks with mbcnt to find the owning
-//    codeword, gathers the source word (LDS or L2) and issues ONE fully
-//    coalesced 256-byte store. Zero runs are ordinary entries that point at a
-//    256-word zero region, exceptions are entries that point at a per-wave
-//    literal pool. Exactly n integers are written per unit, nothing past them
-//    (the reference needs a pre-zeroed buffer and a 256-word overflow area,
-//    include/dint/dint_codecs.hpp:11, dict_posting_list.hpp:296).
+//  * one 64-lane wavefront walks one unit (include/dint_hip.h) in TILES of
+//    64 * kSPL 16-bit slots; lane l owns the kSPL CONSECUTIVE slots kSPL*l ..
+//    (one unaligned load), so (lane, k) order is stream order is output order;
+//  * per slot one metadata word ((size-1) << 24 | payload offset): LDS for the hot
+//    codewords, L2 for the cold ones, looked up one tile ahead of use;
+//  * header/payload classification costs nothing unless a tile holds a 0 or 1
+//    slot (or an exception straddles in); then a short per-lane state machine is
+//    iterated until the lane-to-lane carries agree (one or two rounds);
+//  * a local prefix plus ONE DPP wave scan gives every codeword its output offset;
+//  * EXPANSION is output-centric: every codeword sets ONE bit at its first output
+//    position in a per-wave flag bitmap (ds_or) and stores `source - position` in
+//    a table indexed by its ordinal; a small scan over the bitmap's word
+//    popcounts gives per-word rank bases. Then each lane takes 4 consecutive
+//    output integers: flag word + rank base -> 4 ranks -> 4 table reads -> 4
+//    gathers (LDS: hot payloads and the zero region of the runs; L2: cold
+//    payloads; literal table: exceptions) -> one 16-byte store, so every global
+//    store instruction covers 1 KB of consecutive output. Exactly n integers are
+//    written per unit, nothing past them (the reference needs a pre-zeroed buffer
+//    and a 256-word overflow area, include/dint/dint_codecs.hpp:11,
+//    dict_posting_list.hpp:296).
 //
 // LDS (160 KB/CU, one 1024-thread workgroup per CU):
-//   [ hot meta | 256 zero words | hot payload ]  <= kHotImageWords, shared
-//   16 x [ 1 KiB flag bytes | 64-word delta table | 64-word literal pool ]
+//   [ hot meta | 256 zero words | hot payloads ]  <= kHotImageWords, shared by 16 waves
+//   16 x [ flag bitmap | rank bases | per-codeword delta table | literal table ]
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -35,24 +36,38 @@
 
 namespace dint_dev {
 
+#ifndef DINT_BLOCK_THREADS
+#define DINT_BLOCK_THREADS 1024
+#endif
+#ifndef DINT_BLOCKS_PER_CU
+#define DINT_BLOCKS_PER_CU 1
+#endif
+
 constexpr uint32_t kWave = 64;
-constexpr uint32_t kBlockThreads = 1024;
+constexpr uint32_t kBlockThreads = DINT_BLOCK_THREADS;
 constexpr uint32_t kWavesPerBlock = kBlockThreads / kWave;
-constexpr uint32_t kLdsWords = 160 * 1024 / 4;
-constexpr uint32_t kCap = 1024;                       // outputs per expansion batch (>= 256)
-constexpr uint32_t kScratchWords = kCap / 4 + 64 + 64;  // flags + delta table + literal pool
+constexpr uint32_t kBlocksPerCU = DINT_BLOCKS_PER_CU;
+constexpr uint32_t kLdsWords = 160 * 1024 / 4 / kBlocksPerCU;
+constexpr uint32_t kSPL = 4;                          // slots per lane per tile
+constexpr uint32_t kTileSlots = kWave * kSPL;         // 256 slots per tile
+constexpr uint32_t kCap = 2048;                       // outputs per expansion batch (>= kSPL * 256)
+// per wave: flag bitmap, per-word rank bases, per-codeword delta and literal tables
+constexpr uint32_t kScratchWords = kCap / 32 + kCap / 32 + kTileSlots + kTileSlots;
 constexpr uint32_t kHotImageWords = kLdsWords - kWavesPerBlock * kScratchWords;
 constexpr uint32_t kZeroWords = 256;                  // longest run codeword
 constexpr uint32_t kColdBase = 1u << 24;              // source offsets >= this live in global memory
+constexpr uint32_t kLitAddr = 0x70000000u;            // source "address" of an exception literal
+constexpr uint32_t kQueueShards = 8;                  // dynamic unit queue: one counter per shard
+constexpr uint32_t kQueueStride = 32;                 // words between counters (own 128-byte line each)
 
 // Device view of one dictionary (single kinds: num_dicts == 1).
 struct dict_view {
     const uint32_t* gmeta;      // per codeword: (size-1) << 24 | word offset into gtable
     const uint32_t* gtable;     // [256 zeros][payload words...]
-    const uint32_t* lds_image;  // kHot image, hot_words long
+    const uint32_t* lds_image;  // [hot meta: hot_k words][256 zeros][hot payloads], hot_words long
     uint32_t gtable_words;
     uint32_t hot_words;         // multiple of 4
-    uint32_t hot_k;             // codewords < hot_k have their meta + payload in the LDS image
+    uint32_t hot_k;             // codewords < hot_k have meta + payload in the LDS image
 };
 
 struct decode_args {
@@ -64,18 +79,25 @@ struct decode_args {
     uint32_t* out;
     uint64_t out_capacity;
     uint64_t* end_off;  // nullable
+    uint32_t* queue;    // kQueueShards counters, kQueueStride words apart, zero at launch
+    uint32_t n_shards;  // counters in use
+};
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+struct __attribute__((packed, aligned(4))) u32x4_a4 {
+    u32x4 v;
+};
+struct __attribute__((packed, aligned(1))) u32x2_a1 {
+    u32x2 v;
+};
+struct __attribute__((packed, aligned(1))) u32_a1 {
+    uint32_t v;
 };
 
 __device__ __forceinline__ uint32_t lane_id() {
     return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
-
-// number of set bits of `mask` strictly below this lane
-__device__ __forceinline__ uint32_t mbcnt(uint64_t mask) {
-    return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
-}
-
-__device__ __forceinline__ bool lane_bit(uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
 
 // Inclusive prefix sum over the 64 lanes, in registers: four row_shr steps inside
 // each row of 16, then row_bcast:15 / row_bcast:31 across rows (gfx9 DPP).
@@ -101,177 +123,309 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ uint32_t load_slot16(const uint8_t* enc, uint64_t byte_off, uint64_t last_valid) {
-    uint64_t o = byte_off < last_valid ? byte_off : last_valid;
-    uint16_t v;
-    __builtin_memcpy(&v, enc + o, 2);  // payloads start at arbitrary byte addresses
-    return v;
+// kSPL consecutive 16-bit slots of one lane as a 64-bit value (kSPL == 2: low 32
+// bits), from an arbitrary byte address. Never reads past the
+// buffer: the tail lanes load the final bytes and shift (bytes past the end read
+// as zero).
+__device__ __forceinline__ uint64_t load_lane_slots(const uint8_t* enc, uint64_t byte_off, uint64_t last_valid) {
+    const uint64_t o = byte_off < last_valid ? byte_off : last_valid;
+    const uint64_t over = byte_off - o;  // 0 for all but the tail lanes
+    uint64_t q;
+    if (kSPL == 4) {
+        const u32x2 r = reinterpret_cast<const u32x2_a1*>(enc + o)->v;
+        q = (uint64_t(r.y) << 32) | r.x;
+    } else {
+        q = reinterpret_cast<const u32_a1*>(enc + o)->v;
+    }
+    return over < 2 * kSPL ? q >> (8 * uint32_t(over)) : 0ull;
 }
 
-// Scalar resolution of the header/payload state machine for 64 slots.
-//   e0 / e1 : lanes whose slot value is 0 / 1
-//   carry   : payload slots (0..2) the previous chunk's last exception still owns
-// Returns the mask of exception HEADER lanes; `pay` receives the payload lanes,
-// `carry_out` the payload slots spilling into the next chunk.
-__device__ __forceinline__ uint64_t resolve_slots16(uint64_t e0, uint64_t e1, uint32_t carry, uint64_t& pay,
-                                                     uint32_t& carry_out) {
-    pay = (1ull << carry) - 1ull;
-    carry_out = 0;
-    uint64_t exc = 0;
-    uint64_t cand = (e0 | e1) & ~pay;
-    while (cand) {
-        uint32_t p = uint32_t(__builtin_ctzll(cand));
-        uint64_t bit = 1ull << p;
-        exc |= bit;
-        uint32_t len = (e1 & bit) ? 2u : 1u;
-        uint64_t m = (bit << 1) | (len == 2 ? (bit << 2) : 0ull);  // bits shifted past 63 fall off
-        pay |= m;
-        uint32_t end = p + 1 + len;
-        carry_out = end > 64 ? end - 64 : 0;
-        cand &= ~(pay | bit);
-    }
-    return exc;
+struct tile_regs {
+    uint32_t s[kSPL];  // slot values
+    uint32_t m[kSPL];  // metadata of each slot read as a codeword (garbage for payload slots)
+};
+
+__device__ __forceinline__ void unpack_slots(uint64_t raw, tile_regs& t) {
+#pragma unroll
+    for (uint32_t k = 0; k != kSPL; ++k) t.s[k] = uint32_t(raw >> (16 * k)) & 0xFFFFu;
+}
+
+// Metadata word of a codeword: LDS for the hot codewords, L2 for the cold ones.
+// Two address spaces, two instructions: an unconditional DS read and a global
+// read under the cold lanes' exec mask (a pointer select would turn both into
+// one slow flat load).
+__device__ __forceinline__ uint32_t lookup_meta(const dict_view& d, const uint32_t* lds, uint32_t hot_k,
+                                                uint32_t v) {
+#ifdef DINT_EXP_NOCOLD
+    v = v < hot_k ? v : 7 + v % (hot_k - 7);
+#endif
+    const bool hot = v < hot_k;
+    uint32_t m = lds[hot ? v : 0u];
+    asm volatile("" : "+v"(m));  // keep the DS read a DS read
+    if (!hot) m = d.gmeta[v];
+    return m;
 }
 
 // One unit of a single-dictionary stream (rectangular or packed: the streams
 // are byte-identical, only the dictionary source layout differed on the host).
-__device__ __forceinline__ void decode_unit_single(const decode_args& a, uint32_t* lds, uint32_t* scratch,
+__device__ __forceinline__ void decode_unit_single(const decode_args& a, const uint32_t* lds, uint32_t* scratch,
                                                    uint64_t unit_index, uint32_t lane) {
-    uint8_t* flags = reinterpret_cast<uint8_t*>(scratch);
-    uint32_t* flag_words = scratch;
-    uint32_t* delta = scratch + kCap / 4;
-    uint32_t* lit = delta + 64;
-    const uint32_t lit_base = uint32_t(lit - lds);
+    uint32_t* flagw = scratch;              // kCap / 32 words
+    uint32_t* wbase = scratch + kCap / 32;  // per flag word: (#flags before it) - 1
+    uint32_t* delta = wbase + kCap / 32;    // per codeword ordinal: source - position
+    uint32_t* lit = delta + kTileSlots;     // per codeword ordinal: exception value
 
     const dint_unit* up = a.units + unit_index;
     const uint64_t in_off = up->in_off;
     const uint64_t out_off = up->out_off;
     const uint32_t n = up->n;
-    if (n == 0) return;
-    const uint64_t last_valid = a.enc_bytes >= 2 ? a.enc_bytes - 2 : 0;
+    if (n == 0 || out_off + n > a.out_capacity) return;
+    const uint64_t last_valid = a.enc_bytes >= 2 * kSPL ? a.enc_bytes - 2 * kSPL : 0;
     const uint32_t hot_k = a.dict.hot_k;
+    uint32_t* const out = a.out + out_off;
+
+    // pipeline: tile t in `cur` (slots + metadata), tile t+1 in `nxt`, tile t+2's slots in flight
+    uint64_t slot_byte = in_off + uint64_t(2 * kSPL) * lane;
+    tile_regs cur, nxt;
+    unpack_slots(load_lane_slots(a.enc, slot_byte, last_valid), cur);
+    slot_byte += 2 * kTileSlots;
+    uint64_t raw1 = load_lane_slots(a.enc, slot_byte, last_valid);
+    slot_byte += 2 * kTileSlots;
+    uint64_t raw2 = load_lane_slots(a.enc, slot_byte, last_valid);
+#pragma unroll
+    for (uint32_t k = 0; k != kSPL; ++k) cur.m[k] = lookup_meta(a.dict, lds, hot_k, cur.s[k]);
 
     uint32_t produced = 0;
-    uint32_t carry = 0;
-    // slot values of the next two chunks are kept in flight in registers
-    uint64_t slot_byte = in_off + 2ull * lane;
-    uint32_t v_next = load_slot16(a.enc, slot_byte, last_valid);
-    slot_byte += 2 * kWave;
-    uint32_t v_next2 = load_slot16(a.enc, slot_byte, last_valid);
-    uint64_t chunk_base = in_off;  // byte offset of slot 0 of the current chunk
+    uint32_t carry = 0;            // payload slots an exception of the previous tile still owns
+    uint64_t tile_base = in_off;   // byte offset of slot 0 of the current tile
     uint32_t end_slot = 0;
 
     while (produced < n) {
-        const uint32_t v = v_next;
-        v_next = v_next2;
-        slot_byte += 2 * kWave;
-        v_next2 = load_slot16(a.enc, slot_byte, last_valid);  // prefetch two chunks ahead
+        // ---- stage tile t+1: unpack, start its metadata lookups ---------------------
+        unpack_slots(raw1, nxt);
+#pragma unroll
+        for (uint32_t k = 0; k != kSPL; ++k) nxt.m[k] = lookup_meta(a.dict, lds, hot_k, nxt.s[k]);
+        const uint32_t next_lo = uint32_t(raw1);  // slots 0,1 of the next tile (exception spill)
 
-        // ---- classify slots ------------------------------------------------
-        const uint64_t e0 = __ballot(v == 0);
-        const uint64_t e1 = __ballot(v == 1);
-        uint64_t pay;
-        uint32_t carry_out;
-        const uint64_t exc = resolve_slots16(e0, e1, carry, pay, carry_out);
-        const bool is_hdr = lane_bit(~pay);
-        const bool is_exc = lane_bit(exc);
-
-        // ---- size + source of every header lane -----------------------------
-        uint32_t size = 0, src = 0;
-        if (exc) {  // wave-uniform: rare
-            uint32_t s1 = __shfl_down(v, 1);
-            uint32_t s2 = __shfl_down(v, 2);
-            const uint32_t nx0 = readlane(v_next, 0), nx1 = readlane(v_next, 1);
-            if (lane == 63) s1 = nx0;
-            if (lane == 62) s2 = nx0;
-            if (lane == 63) s2 = nx1;
-            if (is_exc) lit[lane] = (v == 1) ? (s1 | (s2 << 16)) : s1;
-        }
-        if (is_hdr) {
-            if (is_exc) {
-                size = 1;
-                src = lit_base + lane;
-            } else {
-                // two address spaces, two instructions: an unconditional LDS read and a
-                // global read under the cold lanes' exec mask (a pointer select would
-                // turn both into one slow flat load)
-                const bool hot = v < hot_k;
-                uint32_t m = lds[hot ? v : 0u];
-                asm volatile("" : "+v"(m));  // keep the DS read a DS read
-                if (!hot) m = a.dict.gmeta[v];
-                size = (m >> 24) + 1;
-                src = (m & 0xFFFFFFu) + (hot ? 0u : kColdBase);
+        // ---- 1. classification ------------------------------------------------------------
+        uint32_t smin = cur.s[0];
+#pragma unroll
+        for (uint32_t k = 1; k != kSPL; ++k) smin = smin < cur.s[k] ? smin : cur.s[k];
+        const bool any_exc = __ballot(smin < 2) != 0 || carry != 0;
+        uint32_t paybits = 0, excbits = 0;
+        uint32_t carry_out = 0;
+        uint32_t excval[kSPL];
+#pragma unroll
+        for (uint32_t k = 0; k != kSPL; ++k) excval[k] = 0;
+        if (any_exc) {
+            uint32_t st_in = lane == 0 ? carry : 0u;
+            uint32_t st_out;
+            for (;;) {
+                uint32_t st = st_in;
+                paybits = 0;
+                excbits = 0;
+#pragma unroll
+                for (uint32_t k = 0; k != kSPL; ++k) {
+                    const bool p = st != 0;
+                    const bool e = !p && cur.s[k] < 2;
+                    paybits |= uint32_t(p) << k;
+                    excbits |= uint32_t(e) << k;
+                    st = p ? st - 1 : (e ? cur.s[k] + 1 : 0u);
+                }
+                st_out = st;
+                uint32_t prev = __shfl_up(st_out, 1);
+                if (lane == 0) prev = carry;
+                if (__ballot(prev != st_in) == 0) break;
+                st_in = prev;
+            }
+            carry_out = readlane(st_out, 63);
+            if (__ballot(excbits != 0)) {
+                // slot values after this lane's: the next lane's first two (lane 63: next tile's)
+                uint32_t nlo = __shfl_down((cur.s[1] << 16) | cur.s[0], 1);
+                if (lane == 63) nlo = readlane(next_lo, 0);
+                uint32_t e[kSPL + 2];
+#pragma unroll
+                for (uint32_t k = 0; k != kSPL; ++k) e[k] = cur.s[k];
+                e[kSPL] = nlo & 0xFFFFu;
+                e[kSPL + 1] = nlo >> 16;
+#pragma unroll
+                for (uint32_t k = 0; k != kSPL; ++k) excval[k] = e[k] == 0 ? e[k + 1] : (e[k + 1] | (e[k + 2] << 16));
             }
         }
 
-        // ---- output offsets ---------------------------------------------------
-        const uint32_t incl = wave_inclusive_sum(size);
-        const uint32_t excl = incl - size;
-        const uint32_t remaining = n - produced;
-        const bool act = is_hdr && excl < remaining;
-        const uint32_t size_c = act ? (size < remaining - excl ? size : remaining - excl) : 0;
-        const uint32_t endpos = excl + size_c;
-        uint32_t total = readlane(incl, 63);
-        total = total < remaining ? total : remaining;
-
-        if (produced + total >= n) {  // last chunk of the unit: where does the stream end
-            const uint64_t am = __ballot(act);
-            const uint32_t last = 63u - uint32_t(__builtin_clzll(am | 1ull));
-            const uint64_t lb = 1ull << last;
-            end_slot = last + 1 + ((exc & lb) ? ((e1 & lb) ? 2u : 1u) : 0u);
+        // ---- 2. sizes, offsets, ordinals --------------------------------------------------
+        uint32_t size[kSPL], src[kSPL];
+#pragma unroll
+        for (uint32_t k = 0; k != kSPL; ++k) {
+            const bool hdr = !((paybits >> k) & 1u);
+            const bool exc = (excbits >> k) & 1u;
+            size[k] = hdr ? (exc ? 1u : (cur.m[k] >> 24) + 1u) : 0u;
+            src[k] = (cur.m[k] & 0xFFFFFFu) + (cur.s[k] < hot_k ? 0u : kColdBase);
+#ifdef DINT_EXP_NOCOLD
+            src[k] = cur.m[k] & 0xFFFFFFu;
+#endif
         }
+        const uint32_t hdrbits = ~paybits & 0xFu;
+        uint32_t off[kSPL];
+        off[0] = 0;
+#pragma unroll
+        for (uint32_t k = 1; k != kSPL; ++k) off[k] = off[k - 1] + size[k - 1];
+        const uint32_t lsum = off[kSPL - 1] + size[kSPL - 1];
+        const uint32_t packed = (uint32_t(__builtin_popcount(hdrbits)) << 24) | lsum;
+        const uint32_t pincl = wave_inclusive_sum(packed);
+        const uint32_t pexcl = pincl - packed;
+        const uint32_t obase = pexcl & 0xFFFFFFu;  // first output of this lane's codewords
+        const uint32_t rbase = pexcl >> 24;        // ordinal of this lane's first codeword
+        const uint32_t remaining = n - produced;
+        uint32_t total = readlane(pincl, 63) & 0xFFFFFFu;
+        uint32_t actbits = hdrbits;
+        uint32_t lsum_c = lsum;
+        if (total >= remaining) {  // last tile of the unit: clamp, and find where the stream ends
+            total = remaining;
+            uint32_t cand = 0;
+            actbits = 0;
+#pragma unroll
+            for (uint32_t k = 0; k != kSPL; ++k) {
+                const uint32_t pos = obase + off[k];
+                const bool act = ((hdrbits >> k) & 1u) && pos < remaining;
+                if (act) {
+                    size[k] = size[k] < remaining - pos ? size[k] : remaining - pos;
+                    actbits |= 1u << k;
+                    const bool exc = (excbits >> k) & 1u;
+                    cand = kSPL * lane + k + 1 + (exc ? cur.s[k] + 1 : 0u);
+                } else {
+                    size[k] = 0;
+                }
+            }
+            lsum_c = obase < remaining ? (obase + lsum < remaining ? lsum : remaining - obase) : 0u;
+            const uint64_t am = __ballot(actbits != 0);
+            end_slot = readlane(cand, 63u - uint32_t(__builtin_clzll(am | 1ull)));
+        }
+        // ordinal of codeword k inside the lane
+        uint32_t lord[kSPL];
+        lord[0] = 0;
+#pragma unroll
+        for (uint32_t k = 1; k != kSPL; ++k) lord[k] = lord[k - 1] + ((hdrbits >> (k - 1)) & 1u);
 
-        // ---- expand, kCap outputs at a time ---------------------------------
-        uint32_t done = 0;
+        // ---- 3./4. batches of <= kCap outputs -------------------------------------------------
+        uint32_t done = 0, rdone = 0;
         while (done < total) {
-            const uint32_t rel = excl - done;
-            const bool inb = act && excl >= done && (endpos - done) <= kCap;
+            const bool inb = lsum_c != 0 && obase >= done && (obase + lsum_c - done) <= kCap;
             const uint64_t bm = __ballot(inb);
             const uint32_t last = 63u - uint32_t(__builtin_clzll(bm | 1ull));
-            const uint32_t bend = readlane(endpos, last);
+            const uint32_t bend = readlane(obase + lsum_c, last);
+            const uint32_t rend = readlane(rbase + uint32_t(__builtin_popcount(actbits)), last);
             const uint32_t bt = bend - done;  // outputs in this batch, 1..kCap
+            const uint32_t nwords = (bt + 31) >> 5;
 
-            for (uint32_t w = lane; w * 4 < bt; w += kWave) flag_words[w] = 0;
+            if (lane < nwords) flagw[lane] = 0;
             wave_lds_fence();
+            bool any_lit = false;
             if (inb) {
-                flags[rel] = 1;
-                delta[mbcnt(bm)] = src - rel;
+#pragma unroll
+                for (uint32_t k = 0; k != kSPL; ++k) {
+                    if ((actbits >> k) & 1u) {
+                        const uint32_t rel = obase + off[k] - done;
+                        const uint32_t ord = rbase + lord[k] - rdone;
+                        __hip_atomic_fetch_or(&flagw[rel >> 5], 1u << (rel & 31u), __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        if ((excbits >> k) & 1u) {
+                            delta[ord] = kLitAddr - rel;  // position rel resolves to the literal marker
+                            lit[ord] = excval[k];
+                            any_lit = true;
+                        } else {
+                            delta[ord] = src[k] - rel;
+                        }
+                    }
+                }
+            }
+            const bool batch_lit = __ballot(any_lit) != 0;
+            wave_lds_fence();
+            {
+                const uint32_t wv = lane < nwords ? flagw[lane] : 0u;
+                const uint32_t pc = uint32_t(__builtin_popcount(wv));
+                const uint32_t pi = wave_inclusive_sum(pc);
+                wbase[lane] = pi - pc - 1u;
             }
             wave_lds_fence();
 
-            uint32_t rank_base = 0;
-            const uint64_t obase = out_off + produced + done;
-            for (uint32_t q = 0; q < bt; q += kWave) {
-                const uint32_t pos = q + lane;
-                const bool ok = pos < bt;
-                const uint32_t f = ok ? flags[pos] : 0u;
-                const uint64_t fm = __ballot(f != 0);
-                const uint32_t rank = rank_base + mbcnt(fm) + (f ? 1u : 0u) - 1u;
-                rank_base += uint32_t(__builtin_popcountll(fm));
-                if (ok) {
-                    const uint32_t s = delta[rank] + pos;
-                    uint32_t val = lds[s < kColdBase ? s : 0u];
-                    asm volatile("" : "+v"(val));  // keep the DS read a DS read
-                    if (s >= kColdBase) {
-                        uint32_t g = s - kColdBase;
-                        g = g < a.dict.gtable_words ? g : a.dict.gtable_words - 1;
-                        val = a.dict.gtable[g];
+            uint32_t* const obatch = out + (produced + done);
+            for (uint32_t q0 = 0; q0 < bt; q0 += 4 * kWave) {
+                const uint32_t p0 = q0 + 4 * lane;
+                if (p0 < bt) {
+                    const uint32_t widx = p0 >> 5, sh = p0 & 31u;
+                    const uint32_t w = flagw[widx];
+                    const uint32_t nib = (w >> sh) & 15u;
+                    const uint32_t base = wbase[widx] + uint32_t(__builtin_popcount(w & ((1u << sh) - 1u)));
+                    uint32_t r[4], d[4];
+                    r[0] = base + (nib & 1u);
+                    r[1] = base + uint32_t(__builtin_popcount(nib & 3u));
+                    r[2] = base + uint32_t(__builtin_popcount(nib & 7u));
+                    r[3] = base + uint32_t(__builtin_popcount(nib));
+#pragma unroll
+                    for (int k = 0; k != 4; ++k) d[k] = delta[r[k]];
+                    uint32_t x[4], ad[4];
+#pragma unroll
+                    for (int k = 0; k != 4; ++k) {
+                        ad[k] = d[k] + p0 + k;
+                        x[k] = lds[ad[k] < kColdBase ? ad[k] : 0u];
                     }
-                    const uint64_t o = obase + pos;
-                    if (o < a.out_capacity) a.out[o] = val;
+                    asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));  // keep DS reads DS reads
+#ifndef DINT_EXP_NOCOLD
+#pragma unroll
+                    for (int k = 0; k != 4; ++k) {
+                        if (ad[k] >= kColdBase && ad[k] != kLitAddr) {
+                            uint32_t g = ad[k] - kColdBase;
+                            g = g < a.dict.gtable_words ? g : a.dict.gtable_words - 1;
+                            x[k] = a.dict.gtable[g];
+                        }
+                    }
+#endif
+                    if (batch_lit) {
+#pragma unroll
+                        for (int k = 0; k != 4; ++k) {
+                            if (ad[k] == kLitAddr) x[k] = lit[r[k]];
+                        }
+                    }
+#ifdef DINT_EXP_NOSTORE
+                    if (x[0] == 0xDEADBEEFu && x[1] == 0x12345u) obatch[p0] = x[2] + x[3];
+#else
+                    if (p0 + 4 <= bt) {
+                        u32x4 xv = {x[0], x[1], x[2], x[3]};
+                        reinterpret_cast<u32x4_a4*>(obatch + p0)->v = xv;
+                    } else {
+                        obatch[p0] = x[0];
+                        if (p0 + 1 < bt) obatch[p0 + 1] = x[1];
+                        if (p0 + 2 < bt) obatch[p0 + 2] = x[2];
+                    }
+#endif
                 }
             }
             wave_lds_fence();
             done = bend;
+            rdone = rend;
         }
 
         produced += total;
         carry = carry_out;
-        if (produced < n) chunk_base += 2 * kWave;
+        if (produced < n) tile_base += 2 * kTileSlots;
+
+        // ---- rotate the pipeline ---------------------------------------------------
+        cur = nxt;
+        raw1 = raw2;
+        slot_byte += 2 * kTileSlots;
+        raw2 = load_lane_slots(a.enc, slot_byte, last_valid);
     }
-    if (a.end_off && lane == 0) a.end_off[unit_index] = chunk_base + 2ull * end_slot;
+    if (a.end_off && lane == 0) a.end_off[unit_index] = tile_base + 2ull * end_slot;
 }
 
+// Units are handed out dynamically: their cost varies a lot (a sparse list full
+// of exceptions takes several times longer than a dense one of the same length),
+// so a static unit -> wave map leaves most of the chip idle behind the slowest
+// waves. kQueueShards counters (one per group of workgroups, blockIdx % 8 — the
+// workgroups that share an XCD under round-robin placement; a speed choice only)
+// each serve the units u = shard + n_shards * j; a wave draws its next index
+// while it is still decoding the current unit.
 __global__ __launch_bounds__(kBlockThreads) void decode_single_kernel(decode_args a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     for (uint32_t i = threadIdx.x; i < a.dict.hot_words; i += kBlockThreads) lds[i] = a.dict.lds_image[i];
@@ -279,9 +433,19 @@ __global__ __launch_bounds__(kBlockThreads) void decode_single_kernel(decode_arg
     const uint32_t lane = lane_id();
     const uint32_t wave = uniform(threadIdx.x / kWave);
     uint32_t* scratch = lds + a.dict.hot_words + wave * kScratchWords;
-    const uint64_t total_waves = uint64_t(gridDim.x) * kWavesPerBlock;
-    for (uint64_t u = uint64_t(blockIdx.x) * kWavesPerBlock + wave; u < a.n_units; u += total_waves) {
-        decode_unit_single(a, lds, scratch, u, lane);
+    const uint32_t shard = blockIdx.x % a.n_shards;  // n_shards = min(kQueueShards, gridDim.x)
+    uint32_t* counter = a.queue + shard * kQueueStride;
+    const uint64_t shard_units = (a.n_units + a.n_shards - 1 - shard) / a.n_shards;
+    auto draw = [&]() -> uint32_t {
+        uint32_t j = 0;
+        if (lane == 0) j = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return uniform(j);
+    };
+    uint32_t j = draw();
+    while (j < shard_units) {
+        const uint32_t j_next = draw();
+        decode_unit_single(a, lds, scratch, uint64_t(shard) + uint64_t(a.n_shards) * j, lane);
+        j = j_next;
     }
 }
 

@@ -15,7 +15,7 @@ import numpy as np
 from .host import UNIT_DTYPE, KIND_BY_TYPE, RECTANGULAR, SINGLE_PACKED, MULTI_PACKED  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libdint_hip.so")
+_LIB_PATH = os.environ.get("DINT_HIP_LIB") or os.path.join(_HERE, "libdint_hip.so")
 
 #: every symbol include/dint_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Development aid (GPU box): PMC passes over tools/quick_bench.py. usage: tools/pmc_run.sh <tag> [postings]
+TAG=${1:-pmc}; N=${2:-2e8}
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R/tools/quick_bench.py $N 8192 > $OUT/$name.log 2>&1; }
+run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
+run sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA
+run sq3 SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_WAVES SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT SQ_LDS_DATA_FIFO_FULL
+run fetch FETCH_SIZE
+run write WRITE_SIZE
+run tcc TCC_HIT_sum TCC_MISS_sum
+python3 - <<PY
+import csv, glob, collections
+for d in sorted(glob.glob("$OUT/*/")):
+    for f in glob.glob(d + "**/*counter_collection.csv", recursive=True):
+        agg = collections.defaultdict(lambda: [0.0, 0])
+        for row in csv.DictReader(open(f)):
+            if "decode" not in row["Kernel_Name"]: continue
+            a = agg[row["Counter_Name"]]; a[0] += float(row["Counter_Value"]); a[1] += 1
+        for k, (v, n) in agg.items():
+            print(f"{k:28s} per-launch {v / n:.4g}  (launches {n})")
+PY
