@@ -77,3 +77,81 @@ def test_decode_list_call_shape(device, small_corpus, kind):
         assert consumed == used
         off = payload + used
         checked += 1
+
+
+# ---- hand-assembled known-answer vectors through the C ABI -------------------------------------
+from kat import DICT_FILES, cases  # noqa: E402
+
+
+@pytest.mark.parametrize("kind", SINGLE_KINDS)
+@pytest.mark.parametrize("case", cases("single_cases"), ids=lambda c: c[0])
+def test_single_kat(device, kind, case):
+    name, buf, off, n, expect = case
+    d = device.Dictionary(kind, DICT_FILES[kind])
+    got, consumed = d.decode_list(buf, off, n)
+    assert np.array_equal(got, expect)
+    assert consumed == buf.size - off
+
+
+@pytest.mark.parametrize("kind", SINGLE_KINDS)
+def test_all_kats_in_one_launch(device, kind):
+    """Every vector as one unit of a single batched decode: units at arbitrary byte offsets, outputs
+    back to back, a canary after the last integer."""
+    import torch
+
+    cs = cases("single_cases")
+    blob, units, pos = [], [], 0
+    from dint_amd.host import UNIT_DTYPE
+
+    out_pos = 0
+    for i, (name, buf, off, n, expect) in enumerate(cs):
+        blob.append(buf)
+        units.append((pos + off, out_pos, n, i))
+        pos += buf.size
+        out_pos += n
+    enc = np.concatenate(blob + [np.zeros(16, dtype=np.uint8)])
+    table = np.array(units, dtype=UNIT_DTYPE)
+    d = device.Dictionary(kind, DICT_FILES[kind])
+    dev = torch.device("cuda", 0)
+    enc_dev = torch.from_numpy(enc).to(dev)
+    out_dev = torch.full((out_pos + 64,), -1, dtype=torch.int32, device=dev)
+    end_dev = torch.zeros(len(table), dtype=torch.int64, device=dev)
+    d.decode_units(enc_dev, device.units_to_device(table, dev), len(table), out_dev, end_dev)
+    torch.cuda.synchronize()
+    got = out_dev.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got[:out_pos], np.concatenate([c[4] for c in cs]))
+    assert (got[out_pos:] == 0xFFFFFFFF).all()              # nothing written past the last integer
+    ends = end_dev.cpu().numpy()
+    assert np.array_equal(ends, np.cumsum([c[1].size for c in cs]))
+
+
+@pytest.mark.parametrize("unit_ints", [64, 255, 1000, 100_000])
+def test_any_unit_size_gives_the_same_integers(device, small_corpus, unit_ints):
+    d = device.Dictionary(host.SINGLE_PACKED, small_corpus.dict_file(host.SINGLE_PACKED))
+    enc, _ = small_corpus.encoded(host.SINGLE_PACKED)
+    units, total, _ = d.index_stream(enc, unit_ints)
+    out, _, _ = device.decode_stream(d, enc, units, total)
+    assert np.array_equal(out, small_corpus.coll.gaps)
+
+
+def test_full_size_properties(device):
+    """A collection well past the sizes the oracle is used on: bit-exact against the encoder's
+    input, and decode is idempotent (a second pass over the same buffer changes nothing)."""
+    import torch
+
+    coll = host.synth_collection(40_000_000, universe=25_000_000, seed=2024)
+    dict_file = host.build_dictionary(host.SINGLE_PACKED, coll, max_sample_ints=5_000_000)
+    enc, units = host.encode_vroom(host.SINGLE_PACKED, dict_file, coll, unit_ints=8192)
+    d = device.Dictionary(host.SINGLE_PACKED, dict_file)
+    dev = torch.device("cuda", 0)
+    enc_dev = torch.from_numpy(enc).to(dev)
+    units_dev = device.units_to_device(units, dev)
+    out_dev = torch.zeros(coll.num_postings, dtype=torch.int32, device=dev)
+    d.decode_units(enc_dev, units_dev, len(units), out_dev)
+    first = out_dev.clone()
+    d.decode_units(enc_dev, units_dev, len(units), out_dev)
+    torch.cuda.synchronize()
+    assert torch.equal(first, out_dev)
+    got = out_dev.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, coll.gaps)
+    assert int(got.sum(dtype=np.uint64)) == int(coll.gaps.sum(dtype=np.uint64))

@@ -1,0 +1,112 @@
+"""The CPU oracle against the hand-assembled known-answer vectors, the naive Python
+restatement, and the encode -> decode == input contract (the reference's own
+correctness check, vroom_env/check_encoded_data.cpp:76-113)."""
+import numpy as np
+import pytest
+
+import oracle
+import pydecode
+from dint_amd import host
+from kat import DICT_FILES, KAT, cases
+
+PARSERS = {0: pydecode.parse_rectangular, 1: pydecode.parse_single_packed, 2: pydecode.parse_multi_packed}
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("case", cases("single_cases"), ids=lambda c: c[0])
+def test_single_kat(kind, case):
+    name, buf, off, n, expect = case
+    got, used = oracle.OracleDict(kind, DICT_FILES[kind]).decode_list(buf, off, n)
+    assert np.array_equal(got, expect)
+    assert used == buf.size - off
+    py, end = pydecode.decode_single(PARSERS[kind](DICT_FILES[kind]), bytes(buf), off, n)
+    assert py == expect.tolist() and end == buf.size
+
+
+@pytest.mark.parametrize("case", cases("multi_cases"), ids=lambda c: c[0])
+def test_multi_kat(case):
+    name, buf, off, n, expect = case
+    got, used = oracle.OracleDict(2, DICT_FILES[2]).decode_list(buf, off, n)
+    assert np.array_equal(got, expect)
+    assert used == buf.size - off
+    py, end = pydecode.decode_multi(PARSERS[2](DICT_FILES[2]), bytes(buf), off, n)
+    assert py == expect.tolist() and end == buf.size
+
+
+def test_dictionary_copy_semantics():
+    """copy() always writes 16 words and returns the logical size; runs return 256..16."""
+    entries = {int(k): v for k, v in KAT["dict_entries"].items()}
+    for kind in (0, 1, 2):
+        od = oracle.OracleDict(kind, DICT_FILES[kind])
+        for i, run in zip(range(2, 7), (256, 128, 64, 32, 16)):
+            size, words = od.copy(i)
+            assert size == run and not words.any()
+        for i, e in entries.items():
+            size, words = od.copy(i)
+            assert size == len(e)
+            assert words[:size].tolist() == e
+        if kind == 2:
+            size, words = od.copy(9, dict_id=4)
+            assert words[:size].tolist() == [v + 4 for v in entries[9]]
+
+
+@pytest.mark.parametrize("kind", [host.RECTANGULAR, host.SINGLE_PACKED, host.MULTI_PACKED])
+@pytest.mark.parametrize("corpus_name", ["small_corpus", "dense_corpus", "sparse_corpus"])
+def test_encode_then_oracle_decode_is_identity(request, kind, corpus_name):
+    corpus = request.getfixturevalue(corpus_name)
+    enc, units = corpus.encoded(kind)
+    od = oracle.OracleDict(kind, corpus.dict_file(kind))
+    out, lists = od.decode_stream(enc, corpus.coll.num_postings)
+    assert lists == np.count_nonzero(corpus.coll.lens)
+    assert np.array_equal(out, corpus.coll.gaps)
+
+
+@pytest.mark.parametrize("kind", [host.RECTANGULAR, host.SINGLE_PACKED])
+def test_greedy_encoder_round_trip(small_corpus, kind):
+    enc, _ = small_corpus.encoded(kind, greedy=True)
+    out, _ = oracle.OracleDict(kind, small_corpus.dict_file(kind)).decode_stream(enc, small_corpus.coll.num_postings)
+    assert np.array_equal(out, small_corpus.coll.gaps)
+    opt, _ = small_corpus.encoded(kind, greedy=False)
+    assert opt.size <= enc.size  # the optimal parse is never longer than the greedy one
+
+
+def test_rect_and_packed_streams_are_byte_identical(small_corpus):
+    """Both single dictionaries are built from the same statistics, so the encoder makes the
+    same choices."""
+    a, _ = small_corpus.encoded(host.RECTANGULAR)
+    b, _ = small_corpus.encoded(host.SINGLE_PACKED)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
+def test_units_are_independent(small_corpus, kind):
+    """Every unit of the sidecar starts on a codeword boundary: decoding a unit on its own gives
+    exactly its slice of the list (multi: units start on 256-integer block boundaries)."""
+    enc, units = small_corpus.encoded(kind)
+    od = oracle.OracleDict(kind, small_corpus.dict_file(kind))
+    assert int(units["n"].sum()) == small_corpus.coll.num_postings
+    assert np.array_equal(units["out_off"], np.r_[0, np.cumsum(units["n"][:-1], dtype=np.uint64)])
+    step = max(1, len(units) // 300)
+    for u in units[::step]:
+        got, _ = od.decode_list(enc, int(u["in_off"]), int(u["n"]))
+        lo = int(u["out_off"])
+        assert np.array_equal(got, small_corpus.coll.gaps[lo:lo + int(u["n"])])
+
+
+@pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 255, 256, 257, 511, 512, 513, 4096])
+@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
+def test_list_lengths_around_block_sizes(small_corpus, kind, n):
+    """The shape of the reference's codec test (test/test_block_codecs.cpp:9-38): seeded values,
+    sizes around the block size, consumed bytes == produced bytes."""
+    r = np.random.default_rng(12345 + n)
+    for mag in (1, 4, 9, 17, 24):
+        vals = r.integers(0, 1 << mag, n, dtype=np.uint64).astype(np.uint32)
+        vals[r.random(n) < 0.3] = 0
+        coll = host.Collection(vals, np.array([n], dtype=np.uint32))
+        enc, units = host.encode_vroom(kind, small_corpus.dict_file(kind), coll, unit_ints=0)
+        od = oracle.OracleDict(kind, small_corpus.dict_file(kind))
+        hn, _, payload = oracle.header_read(enc, 0)
+        assert hn == n and payload == int(units["in_off"][0])
+        got, used = od.decode_list(enc, payload, n)
+        assert np.array_equal(got, vals)
+        assert payload + used == enc.size

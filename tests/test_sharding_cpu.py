@@ -1,0 +1,89 @@
+"""List-range sharding and the world_size-2 path of bench.py's partition logic on gloo."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from dint_amd import host, sharding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+def test_partition_covers_every_list_once(world):
+    r = np.random.default_rng(world)
+    lens = (r.pareto(1.2, 5000) * 20 + 1).astype(np.uint32)
+    parts = sharding.partition_lists(lens, world)
+    assert parts[0][0] == 0 and parts[-1][1] == len(lens)
+    assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+    loads = [int(lens[a:b].sum()) for a, b in parts]
+    assert sum(loads) == int(lens.sum())
+    assert max(loads) - min(loads) <= 2 * int(lens.max())     # balanced by postings, not by lists
+
+
+def test_partition_units_rebases_offsets(small_corpus):
+    enc, units = small_corpus.encoded(host.SINGLE_PACKED)
+    parts = sharding.partition_units(units, 3)
+    assert sum(len(p[0]) for p in parts) == len(units)
+    pos = 0
+    for part, byte_lo, byte_hi, int_lo, int_hi in parts:
+        if not len(part):
+            continue
+        assert int_lo == pos and part["out_off"][0] == 0
+        pos = int_hi
+        lists = np.unique(part["list"])
+        assert lists.min() > -1
+    assert pos == small_corpus.coll.num_postings
+
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path[:0] = [{root!r}, os.path.join({root!r}, "oracle")]
+    import numpy as np, torch, torch.distributed as dist
+    from dint_amd import host, sharding
+    import oracle
+    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    p = host.synth_params(universe=300000, seed=99)
+    lens_all = host.synth_lengths(p, 200000 * world)
+    lo, hi = sharding.partition_lists(lens_all, world)[rank]
+    lens = lens_all[lo:hi]
+    coll = host.Collection(host.synth_gaps(p, lens, first_list_id=lo, threads=2), lens)
+    box = [host.build_dictionary(host.SINGLE_PACKED, coll, threads=2) if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)                 # dictionary replicated (set-up, not data path)
+    enc, units = host.encode_vroom(host.SINGLE_PACKED, box[0], coll, unit_ints=2048, threads=2)
+    out, _ = oracle.OracleDict(oracle.SINGLE_PACKED, box[0]).decode_stream(enc, coll.num_postings)
+    assert np.array_equal(out, coll.gaps)
+    # the only reductions of the multi-GPU path: total ints (sum), elapsed (max), checksum (sum)
+    t = torch.tensor([coll.num_postings, int(out.astype(np.uint64).sum() % (1 << 62))], dtype=torch.int64)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    el = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    # every rank regenerates the whole collection to check the shards tile it exactly
+    whole = host.synth_gaps(p, lens_all, first_list_id=0, threads=2)
+    assert t[0].item() == whole.size and t[1].item() == int(whole.astype(np.uint64).sum() % (1 << 62)) % (1 << 63)
+    assert el.item() == float(world)
+    dist.destroy_process_group()
+    print("rank", rank, "ok", coll.num_postings)
+""")
+
+
+def test_two_ranks_on_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    assert all("ok" in o for o in outs)

@@ -44,3 +44,16 @@ sz = sizes[7:]
 print("size dist", {s: int((sz == s).sum()) for s in (1, 2, 4, 8, 16)})
 for s in (1, 2, 4, 8, 16):
     print("size", s, "codeword share %.3f" % (hist[7:][sz == s].sum() / tot))
+
+# ---- what would a usage-ranked hot set buy? -------------------------------------------------
+use = hist.copy(); use[:7] = 0
+cost = 4 + 4 * sizes.astype(np.int64)          # meta word + payload words
+order = np.argsort(-(use[:n_off] / cost))       # best codewords per LDS byte first
+cum_bytes = np.cumsum(cost[order]); cum_cov = np.cumsum(use[order]) / tot
+for kb in (16, 32, 64, 96, 120, 140):
+    i = np.searchsorted(cum_bytes, kb * 1024)
+    print("usage-ranked hot set %3d KB: %5d entries, codeword coverage %.4f" % (kb, i, cum_cov[min(i, len(cum_cov) - 1)]))
+idx_cost = np.cumsum(cost[7:n_off]); idx_cov = np.cumsum(use[7:n_off]) / tot
+for kb in (16, 32, 64, 96, 120, 140):
+    i = np.searchsorted(idx_cost, kb * 1024)
+    print("index-ranked hot set %3d KB: %5d entries, codeword coverage %.4f" % (kb, i, idx_cov[min(i, len(idx_cov) - 1)]))
