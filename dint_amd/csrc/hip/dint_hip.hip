@@ -145,6 +145,8 @@ struct dint_dict {
     uint32_t* d_gmeta = nullptr;
     uint32_t* d_gtable = nullptr;
     uint32_t* d_image = nullptr;
+    dint_dev::dict_desc* d_descs = nullptr;
+    uint32_t hot_entries = 0;
     dint_dev::dict_view view{};
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool timed = false;
@@ -162,11 +164,13 @@ namespace {
 
 // Build the device layout:
 //   gtable   = [256 zeros][the file's payload words][16 words of padding];
-//   gmeta[i] = (size-1) << 24 | word offset into gtable (runs -> offset 0);
-//   LDS image = [hot meta: hot_k words][256 zeros][hot payloads], hot meta[i] =
-//               (size-1) << 24 | word offset inside the image (runs -> the zeros).
-// Hot = codewords below hot_k: the DSF builder appends entries in decreasing corpus
-// frequency (dictionary_builders.hpp:61-72), so "index < K" is the hotness test.
+//   gmeta[i] = (size-1) << 24 | word offset into gtable (runs -> offset 0), one word per
+//              offsets slot of the file (multi: the 6 dictionaries back to back);
+//   LDS image = [256 zeros]{[hot meta of dictionary d: hot_k[d] words]}[hot payloads], hot
+//              meta = (size-1) << 24 | word offset inside the image (runs -> the zeros).
+// Hot = codewords below hot_k[d]: the DSF builder appends entries in decreasing corpus
+// frequency (dictionary_builders.hpp:61-72), so "index < K" is the hotness test. The
+// image budget is split evenly between the dictionaries of a multi file.
 int stage_dictionary(dint_dict& dd, parsed_dict const& pd) {
     const size_t slots = pd.size.size();
     std::vector<uint32_t> gmeta(slots);
@@ -181,30 +185,39 @@ int stage_dictionary(dint_dict& dd, parsed_dict const& pd) {
         gmeta[i] = ((sz - 1) << 24) | o;
     }
 
-    // hot set of dictionary 0 (single kinds)
-    uint32_t hot_k = 0;
-    std::vector<uint32_t> image;
-    if (pd.num_dicts == 1) {
-        const uint32_t limit = std::min<uint32_t>(uint32_t(slots), kEntries);
-        uint64_t payload = 0;
+    const uint32_t nd = pd.num_dicts;
+    std::vector<dict_desc> descs(nd);
+    std::vector<uint32_t> image(kZeroWords, 0);
+    const uint64_t budget = (uint64_t(kHotImageWords) - kZeroWords - 4) / nd;
+    // pass 1: how many codewords of each dictionary fit its share
+    for (uint32_t d = 0; d != nd; ++d) {
+        const uint32_t base = pd.start[d];
+        const uint32_t limit = std::min<uint32_t>(pd.start[d + 1] - base, kEntries);
+        uint64_t words = 0;
         uint32_t k = 0;
         for (; k != limit; ++k) {
-            const uint32_t sz = pd.size[k];
-            const uint64_t add = (k >= kReserved && sz <= kMaxEntry) ? sz : 0;
-            if (uint64_t(k + 1) + kZeroWords + payload + add + 3 > kHotImageWords) break;
-            payload += add;
+            const uint32_t sz = pd.size[base + k];
+            const uint64_t add = 1 + ((k >= kReserved && sz <= kMaxEntry) ? sz : 0);
+            if (words + add > budget) break;
+            words += add;
         }
-        hot_k = k;
-        image.assign(size_t(hot_k) + kZeroWords, 0);
-        const uint32_t zero_off = hot_k;
-        for (uint32_t i = 0; i != hot_k; ++i) {
-            const uint32_t sz = pd.size[i];
-            uint32_t o = zero_off;
+        descs[d].meta_base = base;
+        descs[d].hot_k = k;
+        descs[d].hot_base = uint32_t(image.size());
+        descs[d].pad = 0;
+        image.resize(image.size() + k, 0);
+    }
+    // pass 2: payloads and meta words
+    for (uint32_t d = 0; d != nd; ++d) {
+        const uint32_t base = pd.start[d];
+        for (uint32_t i = 0; i != descs[d].hot_k; ++i) {
+            const uint32_t sz = pd.size[base + i];
+            uint32_t o = 0;  // the zero region
             if (i >= kReserved && sz <= kMaxEntry) {
                 o = uint32_t(image.size());
-                for (uint32_t w = 0; w != sz; ++w) image.push_back(pd.table[pd.off[i] + w]);
+                for (uint32_t w = 0; w != sz; ++w) image.push_back(pd.table[pd.off[base + i] + w]);
             }
-            image[i] = ((sz - 1) << 24) | o;
+            image[descs[d].hot_base + i] = ((sz - 1) << 24) | o;
         }
     }
     while (image.size() % 4) image.push_back(0);
@@ -225,9 +238,14 @@ int stage_dictionary(dint_dict& dd, parsed_dict const& pd) {
     dd.view.gmeta = dd.d_gmeta;
     dd.view.gtable = dd.d_gtable;
     dd.view.lds_image = dd.d_image;
+    HIP_TRY(hipMalloc(&dd.d_descs, descs.size() * sizeof(dict_desc)));
+    HIP_TRY(hipMemcpy(dd.d_descs, descs.data(), descs.size() * sizeof(dict_desc), hipMemcpyHostToDevice));
+    dd.view.descs = dd.d_descs;
     dd.view.gtable_words = uint32_t(gtable.size());
     dd.view.hot_words = uint32_t(image.size());
-    dd.view.hot_k = hot_k;
+    dd.view.first = descs[0];
+    dd.hot_entries = 0;
+    for (auto const& x : descs) dd.hot_entries += x.hot_k;
     return DINT_OK;
 }
 
@@ -318,6 +336,9 @@ int dint_dict_create(int kind, const void* file_bytes, size_t len, int device, d
     // the kernel needs the whole 160 KiB of LDS
     if (!hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_single_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsWords * 4)),
+                "hipFuncSetAttribute") ||
+        !hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_multi_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsWords * 4)),
                 "hipFuncSetAttribute")) {
         dint_dict_destroy(dd);
         return DINT_ERR_HIP;
@@ -332,6 +353,7 @@ void dint_dict_destroy(dint_dict* dd) {
     if (dd->d_gmeta) (void)hipFree(dd->d_gmeta);
     if (dd->d_gtable) (void)hipFree(dd->d_gtable);
     if (dd->d_image) (void)hipFree(dd->d_image);
+    if (dd->d_descs) (void)hipFree(dd->d_descs);
     if (dd->ev_start) (void)hipEventDestroy(dd->ev_start);
     if (dd->ev_stop) (void)hipEventDestroy(dd->ev_stop);
     if (dd->d_queues) (void)hipFree(dd->d_queues);
@@ -346,7 +368,7 @@ int dint_dict_info_get(const dint_dict* dd, dint_dict_info* info) {
     info->device = dd->device;
     info->num_dicts = dd->num_dicts;
     info->entries = dd->entries;
-    info->hot_entries = dd->view.hot_k;
+    info->hot_entries = dd->hot_entries;
     info->lds_bytes = dd->view.hot_words * 4;
     info->table_words = dd->view.gtable_words;
     info->compute_units = dd->compute_units;
@@ -451,8 +473,7 @@ int dint_decode_units(const dint_dict* dd, const uint8_t* d_enc, size_t enc_byte
                       size_t n_units, uint32_t* d_out, size_t out_capacity, uint64_t* d_end_off, void* stream) {
     if (!dd) return DINT_ERR_ARG;
     if (n_units == 0) return DINT_OK;
-    if (!d_enc || !d_units || !d_out || enc_bytes < 2 * kSPL) return DINT_ERR_ARG;  // slots are fetched 2*kSPL bytes at a time
-    if (dd->kind == DINT_DICT_MULTI_PACKED) return DINT_ERR_ARG;  // multi kernel: see decode_multi (next)
+    if (!d_enc || !d_units || !d_out || enc_bytes < 8) return DINT_ERR_ARG;  // slots are fetched 8 bytes at a time
     HIP_TRY(hipSetDevice(dd->device));
     decode_args a{};
     a.dict = dd->view;
@@ -475,7 +496,10 @@ int dint_decode_units(const dint_dict* dd, const uint8_t* d_enc, size_t enc_byte
     a.n_shards = std::min<uint32_t>(kQueueShards, grid);
     HIP_TRY(hipMemsetAsync(a.queue, 0, size_t(kQueueShards) * kQueueStride * 4, s));
     HIP_TRY(hipEventRecord(mut->ev_start, s));
-    hipLaunchKernelGGL(decode_single_kernel, dim3(grid), dim3(kBlockThreads), lds_bytes, s, a);
+    if (dd->kind == DINT_DICT_MULTI_PACKED)
+        hipLaunchKernelGGL(decode_multi_kernel, dim3(grid), dim3(kBlockThreads), lds_bytes, s, a);
+    else
+        hipLaunchKernelGGL(decode_single_kernel, dim3(grid), dim3(kBlockThreads), lds_bytes, s, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(mut->ev_stop, s));
     HIP_TRY(hipEventRecord(mut->slot_done[slot], s));

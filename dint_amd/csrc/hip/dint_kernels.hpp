@@ -60,14 +60,23 @@ constexpr uint32_t kLitAddr = 0x70000000u;            // source "address" of an 
 constexpr uint32_t kQueueShards = 8;                  // dynamic unit queue: one counter per shard
 constexpr uint32_t kQueueStride = 32;                 // words between counters (own 128-byte line each)
 
-// Device view of one dictionary (single kinds: num_dicts == 1).
+// One dictionary of the (possibly multi-) dictionary file.
+struct dict_desc {
+    uint32_t meta_base;  // first slot of this dictionary in gmeta
+    uint32_t hot_base;   // LDS word offset of its hot meta table
+    uint32_t hot_k;      // codewords < hot_k have meta + payload in the LDS image
+    uint32_t pad;
+};
+
+// Device view of a dictionary file.
 struct dict_view {
-    const uint32_t* gmeta;      // per codeword: (size-1) << 24 | word offset into gtable
+    const uint32_t* gmeta;      // per codeword slot: (size-1) << 24 | word offset into gtable
     const uint32_t* gtable;     // [256 zeros][payload words...]
-    const uint32_t* lds_image;  // [hot meta: hot_k words][256 zeros][hot payloads], hot_words long
+    const uint32_t* lds_image;  // [256 zeros]{[hot meta of dictionary d]}[hot payloads], hot_words long
+    const dict_desc* descs;     // one per dictionary (multi: 6)
     uint32_t gtable_words;
     uint32_t hot_words;         // multiple of 4
-    uint32_t hot_k;             // codewords < hot_k have meta + payload in the LDS image
+    dict_desc first;            // descs[0], for the single-dictionary kernel
 };
 
 struct decode_args {
@@ -123,21 +132,23 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// kSPL consecutive 16-bit slots of one lane as a 64-bit value (kSPL == 2: low 32
-// bits), from an arbitrary byte address. Never reads past the
-// buffer: the tail lanes load the final bytes and shift (bytes past the end read
-// as zero).
-__device__ __forceinline__ uint64_t load_lane_slots(const uint8_t* enc, uint64_t byte_off, uint64_t last_valid) {
+// kSPL consecutive W-bit slots of one lane (W = 16: 8 bytes, W = 8: 4 bytes) from an
+// arbitrary byte address. Never reads past the buffer: the tail
+// lanes load the final bytes and shift (bytes past the end read as zero).
+template <int W>
+__device__ __forceinline__ uint64_t load_lane_slots(const uint8_t* enc, uint64_t byte_off, uint64_t enc_bytes) {
+    constexpr uint32_t kBytes = kSPL * W / 8;
+    const uint64_t last_valid = enc_bytes - kBytes;  // enc_bytes >= 8 is checked by the host
     const uint64_t o = byte_off < last_valid ? byte_off : last_valid;
     const uint64_t over = byte_off - o;  // 0 for all but the tail lanes
     uint64_t q;
-    if (kSPL == 4) {
+    if (W == 16) {
         const u32x2 r = reinterpret_cast<const u32x2_a1*>(enc + o)->v;
         q = (uint64_t(r.y) << 32) | r.x;
     } else {
         q = reinterpret_cast<const u32_a1*>(enc + o)->v;
     }
-    return over < 2 * kSPL ? q >> (8 * uint32_t(over)) : 0ull;
+    return over < kBytes ? q >> (8 * uint32_t(over)) : 0ull;
 }
 
 struct tile_regs {
@@ -145,55 +156,56 @@ struct tile_regs {
     uint32_t m[kSPL];  // metadata of each slot read as a codeword (garbage for payload slots)
 };
 
+template <int W>
 __device__ __forceinline__ void unpack_slots(uint64_t raw, tile_regs& t) {
 #pragma unroll
-    for (uint32_t k = 0; k != kSPL; ++k) t.s[k] = uint32_t(raw >> (16 * k)) & 0xFFFFu;
+    for (uint32_t k = 0; k != kSPL; ++k) t.s[k] = uint32_t(raw >> (W * k)) & ((1u << W) - 1u);
 }
 
 // Metadata word of a codeword: LDS for the hot codewords, L2 for the cold ones.
 // Two address spaces, two instructions: an unconditional DS read and a global
 // read under the cold lanes' exec mask (a pointer select would turn both into
 // one slow flat load).
-__device__ __forceinline__ uint32_t lookup_meta(const dict_view& d, const uint32_t* lds, uint32_t hot_k,
+__device__ __forceinline__ uint32_t lookup_meta(const dict_view& d, const uint32_t* lds, const dict_desc& dd,
                                                 uint32_t v) {
 #ifdef DINT_EXP_NOCOLD
-    v = v < hot_k ? v : 7 + v % (hot_k - 7);
+    v = v < dd.hot_k ? v : 7 + v % (dd.hot_k - 7);
 #endif
-    const bool hot = v < hot_k;
-    uint32_t m = lds[hot ? v : 0u];
+    const bool hot = v < dd.hot_k;
+    uint32_t m = lds[hot ? dd.hot_base + v : 0u];
     asm volatile("" : "+v"(m));  // keep the DS read a DS read
-    if (!hot) m = d.gmeta[v];
+    if (!hot) m = d.gmeta[dd.meta_base + v];
     return m;
 }
 
-// One unit of a single-dictionary stream (rectangular or packed: the streams
-// are byte-identical, only the dictionary source layout differed on the host).
-__device__ __forceinline__ void decode_unit_single(const decode_args& a, const uint32_t* lds, uint32_t* scratch,
-                                                   uint64_t unit_index, uint32_t lane) {
+// One SEGMENT: n integers from W-bit slots starting at byte in_off, all against one
+// dictionary. A single-dictionary unit is one 16-bit segment; a multi-dictionary
+// unit is a sequence of <= 256-integer segments (blocks), each 16- or 8-bit
+// (vroom_env/dint_codecs.hpp:521-619). Exception payloads are 1 / 2 slots (W = 16)
+// or 2 / 4 slots (W = 8). Returns the byte offset one past the last consumed slot.
+template <int W>
+__device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const uint32_t* lds, uint32_t* scratch,
+                                                   const dict_desc& dd, uint64_t in_off, uint32_t n,
+                                                   uint32_t* const out, uint32_t lane) {
+    constexpr uint32_t kSlotBytes = W / 8;
+    constexpr uint32_t kTileBytes = kTileSlots * kSlotBytes;
     uint32_t* flagw = scratch;              // kCap / 32 words
     uint32_t* wbase = scratch + kCap / 32;  // per flag word: (#flags before it) - 1
     uint32_t* delta = wbase + kCap / 32;    // per codeword ordinal: source - position
     uint32_t* lit = delta + kTileSlots;     // per codeword ordinal: exception value
 
-    const dint_unit* up = a.units + unit_index;
-    const uint64_t in_off = up->in_off;
-    const uint64_t out_off = up->out_off;
-    const uint32_t n = up->n;
-    if (n == 0 || out_off + n > a.out_capacity) return;
-    const uint64_t last_valid = a.enc_bytes >= 2 * kSPL ? a.enc_bytes - 2 * kSPL : 0;
-    const uint32_t hot_k = a.dict.hot_k;
-    uint32_t* const out = a.out + out_off;
+    const uint32_t hot_k = dd.hot_k;
 
     // pipeline: tile t in `cur` (slots + metadata), tile t+1 in `nxt`, tile t+2's slots in flight
-    uint64_t slot_byte = in_off + uint64_t(2 * kSPL) * lane;
+    uint64_t slot_byte = in_off + uint64_t(kSlotBytes * kSPL) * lane;
     tile_regs cur, nxt;
-    unpack_slots(load_lane_slots(a.enc, slot_byte, last_valid), cur);
-    slot_byte += 2 * kTileSlots;
-    uint64_t raw1 = load_lane_slots(a.enc, slot_byte, last_valid);
-    slot_byte += 2 * kTileSlots;
-    uint64_t raw2 = load_lane_slots(a.enc, slot_byte, last_valid);
+    unpack_slots<W>(load_lane_slots<W>(a.enc, slot_byte, a.enc_bytes), cur);
+    slot_byte += kTileBytes;
+    uint64_t raw1 = load_lane_slots<W>(a.enc, slot_byte, a.enc_bytes);
+    slot_byte += kTileBytes;
+    uint64_t raw2 = load_lane_slots<W>(a.enc, slot_byte, a.enc_bytes);
 #pragma unroll
-    for (uint32_t k = 0; k != kSPL; ++k) cur.m[k] = lookup_meta(a.dict, lds, hot_k, cur.s[k]);
+    for (uint32_t k = 0; k != kSPL; ++k) cur.m[k] = lookup_meta(a.dict, lds, dd, cur.s[k]);
 
     uint32_t produced = 0;
     uint32_t carry = 0;            // payload slots an exception of the previous tile still owns
@@ -202,10 +214,10 @@ __device__ __forceinline__ void decode_unit_single(const decode_args& a, const u
 
     while (produced < n) {
         // ---- stage tile t+1: unpack, start its metadata lookups ---------------------
-        unpack_slots(raw1, nxt);
+        unpack_slots<W>(raw1, nxt);
 #pragma unroll
-        for (uint32_t k = 0; k != kSPL; ++k) nxt.m[k] = lookup_meta(a.dict, lds, hot_k, nxt.s[k]);
-        const uint32_t next_lo = uint32_t(raw1);  // slots 0,1 of the next tile (exception spill)
+        for (uint32_t k = 0; k != kSPL; ++k) nxt.m[k] = lookup_meta(a.dict, lds, dd, nxt.s[k]);
+        const uint32_t next_lo = uint32_t(raw1);  // first slots of the next tile (exception spill)
 
         // ---- 1. classification ------------------------------------------------------------
         uint32_t smin = cur.s[0];
@@ -230,7 +242,7 @@ __device__ __forceinline__ void decode_unit_single(const decode_args& a, const u
                     const bool e = !p && cur.s[k] < 2;
                     paybits |= uint32_t(p) << k;
                     excbits |= uint32_t(e) << k;
-                    st = p ? st - 1 : (e ? cur.s[k] + 1 : 0u);
+                    st = p ? st - 1 : (e ? (W == 16 ? cur.s[k] + 1 : 2 * cur.s[k] + 2) : 0u);
                 }
                 st_out = st;
                 uint32_t prev = __shfl_up(st_out, 1);
@@ -240,16 +252,32 @@ __device__ __forceinline__ void decode_unit_single(const decode_args& a, const u
             }
             carry_out = readlane(st_out, 63);
             if (__ballot(excbits != 0)) {
-                // slot values after this lane's: the next lane's first two (lane 63: next tile's)
-                uint32_t nlo = __shfl_down((cur.s[1] << 16) | cur.s[0], 1);
-                if (lane == 63) nlo = readlane(next_lo, 0);
-                uint32_t e[kSPL + 2];
+                // slot values after this lane's: the next lane's first ones (lane 63: next tile's)
+                if (W == 16) {
+                    uint32_t nlo = __shfl_down((cur.s[1] << 16) | cur.s[0], 1);
+                    if (lane == 63) nlo = readlane(next_lo, 0);
+                    uint32_t e[kSPL + 2];
 #pragma unroll
-                for (uint32_t k = 0; k != kSPL; ++k) e[k] = cur.s[k];
-                e[kSPL] = nlo & 0xFFFFu;
-                e[kSPL + 1] = nlo >> 16;
+                    for (uint32_t k = 0; k != kSPL; ++k) e[k] = cur.s[k];
+                    e[kSPL] = nlo & 0xFFFFu;
+                    e[kSPL + 1] = nlo >> 16;
 #pragma unroll
-                for (uint32_t k = 0; k != kSPL; ++k) excval[k] = e[k] == 0 ? e[k + 1] : (e[k + 1] | (e[k + 2] << 16));
+                    for (uint32_t k = 0; k != kSPL; ++k)
+                        excval[k] = e[k] == 0 ? e[k + 1] : (e[k + 1] | (e[k + 2] << 16));
+                } else {
+                    uint32_t nlo = __shfl_down(cur.s[0] | (cur.s[1] << 8) | (cur.s[2] << 16) | (cur.s[3] << 24), 1);
+                    if (lane == 63) nlo = readlane(next_lo, 0);
+                    uint32_t e[kSPL + 4];
+#pragma unroll
+                    for (uint32_t k = 0; k != kSPL; ++k) e[k] = cur.s[k];
+#pragma unroll
+                    for (uint32_t k = 0; k != 4; ++k) e[kSPL + k] = (nlo >> (8 * k)) & 0xFFu;
+#pragma unroll
+                    for (uint32_t k = 0; k != kSPL; ++k) {
+                        const uint32_t lo16 = e[k + 1] | (e[k + 2] << 8);
+                        excval[k] = e[k] == 0 ? lo16 : (lo16 | (e[k + 3] << 16) | (e[k + 4] << 24));
+                    }
+                }
             }
         }
 
@@ -292,7 +320,7 @@ __device__ __forceinline__ void decode_unit_single(const decode_args& a, const u
                     size[k] = size[k] < remaining - pos ? size[k] : remaining - pos;
                     actbits |= 1u << k;
                     const bool exc = (excbits >> k) & 1u;
-                    cand = kSPL * lane + k + 1 + (exc ? cur.s[k] + 1 : 0u);
+                    cand = kSPL * lane + k + 1 + (exc ? (W == 16 ? cur.s[k] + 1 : 2 * cur.s[k] + 2) : 0u);
                 } else {
                     size[k] = 0;
                 }
@@ -408,15 +436,57 @@ __device__ __forceinline__ void decode_unit_single(const decode_args& a, const u
 
         produced += total;
         carry = carry_out;
-        if (produced < n) tile_base += 2 * kTileSlots;
+        if (produced < n) tile_base += kTileBytes;
 
         // ---- rotate the pipeline ---------------------------------------------------
         cur = nxt;
         raw1 = raw2;
-        slot_byte += 2 * kTileSlots;
-        raw2 = load_lane_slots(a.enc, slot_byte, last_valid);
+        slot_byte += kTileBytes;
+        raw2 = load_lane_slots<W>(a.enc, slot_byte, a.enc_bytes);
     }
-    if (a.end_off && lane == 0) a.end_off[unit_index] = tile_base + 2ull * end_slot;
+    return tile_base + uint64_t(kSlotBytes) * end_slot;
+}
+
+// A single-dictionary unit (rectangular or packed: the streams are byte-identical,
+// only the dictionary source layout differed on the host) is one 16-bit segment.
+__device__ __forceinline__ void decode_unit_single(const decode_args& a, const uint32_t* lds, uint32_t* scratch,
+                                                   uint64_t unit_index, uint32_t lane) {
+    const dint_unit* up = a.units + unit_index;
+    const uint64_t out_off = up->out_off;
+    const uint32_t n = up->n;
+    if (n == 0 || out_off + n > a.out_capacity) return;
+    const uint64_t end = decode_segment<16>(a, lds, scratch, a.dict.first, up->in_off, n, a.out + out_off, lane);
+    if (a.end_off && lane == 0) a.end_off[unit_index] = end;
+}
+
+// A multi-dictionary unit: blocks of 256 integers (the last one shorter), each opened
+// by a selector byte: < 6 -> 16-bit codewords against dictionary `selector`, else 8-bit
+// codewords against dictionary `selector - 6` (vroom_env/dint_codecs.hpp:521-619).
+// Blocks carry no length, so they are decoded one after the other.
+__device__ __forceinline__ void decode_unit_multi(const decode_args& a, const uint32_t* lds, uint32_t* scratch,
+                                                  uint64_t unit_index, uint32_t lane) {
+    const dint_unit* up = a.units + unit_index;
+    const uint64_t out_off = up->out_off;
+    const uint32_t n = up->n;
+    if (n == 0 || out_off + n > a.out_capacity) return;
+    uint64_t pos = up->in_off;
+    for (uint32_t done = 0; done < n;) {
+        const uint32_t bsize = n - done < 256u ? n - done : 256u;
+        const uint64_t sp = pos < a.enc_bytes ? pos : a.enc_bytes - 1;
+        const uint32_t sel = uniform(a.enc[sp]);
+        const bool narrow = sel >= 6;
+        const uint32_t d = (narrow ? sel - 6 : sel) % 6;
+        dict_desc dd;
+        dd.meta_base = uniform(a.dict.descs[d].meta_base);
+        dd.hot_base = uniform(a.dict.descs[d].hot_base);
+        dd.hot_k = uniform(a.dict.descs[d].hot_k);
+        dd.pad = 0;
+        uint32_t* const out = a.out + out_off + done;
+        if (narrow) pos = decode_segment<8>(a, lds, scratch, dd, pos + 1, bsize, out, lane);
+        else pos = decode_segment<16>(a, lds, scratch, dd, pos + 1, bsize, out, lane);
+        done += bsize;
+    }
+    if (a.end_off && lane == 0) a.end_off[unit_index] = pos;
 }
 
 // Units are handed out dynamically: their cost varies a lot (a sparse list full
@@ -426,7 +496,8 @@ __device__ __forceinline__ void decode_unit_single(const decode_args& a, const u
 // workgroups that share an XCD under round-robin placement; a speed choice only)
 // each serve the units u = shard + n_shards * j; a wave draws its next index
 // while it is still decoding the current unit.
-__global__ __launch_bounds__(kBlockThreads) void decode_single_kernel(decode_args a) {
+template <bool MULTI>
+__device__ __forceinline__ void decode_kernel_body(const decode_args& a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     for (uint32_t i = threadIdx.x; i < a.dict.hot_words; i += kBlockThreads) lds[i] = a.dict.lds_image[i];
     __syncthreads();
@@ -444,10 +515,15 @@ __global__ __launch_bounds__(kBlockThreads) void decode_single_kernel(decode_arg
     uint32_t j = draw();
     while (j < shard_units) {
         const uint32_t j_next = draw();
-        decode_unit_single(a, lds, scratch, uint64_t(shard) + uint64_t(a.n_shards) * j, lane);
+        const uint64_t u = uint64_t(shard) + uint64_t(a.n_shards) * j;
+        if (MULTI) decode_unit_multi(a, lds, scratch, u, lane);
+        else decode_unit_single(a, lds, scratch, u, lane);
         j = j_next;
     }
 }
+
+__global__ __launch_bounds__(kBlockThreads) void decode_single_kernel(decode_args a) { decode_kernel_body<false>(a); }
+__global__ __launch_bounds__(kBlockThreads) void decode_multi_kernel(decode_args a) { decode_kernel_body<true>(a); }
 
 // test hook: out[i] = inclusive prefix sum of in[0..i] over one wave
 __global__ void debug_wave_scan_kernel(const uint32_t* in, uint32_t* out) {

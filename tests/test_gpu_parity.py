@@ -8,6 +8,7 @@ from dint_amd import host
 pytestmark = pytest.mark.gpu
 
 SINGLE_KINDS = [host.SINGLE_PACKED, host.RECTANGULAR]
+ALL_KINDS = SINGLE_KINDS + [host.MULTI_PACKED]
 
 
 @pytest.fixture(scope="module")
@@ -28,7 +29,7 @@ def test_wave_scan(device):
     assert np.array_equal(device.debug_wave_scan(np.ones(64)), np.arange(1, 65, dtype=np.uint32))
 
 
-@pytest.mark.parametrize("kind", SINGLE_KINDS)
+@pytest.mark.parametrize("kind", ALL_KINDS)
 @pytest.mark.parametrize("corpus_name", ["small_corpus", "dense_corpus", "sparse_corpus"])
 def test_stream_matches_oracle(device, request, kind, corpus_name):
     corpus = request.getfixturevalue(corpus_name)
@@ -44,7 +45,7 @@ def test_stream_matches_oracle(device, request, kind, corpus_name):
     assert ends[-1] == enc.size
 
 
-@pytest.mark.parametrize("kind", SINGLE_KINDS)
+@pytest.mark.parametrize("kind", ALL_KINDS)
 def test_index_stream_equals_encoder_sidecar(device, small_corpus, kind):
     """The host pre-pass finds the same list boundaries the encoder recorded."""
     enc, units = small_corpus.encoded(kind)
@@ -61,7 +62,7 @@ def test_index_stream_equals_encoder_sidecar(device, small_corpus, kind):
     assert np.array_equal(idx0["in_off"], units["in_off"][first])
 
 
-@pytest.mark.parametrize("kind", SINGLE_KINDS)
+@pytest.mark.parametrize("kind", ALL_KINDS)
 def test_decode_list_call_shape(device, small_corpus, kind):
     """Coder::decode(dict, in, out, universe, n) -> in_end, one list at a time."""
     enc, _ = small_corpus.encoded(kind)
@@ -155,3 +156,19 @@ def test_full_size_properties(device):
     got = out_dev.cpu().numpy().view(np.uint32)
     assert np.array_equal(got, coll.gaps)
     assert int(got.sum(dtype=np.uint64)) == int(coll.gaps.sum(dtype=np.uint64))
+
+
+@pytest.mark.parametrize("case", cases("multi_cases"), ids=lambda c: c[0])
+def test_multi_kat(device, case):
+    name, buf, off, n, expect = case
+    d = device.Dictionary(host.MULTI_PACKED, DICT_FILES[2])
+    got, consumed = d.decode_list(buf, off, n)
+    assert np.array_equal(got, expect)
+    assert consumed == buf.size - off
+
+
+def test_multi_blocks_use_both_codeword_widths(small_corpus):
+    """Guard against a vacuous multi test: the corpus must exercise 16-bit AND 8-bit blocks."""
+    enc, units = small_corpus.encoded(host.MULTI_PACKED)
+    sels = enc[units["in_off"].astype(np.int64)]
+    assert (sels < 6).any() and (sels >= 6).any() and (sels < 12).all()
