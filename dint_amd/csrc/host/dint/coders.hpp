@@ -1,0 +1,137 @@
+// The reference's Coder / Dictionary operator surface over the device path.
+//
+// A ds2i-style *Coder* is a struct of statics (reference include/dint/dint_codecs.hpp:
+// 141-283; whole-list twins vroom_env/dint_codecs.hpp:109-331, :333-619):
+//
+//   encode(Builder&, uint32_t const* in, uint32_t universe, uint32_t n, std::vector<uint8_t>& out)
+//   decode(Dictionary const&, uint8_t const* in, uint32_t* out, uint32_t universe, size_t n)
+//       -> uint8_t const*            (pointer one past the consumed bytes)
+//
+// and a *Dictionary* carries a nested `builder` with load / build(dict)
+// (single_dictionary.hpp:24-226). The types below have exactly those shapes, so code
+// written against the reference (vroom_env/decode.cpp:95-155) compiles against them;
+// `encode` runs the CPU encoders of encoders.hpp, `decode` goes through the C ABI of
+// include/dint_hip.h to the HIP kernels. There is no CPU decode here.
+//
+// The per-call `decode` is the reference's granularity (one list per call): it uploads,
+// runs ONE unit on the device and downloads — correct for any n, but one wavefront
+// wide. Throughput comes from the batched entry point (`dint::decode_stream`, or
+// dint_decode_units directly), which is what tools/dint_decode.cpp uses.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "dint_hip.h"
+#include "dictionaries.hpp"
+#include "encoders.hpp"
+
+namespace dint {
+
+inline void check(int status, char const* what) {
+    if (status != DINT_OK)
+        throw std::runtime_error(std::string(what) + ": " + dint_strerror(status) +
+                                 (status == DINT_ERR_HIP ? std::string(" — ") + dint_last_hip_error() : ""));
+}
+
+// Device-resident dictionary with the reference's `Dictionary` shape: default
+// constructible, filled by builder::build(dict), movable.
+template <typename HostBuilder>
+class device_dictionary {
+public:
+    static const uint32_t num_entries = kNumEntries;
+    static const uint32_t max_entry_size = kMaxEntrySize;
+    static const uint32_t reserved = kReserved;
+
+    // The nested builder: the host builder (file formats, append/build, encoder
+    // lookup) plus build(dict), which stages the dictionary on a device.
+    struct builder : HostBuilder {
+        size_t load(std::vector<uint8_t> const& file_bytes) {
+            HostBuilder::load(file_bytes.data(), file_bytes.size());
+            m_file = file_bytes;
+            return file_bytes.size();
+        }
+        void build(device_dictionary& dict, int device = 0) {
+            if (m_file.empty()) HostBuilder::write(m_file);
+            dint_dict* h = nullptr;
+            check(dint_dict_create(int(HostBuilder::kind), m_file.data(), m_file.size(), device, &h),
+                  "dint_dict_create");
+            dict.reset(h);
+        }
+
+    private:
+        std::vector<uint8_t> m_file;
+    };
+
+    device_dictionary() = default;
+    device_dictionary(device_dictionary const&) = delete;
+    device_dictionary& operator=(device_dictionary const&) = delete;
+    device_dictionary(device_dictionary&& o) noexcept : m_handle(o.m_handle) { o.m_handle = nullptr; }
+    ~device_dictionary() { reset(nullptr); }
+    void swap(device_dictionary& o) { std::swap(m_handle, o.m_handle); }
+    dint_dict* handle() const { return m_handle; }
+    void reset(dint_dict* h) {
+        if (m_handle) dint_dict_destroy(m_handle);
+        m_handle = h;
+    }
+
+private:
+    dint_dict* m_handle = nullptr;
+};
+
+using single_dictionary_rectangular_type = device_dictionary<rectangular_builder>;  // dictionary_types.hpp:8-9
+using single_dictionary_packed_type = device_dictionary<single_packed_builder>;     // :10-12
+using multi_dictionary_packed_type = device_dictionary<multi_packed_builder>;       // :19-21
+
+namespace detail {
+// Upper bound of the bytes n integers can occupy: every integer a 32-bit exception
+// (6 bytes with 16-bit codewords), plus one selector byte per 256 integers.
+inline size_t worst_case_bytes(size_t n) { return 6 * n + n / 256 + 16; }
+
+template <typename Dictionary>
+uint8_t const* decode_list(Dictionary const& dict, uint8_t const* in, uint8_t const* in_end, uint32_t* out,
+                           size_t n) {
+    size_t consumed = 0;
+    check(dint_decode_list_host(dict.handle(), in, size_t(in_end - in), out, n, &consumed), "dint_decode_list_host");
+    return in + consumed;
+}
+}  // namespace detail
+
+// Device-backed Coders. `in_end` bounds what may be read (and uploaded); the
+// reference-shaped overload assumes worst_case_bytes(n) are readable, which holds
+// for a list inside a larger buffer but not for the last list of an mmap'ed file —
+// use the bounded overload there.
+struct single_opt_dint_device : single_opt_dint {
+    template <typename Dictionary>
+    static uint8_t const* decode(Dictionary const& dict, uint8_t const* in, uint32_t* out, uint32_t /*universe*/,
+                                 size_t n) {
+        return detail::decode_list(dict, in, in + detail::worst_case_bytes(n), out, n);
+    }
+    template <typename Dictionary>
+    static uint8_t const* decode(Dictionary const& dict, uint8_t const* in, uint8_t const* in_end, uint32_t* out,
+                                 uint32_t /*universe*/, size_t n) {
+        return detail::decode_list(dict, in, in_end, out, n);
+    }
+};
+struct single_greedy_dint_device : single_greedy_dint {
+    template <typename Dictionary>
+    static uint8_t const* decode(Dictionary const& dict, uint8_t const* in, uint32_t* out, uint32_t universe,
+                                 size_t n) {
+        return single_opt_dint_device::decode(dict, in, out, universe, n);
+    }
+};
+struct multi_opt_dint_device : multi_opt_dint {
+    template <typename Dictionary>
+    static uint8_t const* decode(Dictionary const& dict, uint8_t const* in, uint32_t* out, uint32_t /*universe*/,
+                                 size_t n) {
+        return detail::decode_list(dict, in, in + detail::worst_case_bytes(n), out, n);
+    }
+    template <typename Dictionary>
+    static uint8_t const* decode(Dictionary const& dict, uint8_t const* in, uint8_t const* in_end, uint32_t* out,
+                                 uint32_t /*universe*/, size_t n) {
+        return detail::decode_list(dict, in, in_end, out, n);
+    }
+};
+
+}  // namespace dint
