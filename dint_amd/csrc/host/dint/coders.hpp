@@ -120,6 +120,11 @@ struct single_greedy_dint_device : single_greedy_dint {
                                  size_t n) {
         return single_opt_dint_device::decode(dict, in, out, universe, n);
     }
+    template <typename Dictionary>
+    static uint8_t const* decode(Dictionary const& dict, uint8_t const* in, uint8_t const* in_end, uint32_t* out,
+                                 uint32_t universe, size_t n) {
+        return single_opt_dint_device::decode(dict, in, in_end, out, universe, n);
+    }
 };
 struct multi_opt_dint_device : multi_opt_dint {
     template <typename Dictionary>
