@@ -241,6 +241,7 @@ int stage_dictionary(dint_dict& dd, parsed_dict const& pd) {
     HIP_TRY(hipMalloc(&dd.d_descs, descs.size() * sizeof(dict_desc)));
     HIP_TRY(hipMemcpy(dd.d_descs, descs.data(), descs.size() * sizeof(dict_desc), hipMemcpyHostToDevice));
     dd.view.descs = dd.d_descs;
+    dd.view.gmeta_words = uint32_t(gmeta.size());
     dd.view.gtable_words = uint32_t(gtable.size());
     dd.view.hot_words = uint32_t(image.size());
     dd.view.first = descs[0];
@@ -487,7 +488,7 @@ int dint_decode_units(const dint_dict* dd, const uint8_t* d_enc, size_t enc_byte
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint64_t blocks_needed = (uint64_t(n_units) + kWavesPerBlock - 1) / kWavesPerBlock;
     const uint32_t grid = uint32_t(std::min<uint64_t>(blocks_needed, std::max<uint32_t>(1, dd->compute_units) * kBlocksPerCU));
-    const size_t lds_bytes = (size_t(dd->view.hot_words) + kWavesPerBlock * kScratchWords) * 4;
+    const size_t lds_bytes = (size_t(dd->view.hot_words) + kClassTableWords + kWavesPerBlock * kScratchWords) * 4;
     dint_dict* mut = const_cast<dint_dict*>(dd);
     std::lock_guard<std::mutex> lock(mut->launch_mutex);
     const uint32_t slot = mut->next_slot.fetch_add(1) % dint_dict::kQueueSlots;
@@ -561,6 +562,16 @@ int dint_decode_list_host(const dint_dict* dd, const uint8_t* in, size_t in_byte
     cleanup();
     return st;
 }
+
+#ifdef DINT_STAMPS
+// Diagnostic build only: read and clear the per-phase wave-cycle sums.
+int dint_debug_read_stamps(unsigned long long* out16) {
+    HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(dint_dev::g_stamps), 16 * sizeof(unsigned long long)));
+    unsigned long long zeros[16] = {};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(dint_dev::g_stamps), zeros, sizeof zeros));
+    return DINT_OK;
+}
+#endif
 
 // Test hook (not part of the decode ABI): inclusive wave prefix sum of 64 host words.
 int dint_debug_wave_scan(const uint32_t* in64, uint32_t* out64) {

@@ -27,7 +27,8 @@
 //
 // LDS (160 KB/CU, one 1024-thread workgroup per CU):
 //   [ hot meta | 256 zero words | hot payloads ]  <= kHotImageWords, shared by 16 waves
-//   16 x [ flag bitmap | rank bases | per-codeword delta table | literal table ]
+//   [ slot classification table, 4 KB ]
+//   16 x [ {flag word, rank base} pairs | per-codeword delta table | literal table ]
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -50,13 +51,19 @@ constexpr uint32_t kBlocksPerCU = DINT_BLOCKS_PER_CU;
 constexpr uint32_t kLdsWords = 160 * 1024 / 4 / kBlocksPerCU;
 constexpr uint32_t kSPL = 4;                          // slots per lane per tile
 constexpr uint32_t kTileSlots = kWave * kSPL;         // 256 slots per tile
-constexpr uint32_t kCap = 2048;                       // outputs per expansion batch (>= kSPL * 256)
-// per wave: flag bitmap, per-word rank bases, per-codeword delta and literal tables
-constexpr uint32_t kScratchWords = kCap / 32 + kCap / 32 + kTileSlots + kTileSlots;
-constexpr uint32_t kHotImageWords = kLdsWords - kWavesPerBlock * kScratchWords;
+constexpr uint32_t kGroups = 4;                       // 256-output groups expanded together
+constexpr uint32_t kCap = kGroups * 256;              // outputs per expansion batch (>= kSPL * 256)
+// per wave: 64 {flag word, rank base} pairs (+ spare), per-codeword delta table (+ 4 dummy
+// entries for codewords that are not live in a batch), literal table of the same shape
+constexpr uint32_t kFwWords = 2 * 64 + 4;              // 64 pairs: flag positions are taken mod 2048
+constexpr uint32_t kDeltaWords = kTileSlots + 4;
+constexpr uint32_t kScratchWords = kFwWords + 2 * kDeltaWords;
+constexpr uint32_t kClassTableWords = (3 * 256 + 5 * 256) / 2;  // slot classification table (u16 rows)
+constexpr uint32_t kHotImageWords = kLdsWords - kClassTableWords - kWavesPerBlock * kScratchWords;
 constexpr uint32_t kZeroWords = 256;                  // longest run codeword
 constexpr uint32_t kColdBase = 1u << 24;              // source offsets >= this live in global memory
-constexpr uint32_t kLitAddr = 0x70000000u;            // source "address" of an exception literal
+constexpr uint32_t kColdBase4 = 4 * kColdBase;        // the same in bytes
+constexpr uint32_t kLitAddr4 = 0xC0000000u;           // source byte "address" of an exception literal
 constexpr uint32_t kQueueShards = 8;                  // dynamic unit queue: one counter per shard
 constexpr uint32_t kQueueStride = 32;                 // words between counters (own 128-byte line each)
 
@@ -74,6 +81,7 @@ struct dict_view {
     const uint32_t* gtable;     // [256 zeros][payload words...]
     const uint32_t* lds_image;  // [256 zeros]{[hot meta of dictionary d]}[hot payloads], hot_words long
     const dict_desc* descs;     // one per dictionary (multi: 6)
+    uint32_t gmeta_words;
     uint32_t gtable_words;
     uint32_t hot_words;         // multiple of 4
     dict_desc first;            // descs[0], for the single-dictionary kernel
@@ -178,23 +186,93 @@ __device__ __forceinline__ uint32_t lookup_meta(const dict_view& d, const uint32
     return m;
 }
 
+// Slot classification table. Whether a slot is a codeword header or an exception
+// payload depends on its predecessors; per lane (4 consecutive slots) the outcome is a
+// function of: how many payload slots the previous lane still owes (st_in), which slots
+// are < 2 (L) and which are == 1 (O). One table row per (st_in, O, L):
+//   bits 0-3 payload slots, bits 4-7 exception headers, bits 8-10 st_out.
+// Rows [0, 768) are for 16-bit slots (payloads of 1 / 2 slots), rows [768, 2048) for
+// 8-bit slots (2 / 4 slots).
+constexpr uint32_t kClassRows = 3 * 256 + 5 * 256;
+constexpr uint32_t kClassWords = kClassRows / 2;  // u16 entries
+
+__device__ __forceinline__ uint32_t class_row(uint32_t w16, uint32_t st, uint32_t O, uint32_t L) {
+    uint32_t pay = 0, exc = 0;
+    for (uint32_t k = 0; k != 4; ++k) {
+        const bool p = st != 0;
+        const bool e = !p && ((L >> k) & 1u);
+        const bool one = (O >> k) & 1u;
+        pay |= uint32_t(p) << k;
+        exc |= uint32_t(e) << k;
+        st = p ? st - 1 : (e ? (w16 ? (one ? 2u : 1u) : (one ? 4u : 2u)) : 0u);
+    }
+    return pay | (exc << 4) | (st << 8);
+}
+
+__device__ __forceinline__ void build_class_table(uint16_t* table) {
+    for (uint32_t i = threadIdx.x; i < kClassRows; i += kBlockThreads) {
+        const bool w16 = i < 768;
+        const uint32_t j = w16 ? i : i - 768;
+        table[i] = uint16_t(class_row(w16, j >> 8, (j >> 4) & 15u, j & 15u));
+    }
+}
+
 // One SEGMENT: n integers from W-bit slots starting at byte in_off, all against one
 // dictionary. A single-dictionary unit is one 16-bit segment; a multi-dictionary
 // unit is a sequence of <= 256-integer segments (blocks), each 16- or 8-bit
 // (vroom_env/dint_codecs.hpp:521-619). Exception payloads are 1 / 2 slots (W = 16)
 // or 2 / 4 slots (W = 8). Returns the byte offset one past the last consumed slot.
+#ifdef DINT_STAMPS
+// Diagnostic build only: wave-cycles per phase, summed over all waves (never in the shipped kernel).
+__device__ unsigned long long g_stamps[16];
+#define STAMP(i)                                                  \
+    do {                                                          \
+        __builtin_amdgcn_sched_barrier(0);                        \
+        const uint64_t now_ = __builtin_amdgcn_s_memtime();       \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                       \
+        tacc[i] += now_ - tprev;                                  \
+        tprev = now_;                                             \
+        __builtin_amdgcn_sched_barrier(0);                        \
+    } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
 template <int W>
-__device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const uint32_t* lds, uint32_t* scratch,
-                                                   const dict_desc& dd, uint64_t in_off, uint32_t n,
-                                                   uint32_t* const out, uint32_t lane) {
+__device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const uint32_t* lds, const uint16_t* cls,
+                                                   uint32_t* scratch, const dict_desc& dd, uint64_t in_off,
+                                                   uint32_t n, uint32_t* const out, uint32_t lane) {
     constexpr uint32_t kSlotBytes = W / 8;
     constexpr uint32_t kTileBytes = kTileSlots * kSlotBytes;
-    uint32_t* flagw = scratch;              // kCap / 32 words
-    uint32_t* wbase = scratch + kCap / 32;  // per flag word: (#flags before it) - 1
-    uint32_t* delta = wbase + kCap / 32;    // per codeword ordinal: source - position
-    uint32_t* lit = delta + kTileSlots;     // per codeword ordinal: exception value
+    // per-wave scratch (byte offsets): {flag word, rank base} pairs | delta table | literal table
+    uint8_t* const fw = reinterpret_cast<uint8_t*>(scratch);                  // 64 pairs of 8 bytes (+1 spare)
+    uint8_t* const delta = reinterpret_cast<uint8_t*>(scratch + kFwWords);    // 256 entries + 4 dummies
+    constexpr uint32_t kLitOff = 4 * kDeltaWords;                             // literal table = delta + kLitOff
+    const uint8_t* const lds_bytes = reinterpret_cast<const uint8_t*>(lds);
+    const uint16_t* const rows = cls + (W == 16 ? 0 : 768);
 
     const uint32_t hot_k = dd.hot_k;
+    const __amdgpu_buffer_rsrc_t rs_meta =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.dict.gmeta), 0, int(a.dict.gmeta_words * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_table =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.dict.gtable), 0, int(a.dict.gtable_words * 4), 0x00020000);
+    // hardware bounds: nothing past this segment's n integers can be written
+    const uint64_t out_bits = reinterpret_cast<uint64_t>(out);
+    uint32_t* const out_u = reinterpret_cast<uint32_t*>((uint64_t(uniform(uint32_t(out_bits >> 32))) << 32) |
+                                                        uniform(uint32_t(out_bits)));
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out_u, 0, int(uniform(n) * 4), 0x00020000);
+
+    auto meta_of = [&](uint32_t v) -> uint32_t {
+#ifdef DINT_EXP_NOCOLD
+        v = v < hot_k ? v : 7 + v % (hot_k - 7);
+#endif
+        // LDS for the hot codewords (unconditional read: cold lanes read word 0), L2 for the cold ones
+        const bool hot = v < hot_k;
+        uint32_t m = lds[hot ? dd.hot_base + v : 0u];
+        asm volatile("" : "+v"(m));  // keep the DS read a DS read (no pointer select -> flat load)
+        if (!hot) m = __builtin_amdgcn_raw_buffer_load_b32(rs_meta, 4 * (dd.meta_base + v), 0, 0);
+        return m;
+    };
 
     // pipeline: tile t in `cur` (slots + metadata), tile t+1 in `nxt`, tile t+2's slots in flight
     uint64_t slot_byte = in_off + uint64_t(kSlotBytes * kSPL) * lane;
@@ -205,53 +283,56 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
     slot_byte += kTileBytes;
     uint64_t raw2 = load_lane_slots<W>(a.enc, slot_byte, a.enc_bytes);
 #pragma unroll
-    for (uint32_t k = 0; k != kSPL; ++k) cur.m[k] = lookup_meta(a.dict, lds, dd, cur.s[k]);
+    for (uint32_t k = 0; k != kSPL; ++k) cur.m[k] = meta_of(cur.s[k]);
+
+    // lane constants of the expansion: this lane owns outputs 4*lane .. 4*lane+3 of every group
+    const uint32_t sh = (4 * lane) & 31u;                 // bit position of its nibble in its flag word
+    const uint32_t below = (1u << sh) - 1u;               // flag bits before that nibble
+    const uint32_t pair_byte = (lane >> 3) * 8;           // its {flag, base} pair inside a group's 8 pairs
 
     uint32_t produced = 0;
     uint32_t carry = 0;            // payload slots an exception of the previous tile still owns
     uint64_t tile_base = in_off;   // byte offset of slot 0 of the current tile
     uint32_t end_slot = 0;
+#ifdef DINT_STAMPS
+    uint64_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t tprev = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+    STAMP(7);  // segment prologue (unit descriptor, first slot + metadata loads)
 
     while (produced < n) {
-        // ---- stage tile t+1: unpack, start its metadata lookups ---------------------
-        unpack_slots<W>(raw1, nxt);
-#pragma unroll
-        for (uint32_t k = 0; k != kSPL; ++k) nxt.m[k] = lookup_meta(a.dict, lds, dd, nxt.s[k]);
         const uint32_t next_lo = uint32_t(raw1);  // first slots of the next tile (exception spill)
 
-        // ---- 1. classification ------------------------------------------------------------
+        // ---- 1. classification: table lookup, repeated until the lane-to-lane carries agree ----
         uint32_t smin = cur.s[0];
 #pragma unroll
         for (uint32_t k = 1; k != kSPL; ++k) smin = smin < cur.s[k] ? smin : cur.s[k];
-        const bool any_exc = __ballot(smin < 2) != 0 || carry != 0;
+        const bool special = __ballot(smin < 2) != 0 || carry != 0;
         uint32_t paybits = 0, excbits = 0;
         uint32_t carry_out = 0;
         uint32_t excval[kSPL];
 #pragma unroll
         for (uint32_t k = 0; k != kSPL; ++k) excval[k] = 0;
-        if (any_exc) {
-            uint32_t st_in = lane == 0 ? carry : 0u;
-            uint32_t st_out;
-            for (;;) {
-                uint32_t st = st_in;
-                paybits = 0;
-                excbits = 0;
+        bool tile_exc = false;
+        if (special) {
+            uint32_t lo = 0;  // O << 4 | L
 #pragma unroll
-                for (uint32_t k = 0; k != kSPL; ++k) {
-                    const bool p = st != 0;
-                    const bool e = !p && cur.s[k] < 2;
-                    paybits |= uint32_t(p) << k;
-                    excbits |= uint32_t(e) << k;
-                    st = p ? st - 1 : (e ? (W == 16 ? cur.s[k] + 1 : 2 * cur.s[k] + 2) : 0u);
-                }
-                st_out = st;
-                uint32_t prev = __shfl_up(st_out, 1);
+            for (uint32_t k = 0; k != kSPL; ++k) lo |= (cur.s[k] < 2 ? 1u << k : 0u) | (cur.s[k] == 1 ? 16u << k : 0u);
+            uint32_t st_in = lane == 0 ? carry : 0u;
+            uint32_t row;
+            for (;;) {
+                row = rows[st_in * 256 + lo];
+                uint32_t prev = __shfl_up(row >> 8, 1);
                 if (lane == 0) prev = carry;
                 if (__ballot(prev != st_in) == 0) break;
                 st_in = prev;
             }
-            carry_out = readlane(st_out, 63);
-            if (__ballot(excbits != 0)) {
+            paybits = row & 15u;
+            excbits = (row >> 4) & 15u;
+            carry_out = readlane(row >> 8, 63);
+            tile_exc = __ballot(excbits != 0) != 0;
+            if (tile_exc) {
                 // slot values after this lane's: the next lane's first ones (lane 63: next tile's)
                 if (W == 16) {
                     uint32_t nlo = __shfl_down((cur.s[1] << 16) | cur.s[0], 1);
@@ -281,150 +362,195 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
             }
         }
 
-        // ---- 2. sizes, offsets, ordinals --------------------------------------------------
-        uint32_t size[kSPL], src[kSPL];
+        STAMP(1);  // classification
+        // ---- 2. sizes, offsets, ordinals (sizes and sources in BYTES of output / payload) --------
+        uint32_t sz4[kSPL], src4[kSPL];
+        bool live[kSPL];
 #pragma unroll
         for (uint32_t k = 0; k != kSPL; ++k) {
-            const bool hdr = !((paybits >> k) & 1u);
-            const bool exc = (excbits >> k) & 1u;
-            size[k] = hdr ? (exc ? 1u : (cur.m[k] >> 24) + 1u) : 0u;
-            src[k] = (cur.m[k] & 0xFFFFFFu) + (cur.s[k] < hot_k ? 0u : kColdBase);
+            const uint32_t m = cur.m[k];
+            sz4[k] = ((m >> 22) & 0x3FCu) + 4u;
+            src4[k] = ((m << 2) & 0x3FFFFFCu) + (cur.s[k] < hot_k ? 0u : kColdBase4);
 #ifdef DINT_EXP_NOCOLD
-            src[k] = cur.m[k] & 0xFFFFFFu;
+            src4[k] = (m << 2) & 0x3FFFFFCu;
 #endif
+            live[k] = true;
         }
-        const uint32_t hdrbits = ~paybits & 0xFu;
-        uint32_t off[kSPL];
-        off[0] = 0;
+        uint32_t hdrcnt = 4;
+        if (special) {
 #pragma unroll
-        for (uint32_t k = 1; k != kSPL; ++k) off[k] = off[k - 1] + size[k - 1];
-        const uint32_t lsum = off[kSPL - 1] + size[kSPL - 1];
-        const uint32_t packed = (uint32_t(__builtin_popcount(hdrbits)) << 24) | lsum;
+            for (uint32_t k = 0; k != kSPL; ++k) {
+                const bool pay = (paybits >> k) & 1u;
+                const bool exc = (excbits >> k) & 1u;
+                sz4[k] = pay ? 0u : (exc ? 4u : sz4[k]);
+                src4[k] = exc ? kLitAddr4 : src4[k];
+                live[k] = !pay;
+            }
+            hdrcnt = 4 - uint32_t(__builtin_popcount(paybits));
+        }
+        uint32_t off4[kSPL];
+        off4[0] = 0;
+#pragma unroll
+        for (uint32_t k = 1; k != kSPL; ++k) off4[k] = off4[k - 1] + sz4[k - 1];
+        uint32_t lsum = (off4[kSPL - 1] + sz4[kSPL - 1]) >> 2;
+        const uint32_t packed = (hdrcnt << 24) | lsum;
         const uint32_t pincl = wave_inclusive_sum(packed);
         const uint32_t pexcl = pincl - packed;
         const uint32_t obase = pexcl & 0xFFFFFFu;  // first output of this lane's codewords
         const uint32_t rbase = pexcl >> 24;        // ordinal of this lane's first codeword
         const uint32_t remaining = n - produced;
         uint32_t total = readlane(pincl, 63) & 0xFFFFFFu;
-        uint32_t actbits = hdrbits;
-        uint32_t lsum_c = lsum;
-        if (total >= remaining) {  // last tile of the unit: clamp, and find where the stream ends
+        if (total >= remaining) {  // last tile of the segment: clamp, and find where the stream ends
             total = remaining;
             uint32_t cand = 0;
-            actbits = 0;
 #pragma unroll
             for (uint32_t k = 0; k != kSPL; ++k) {
-                const uint32_t pos = obase + off[k];
-                const bool act = ((hdrbits >> k) & 1u) && pos < remaining;
+                const uint32_t pos = obase + (off4[k] >> 2);
+                const bool act = live[k] && pos < remaining;
                 if (act) {
-                    size[k] = size[k] < remaining - pos ? size[k] : remaining - pos;
-                    actbits |= 1u << k;
+                    const uint32_t room4 = 4 * (remaining - pos);
+                    sz4[k] = sz4[k] < room4 ? sz4[k] : room4;
                     const bool exc = (excbits >> k) & 1u;
                     cand = kSPL * lane + k + 1 + (exc ? (W == 16 ? cur.s[k] + 1 : 2 * cur.s[k] + 2) : 0u);
-                } else {
-                    size[k] = 0;
                 }
+                live[k] = act;
             }
-            lsum_c = obase < remaining ? (obase + lsum < remaining ? lsum : remaining - obase) : 0u;
-            const uint64_t am = __ballot(actbits != 0);
+            lsum = obase < remaining ? (obase + lsum < remaining ? lsum : remaining - obase) : 0u;
+            const uint64_t am = __ballot(cand != 0);
             end_slot = readlane(cand, 63u - uint32_t(__builtin_clzll(am | 1ull)));
         }
-        // ordinal of codeword k inside the lane
+        // ordinal of codeword k inside the lane (headers before it)
         uint32_t lord[kSPL];
         lord[0] = 0;
 #pragma unroll
-        for (uint32_t k = 1; k != kSPL; ++k) lord[k] = lord[k - 1] + ((hdrbits >> (k - 1)) & 1u);
+        for (uint32_t k = 1; k != kSPL; ++k) lord[k] = lord[k - 1] + (special ? ((~paybits >> (k - 1)) & 1u) : 1u);
+        uint32_t nlive = 0;
+#pragma unroll
+        for (uint32_t k = 0; k != kSPL; ++k) nlive += live[k] ? 1u : 0u;
 
-        // ---- 3./4. batches of <= kCap outputs -------------------------------------------------
+        STAMP(2);  // sizes, scan
+        // ---- prefetch: metadata of tile t+1 (its slots are already here), slots of tile t+2. Issued
+        // before this tile's cold gathers and stores; waited for together with the gathers, right
+        // before the stores (vmcnt is one in-order counter for loads AND stores on gfx950: a wait
+        // placed after the stores would also wait for their acknowledgements).
+        unpack_slots<W>(raw1, nxt);
+#pragma unroll
+        for (uint32_t k = 0; k != kSPL; ++k) nxt.m[k] = meta_of(nxt.s[k]);
+        slot_byte += kTileBytes;
+        const uint64_t raw3 = load_lane_slots<W>(a.enc, slot_byte, a.enc_bytes);
+        STAMP(0);
+        // ---- 3./4. batches of <= kCap outputs (normally one: the whole tile) ------------------------
         uint32_t done = 0, rdone = 0;
         while (done < total) {
-            const bool inb = lsum_c != 0 && obase >= done && (obase + lsum_c - done) <= kCap;
+            const bool inb = lsum != 0 && obase >= done && (obase + lsum - done) <= kCap;
             const uint64_t bm = __ballot(inb);
             const uint32_t last = 63u - uint32_t(__builtin_clzll(bm | 1ull));
-            const uint32_t bend = readlane(obase + lsum_c, last);
-            const uint32_t rend = readlane(rbase + uint32_t(__builtin_popcount(actbits)), last);
+            const uint32_t bend = readlane(obase + lsum, last);
+            const uint32_t rend = readlane(rbase + nlive, last);
             const uint32_t bt = bend - done;  // outputs in this batch, 1..kCap
-            const uint32_t nwords = (bt + 31) >> 5;
 
-            if (lane < nwords) flagw[lane] = 0;
+            *reinterpret_cast<uint32_t*>(fw + 8 * lane) = 0;  // clear all 64 flag words
             wave_lds_fence();
-            bool any_lit = false;
-            if (inb) {
+            // Every slot runs the same instructions: a codeword that is not live in this batch ORs
+            // a zero into an in-range flag word and parks its delta in a dummy entry.
+            bool any_cold = false;
+            const uint32_t rel0 = obase - done, ord0 = rbase - rdone;
 #pragma unroll
-                for (uint32_t k = 0; k != kSPL; ++k) {
-                    if ((actbits >> k) & 1u) {
-                        const uint32_t rel = obase + off[k] - done;
-                        const uint32_t ord = rbase + lord[k] - rdone;
-                        __hip_atomic_fetch_or(&flagw[rel >> 5], 1u << (rel & 31u), __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_WAVEFRONT);
-                        if ((excbits >> k) & 1u) {
-                            delta[ord] = kLitAddr - rel;  // position rel resolves to the literal marker
-                            lit[ord] = excval[k];
-                            any_lit = true;
-                        } else {
-                            delta[ord] = src[k] - rel;
-                        }
-                    }
-                }
+            for (uint32_t k = 0; k != kSPL; ++k) {
+                const bool lv = live[k] && inb;
+                const uint32_t rel = rel0 + (off4[k] >> 2);
+                uint32_t* const fword = reinterpret_cast<uint32_t*>(fw + ((rel >> 2) & 0x1F8u));
+                __hip_atomic_fetch_or(fword, lv ? 1u << (rel & 31u) : 0u, __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_WAVEFRONT);
+                const uint32_t ord = lv ? ord0 + lord[k] : kTileSlots + k;
+                uint32_t* const dslot = reinterpret_cast<uint32_t*>(delta + 4 * ord);
+                *dslot = src4[k] - 4 * rel;  // literal: kLitAddr4 - 4 * rel
+                if (tile_exc) dslot[kLitOff / 4] = excval[k];
+                any_cold = any_cold || (lv && src4[k] >= kColdBase4 && src4[k] != kLitAddr4);
             }
-            const bool batch_lit = __ballot(any_lit) != 0;
+            const bool batch_cold = __ballot(any_cold) != 0;
+            (void)batch_cold;
             wave_lds_fence();
             {
-                const uint32_t wv = lane < nwords ? flagw[lane] : 0u;
-                const uint32_t pc = uint32_t(__builtin_popcount(wv));
+                uint32_t* const pair = reinterpret_cast<uint32_t*>(fw + 8 * lane);
+                const uint32_t pc = uint32_t(__builtin_popcount(pair[0]));
                 const uint32_t pi = wave_inclusive_sum(pc);
-                wbase[lane] = pi - pc - 1u;
+                pair[1] = pi - pc - 1u;  // flags before this word, minus one
             }
             wave_lds_fence();
 
-            uint32_t* const obatch = out + (produced + done);
-            for (uint32_t q0 = 0; q0 < bt; q0 += 4 * kWave) {
-                const uint32_t p0 = q0 + 4 * lane;
-                if (p0 < bt) {
-                    const uint32_t widx = p0 >> 5, sh = p0 & 31u;
-                    const uint32_t w = flagw[widx];
-                    const uint32_t nib = (w >> sh) & 15u;
-                    const uint32_t base = wbase[widx] + uint32_t(__builtin_popcount(w & ((1u << sh) - 1u)));
-                    uint32_t r[4], d[4];
+            STAMP(3);  // batch build: flags, deltas, rank bases
+            // expansion: each lane takes 4 consecutive outputs of every 256-output group. Pass 1 runs
+            // the LDS chains and issues the cold gathers of ALL groups; then one wait; pass 2 stores.
+            const uint32_t obyte = 4 * (produced + done);  // byte offset of the batch in the segment's output
+            uint32_t x[kGroups][4];
+            static_assert(kCap == kGroups * 4 * kWave, "one round per batch");
+#pragma unroll
+            for (uint32_t g = 0; g != kGroups; ++g) {
+                if (g * 4 * kWave < bt) {  // wave-uniform
+                    const u32x2 pr = *reinterpret_cast<const u32x2*>(fw + g * 64 + pair_byte);
+                    const uint32_t w = pr.x;
+                    const uint32_t base = pr.y + uint32_t(__builtin_popcount(w & below));
+                    const uint32_t nib = w >> sh;
+                    uint32_t r[4];
                     r[0] = base + (nib & 1u);
                     r[1] = base + uint32_t(__builtin_popcount(nib & 3u));
                     r[2] = base + uint32_t(__builtin_popcount(nib & 7u));
-                    r[3] = base + uint32_t(__builtin_popcount(nib));
-#pragma unroll
-                    for (int k = 0; k != 4; ++k) d[k] = delta[r[k]];
-                    uint32_t x[4], ad[4];
+                    r[3] = base + uint32_t(__builtin_popcount(nib & 15u));
+                    const uint32_t pos4 = g * 16 * kWave + 16 * lane;  // byte position of this lane's first output
+                    uint32_t ad[4];
 #pragma unroll
                     for (int k = 0; k != 4; ++k) {
-                        ad[k] = d[k] + p0 + k;
-                        x[k] = lds[ad[k] < kColdBase ? ad[k] : 0u];
+                        ad[k] = *reinterpret_cast<const uint32_t*>(delta + 4 * r[k]) + pos4 + 4 * k;
+                        // cold / literal sources are far out of LDS range: such reads return nothing used
+                        x[g][k] = *reinterpret_cast<const uint32_t*>(lds_bytes + ad[k]);
                     }
-                    asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));  // keep DS reads DS reads
-#ifndef DINT_EXP_NOCOLD
+                    asm volatile("" : "+v"(x[g][0]), "+v"(x[g][1]), "+v"(x[g][2]), "+v"(x[g][3]));
+                    if (tile_exc) {
 #pragma unroll
-                    for (int k = 0; k != 4; ++k) {
-                        if (ad[k] >= kColdBase && ad[k] != kLitAddr) {
-                            uint32_t g = ad[k] - kColdBase;
-                            g = g < a.dict.gtable_words ? g : a.dict.gtable_words - 1;
-                            x[k] = a.dict.gtable[g];
+                        for (int k = 0; k != 4; ++k) {
+                            if (ad[k] == kLitAddr4)
+                                x[g][k] = *reinterpret_cast<const uint32_t*>(delta + 4 * r[k] + kLitOff);
+                        }
+                    }
+#ifndef DINT_EXP_NOCOLD
+                    if (batch_cold) {
+#pragma unroll
+                        for (int k = 0; k != 4; ++k) {
+                            if (ad[k] >= kColdBase4 && ad[k] != kLitAddr4)
+                                x[g][k] = __builtin_amdgcn_raw_buffer_load_b32(rs_table, ad[k] - kColdBase4, 0, 0);
                         }
                     }
 #endif
-                    if (batch_lit) {
+                }
+            }
+            STAMP(4);  // expansion LDS chains, cold gathers issued
+            // the prefetched registers must have landed before the first store is issued
+            asm volatile("" ::"v"(raw3), "v"(nxt.m[0]), "v"(nxt.m[1]), "v"(nxt.m[2]), "v"(nxt.m[3]));
+#ifdef DINT_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            STAMP(5);  // cold gathers + prefetch returned
 #pragma unroll
-                        for (int k = 0; k != 4; ++k) {
-                            if (ad[k] == kLitAddr) x[k] = lit[r[k]];
-                        }
-                    }
+            for (uint32_t g = 0; g != kGroups; ++g) {
+                if (g * 4 * kWave < bt) {
+                    const uint32_t pos4 = g * 16 * kWave + 16 * lane;
 #ifdef DINT_EXP_NOSTORE
-                    if (x[0] == 0xDEADBEEFu && x[1] == 0x12345u) obatch[p0] = x[2] + x[3];
+                    if (x[g][0] == 0xDEADBEEFu && x[g][1] == 0x12345u) out[g] = x[g][2] + x[g][3];
 #else
-                    if (p0 + 4 <= bt) {
-                        u32x4 xv = {x[0], x[1], x[2], x[3]};
-                        reinterpret_cast<u32x4_a4*>(obatch + p0)->v = xv;
+                    if ((g + 1) * 4 * kWave <= bt) {  // wave-uniform: a full group
+                        const u32x4 xv = {x[g][0], x[g][1], x[g][2], x[g][3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(xv, rs_out, pos4, obyte, 0);
                     } else {
-                        obatch[p0] = x[0];
-                        if (p0 + 1 < bt) obatch[p0 + 1] = x[1];
-                        if (p0 + 2 < bt) obatch[p0 + 2] = x[2];
+                        const uint32_t p0 = g * 4 * kWave + 4 * lane;
+                        if (p0 + 4 <= bt) {
+                            const u32x4 xv = {x[g][0], x[g][1], x[g][2], x[g][3]};
+                            __builtin_amdgcn_raw_buffer_store_b128(xv, rs_out, pos4, obyte, 0);
+                        } else if (p0 < bt) {
+                            __builtin_amdgcn_raw_buffer_store_b32(x[g][0], rs_out, pos4, obyte, 0);
+                            if (p0 + 1 < bt) __builtin_amdgcn_raw_buffer_store_b32(x[g][1], rs_out, pos4 + 4, obyte, 0);
+                            if (p0 + 2 < bt) __builtin_amdgcn_raw_buffer_store_b32(x[g][2], rs_out, pos4 + 8, obyte, 0);
+                        }
                     }
 #endif
                 }
@@ -441,21 +567,26 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
         // ---- rotate the pipeline ---------------------------------------------------
         cur = nxt;
         raw1 = raw2;
-        slot_byte += kTileBytes;
-        raw2 = load_lane_slots<W>(a.enc, slot_byte, a.enc_bytes);
+        raw2 = raw3;
+        STAMP(6);  // store issue, rotate
     }
+#ifdef DINT_STAMPS
+    if (lane == 0) {
+        for (int i = 0; i != 8; ++i) atomicAdd(&g_stamps[i], (unsigned long long)tacc[i]);
+    }
+#endif
     return tile_base + uint64_t(kSlotBytes) * end_slot;
 }
 
 // A single-dictionary unit (rectangular or packed: the streams are byte-identical,
 // only the dictionary source layout differed on the host) is one 16-bit segment.
-__device__ __forceinline__ void decode_unit_single(const decode_args& a, const uint32_t* lds, uint32_t* scratch,
-                                                   uint64_t unit_index, uint32_t lane) {
+__device__ __forceinline__ void decode_unit_single(const decode_args& a, const uint32_t* lds, const uint16_t* cls,
+                                                   uint32_t* scratch, uint64_t unit_index, uint32_t lane) {
     const dint_unit* up = a.units + unit_index;
     const uint64_t out_off = up->out_off;
     const uint32_t n = up->n;
     if (n == 0 || out_off + n > a.out_capacity) return;
-    const uint64_t end = decode_segment<16>(a, lds, scratch, a.dict.first, up->in_off, n, a.out + out_off, lane);
+    const uint64_t end = decode_segment<16>(a, lds, cls, scratch, a.dict.first, up->in_off, n, a.out + out_off, lane);
     if (a.end_off && lane == 0) a.end_off[unit_index] = end;
 }
 
@@ -463,8 +594,8 @@ __device__ __forceinline__ void decode_unit_single(const decode_args& a, const u
 // by a selector byte: < 6 -> 16-bit codewords against dictionary `selector`, else 8-bit
 // codewords against dictionary `selector - 6` (vroom_env/dint_codecs.hpp:521-619).
 // Blocks carry no length, so they are decoded one after the other.
-__device__ __forceinline__ void decode_unit_multi(const decode_args& a, const uint32_t* lds, uint32_t* scratch,
-                                                  uint64_t unit_index, uint32_t lane) {
+__device__ __forceinline__ void decode_unit_multi(const decode_args& a, const uint32_t* lds, const uint16_t* cls,
+                                                  uint32_t* scratch, uint64_t unit_index, uint32_t lane) {
     const dint_unit* up = a.units + unit_index;
     const uint64_t out_off = up->out_off;
     const uint32_t n = up->n;
@@ -482,8 +613,8 @@ __device__ __forceinline__ void decode_unit_multi(const decode_args& a, const ui
         dd.hot_k = uniform(a.dict.descs[d].hot_k);
         dd.pad = 0;
         uint32_t* const out = a.out + out_off + done;
-        if (narrow) pos = decode_segment<8>(a, lds, scratch, dd, pos + 1, bsize, out, lane);
-        else pos = decode_segment<16>(a, lds, scratch, dd, pos + 1, bsize, out, lane);
+        if (narrow) pos = decode_segment<8>(a, lds, cls, scratch, dd, pos + 1, bsize, out, lane);
+        else pos = decode_segment<16>(a, lds, cls, scratch, dd, pos + 1, bsize, out, lane);
         done += bsize;
     }
     if (a.end_off && lane == 0) a.end_off[unit_index] = pos;
@@ -500,10 +631,12 @@ template <bool MULTI>
 __device__ __forceinline__ void decode_kernel_body(const decode_args& a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     for (uint32_t i = threadIdx.x; i < a.dict.hot_words; i += kBlockThreads) lds[i] = a.dict.lds_image[i];
+    uint16_t* const cls = reinterpret_cast<uint16_t*>(lds + a.dict.hot_words);
+    build_class_table(cls);
     __syncthreads();
     const uint32_t lane = lane_id();
     const uint32_t wave = uniform(threadIdx.x / kWave);
-    uint32_t* scratch = lds + a.dict.hot_words + wave * kScratchWords;
+    uint32_t* scratch = lds + a.dict.hot_words + kClassWords + wave * kScratchWords;
     const uint32_t shard = blockIdx.x % a.n_shards;  // n_shards = min(kQueueShards, gridDim.x)
     uint32_t* counter = a.queue + shard * kQueueStride;
     const uint64_t shard_units = (a.n_units + a.n_shards - 1 - shard) / a.n_shards;
@@ -516,8 +649,8 @@ __device__ __forceinline__ void decode_kernel_body(const decode_args& a) {
     while (j < shard_units) {
         const uint32_t j_next = draw();
         const uint64_t u = uint64_t(shard) + uint64_t(a.n_shards) * j;
-        if (MULTI) decode_unit_multi(a, lds, scratch, u, lane);
-        else decode_unit_single(a, lds, scratch, u, lane);
+        if (MULTI) decode_unit_multi(a, lds, cls, scratch, u, lane);
+        else decode_unit_single(a, lds, cls, scratch, u, lane);
         j = j_next;
     }
 }

@@ -1,0 +1,17 @@
+#!/bin/bash
+# usage: tools/pmc_quick.sh <tag> [postings] [lib]   -- one SQ pass (instruction counts + waits)
+TAG=${1:-pq}; N=${2:-4e8}; LIB=$3
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+[ -n "$LIB" ] && export DINT_HIP_LIB=$LIB
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $OUT/sq1 -- python3 $R/tools/quick_bench.py $N 8192 > $OUT/sq1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA --output-format csv -d $OUT/sq2 -- python3 $R/tools/quick_bench.py $N 8192 > $OUT/sq2.log 2>&1
+python3 - <<PY
+import csv, glob, collections
+for f in sorted(glob.glob("$OUT/**/*counter_collection.csv", recursive=True)):
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for row in csv.DictReader(open(f)):
+        if "decode" not in row["Kernel_Name"]: continue
+        a = agg[row["Counter_Name"]]; a[0] += float(row["Counter_Value"]); a[1] += 1
+    for k, (v, n) in agg.items(): print(f"{k:28s} per-launch {v / n:.4g}")
+PY
