@@ -58,7 +58,7 @@ constexpr uint32_t kCap = kGroups * 256;              // outputs per expansion b
 constexpr uint32_t kFwWords = 2 * 64 + 4;              // 64 pairs: flag positions are taken mod 2048
 constexpr uint32_t kDeltaWords = kTileSlots + 4;
 constexpr uint32_t kScratchWords = kFwWords + 2 * kDeltaWords;
-constexpr uint32_t kClassTableWords = (3 * 256 + 5 * 256) / 2;  // slot classification table (u16 rows)
+constexpr uint32_t kClassTableWords = 328;            // slot classification table: 648 u16 rows, padded
 constexpr uint32_t kHotImageWords = kLdsWords - kClassTableWords - kWavesPerBlock * kScratchWords;
 constexpr uint32_t kZeroWords = 256;                  // longest run codeword
 constexpr uint32_t kColdBase = 1u << 24;              // source offsets >= this live in global memory
@@ -188,40 +188,42 @@ __device__ __forceinline__ uint32_t lookup_meta(const dict_view& d, const uint32
 
 // Slot classification table. Whether a slot is a codeword header or an exception
 // payload depends on its predecessors; per lane (4 consecutive slots) the outcome is a
-// function of: how many payload slots the previous lane still owes (st_in), which slots
-// are < 2 (L) and which are == 1 (O). One table row per (st_in, O, L):
-//   bits 0-3 payload slots, bits 4-7 exception headers, bits 8-10 st_out.
-// Rows [0, 768) are for 16-bit slots (payloads of 1 / 2 slots), rows [768, 2048) for
+// function of how many payload slots the previous lane still owes (st_in) and of the
+// digits d_k = 2 - min(slot_k, 2) (0: ordinary, 1: value 1, 2: value 0). One u16 row per
+// (st_in, d3 d2 d1 d0 in base 3):
+//   bits 0-3 payload slots | 4-7 exception headers | 8-10 st_out |
+//   bit 11, bits 12-13, bits 14-15: headers before slot 1, 2, 3 (ordinal inside the lane)
+// Rows [0, 243) are for 16-bit slots (payloads of 1 / 2 slots), rows [243, 648) for
 // 8-bit slots (2 / 4 slots).
-constexpr uint32_t kClassRows = 3 * 256 + 5 * 256;
-constexpr uint32_t kClassWords = kClassRows / 2;  // u16 entries
+constexpr uint32_t kRows16 = 3 * 81, kRows8 = 5 * 81;
+constexpr uint32_t kClassRows = kRows16 + kRows8;
 
-__device__ __forceinline__ uint32_t class_row(uint32_t w16, uint32_t st, uint32_t O, uint32_t L) {
-    uint32_t pay = 0, exc = 0;
+__device__ __forceinline__ uint32_t class_row(bool w16, uint32_t st, uint32_t digits) {
+    uint32_t pay = 0, exc = 0, hdr_before = 0, ords = 0;
     for (uint32_t k = 0; k != 4; ++k) {
+        const uint32_t d = digits % 3;
+        digits /= 3;
+        if (k == 1) ords |= hdr_before << 11;
+        if (k == 2) ords |= hdr_before << 12;
+        if (k == 3) ords |= hdr_before << 14;
         const bool p = st != 0;
-        const bool e = !p && ((L >> k) & 1u);
-        const bool one = (O >> k) & 1u;
+        const bool e = !p && d != 0;
         pay |= uint32_t(p) << k;
         exc |= uint32_t(e) << k;
-        st = p ? st - 1 : (e ? (w16 ? (one ? 2u : 1u) : (one ? 4u : 2u)) : 0u);
+        hdr_before += p ? 0u : 1u;
+        st = p ? st - 1 : (e ? (w16 ? (d == 1 ? 2u : 1u) : (d == 1 ? 4u : 2u)) : 0u);
     }
-    return pay | (exc << 4) | (st << 8);
+    return pay | (exc << 4) | (st << 8) | ords;
 }
 
 __device__ __forceinline__ void build_class_table(uint16_t* table) {
     for (uint32_t i = threadIdx.x; i < kClassRows; i += kBlockThreads) {
-        const bool w16 = i < 768;
-        const uint32_t j = w16 ? i : i - 768;
-        table[i] = uint16_t(class_row(w16, j >> 8, (j >> 4) & 15u, j & 15u));
+        const bool w16 = i < kRows16;
+        const uint32_t j = w16 ? i : i - kRows16;
+        table[i] = uint16_t(class_row(w16, j / 81, j % 81));
     }
 }
 
-// One SEGMENT: n integers from W-bit slots starting at byte in_off, all against one
-// dictionary. A single-dictionary unit is one 16-bit segment; a multi-dictionary
-// unit is a sequence of <= 256-integer segments (blocks), each 16- or 8-bit
-// (vroom_env/dint_codecs.hpp:521-619). Exception payloads are 1 / 2 slots (W = 16)
-// or 2 / 4 slots (W = 8). Returns the byte offset one past the last consumed slot.
 #ifdef DINT_STAMPS
 // Diagnostic build only: wave-cycles per phase, summed over all waves (never in the shipped kernel).
 __device__ unsigned long long g_stamps[16];
@@ -249,7 +251,7 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
     uint8_t* const delta = reinterpret_cast<uint8_t*>(scratch + kFwWords);    // 256 entries + 4 dummies
     constexpr uint32_t kLitOff = 4 * kDeltaWords;                             // literal table = delta + kLitOff
     const uint8_t* const lds_bytes = reinterpret_cast<const uint8_t*>(lds);
-    const uint16_t* const rows = cls + (W == 16 ? 0 : 768);
+    const uint16_t* const rows = cls + (W == 16 ? 0 : kRows16);
 
     const uint32_t hot_k = dd.hot_k;
     const __amdgpu_buffer_rsrc_t rs_meta =
@@ -309,28 +311,28 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
 #pragma unroll
         for (uint32_t k = 1; k != kSPL; ++k) smin = smin < cur.s[k] ? smin : cur.s[k];
         const bool special = __ballot(smin < 2) != 0 || carry != 0;
-        uint32_t paybits = 0, excbits = 0;
+        uint32_t paybits = 0, excbits = 0, row = 0;
         uint32_t carry_out = 0;
         uint32_t excval[kSPL];
 #pragma unroll
         for (uint32_t k = 0; k != kSPL; ++k) excval[k] = 0;
         bool tile_exc = false;
         if (special) {
-            uint32_t lo = 0;  // O << 4 | L
+            // base-3 digits of the four slots: 2 - min(slot, 2)
+            uint32_t lo = 0;
 #pragma unroll
-            for (uint32_t k = 0; k != kSPL; ++k) lo |= (cur.s[k] < 2 ? 1u << k : 0u) | (cur.s[k] == 1 ? 16u << k : 0u);
+            for (uint32_t k = kSPL; k-- != 0;) lo = 3 * lo + (2u - (cur.s[k] < 2 ? cur.s[k] : 2u));
             uint32_t st_in = lane == 0 ? carry : 0u;
-            uint32_t row;
             for (;;) {
-                row = rows[st_in * 256 + lo];
-                uint32_t prev = __shfl_up(row >> 8, 1);
+                row = rows[st_in * 81 + lo];
+                uint32_t prev = __shfl_up((row >> 8) & 7u, 1);
                 if (lane == 0) prev = carry;
                 if (__ballot(prev != st_in) == 0) break;
                 st_in = prev;
             }
             paybits = row & 15u;
             excbits = (row >> 4) & 15u;
-            carry_out = readlane(row >> 8, 63);
+            carry_out = readlane((row >> 8) & 7u, 63);
             tile_exc = __ballot(excbits != 0) != 0;
             if (tile_exc) {
                 // slot values after this lane's: the next lane's first ones (lane 63: next tile's)
@@ -364,8 +366,8 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
 
         STAMP(1);  // classification
         // ---- 2. sizes, offsets, ordinals (sizes and sources in BYTES of output / payload) --------
-        uint32_t sz4[kSPL], src4[kSPL];
-        bool live[kSPL];
+        // live[k]: all ones when slot k is a codeword header that belongs to this segment
+        uint32_t sz4[kSPL], src4[kSPL], live[kSPL], lord[kSPL];
 #pragma unroll
         for (uint32_t k = 0; k != kSPL; ++k) {
             const uint32_t m = cur.m[k];
@@ -374,18 +376,22 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
 #ifdef DINT_EXP_NOCOLD
             src4[k] = (m << 2) & 0x3FFFFFCu;
 #endif
-            live[k] = true;
+            live[k] = ~0u;
+            lord[k] = k;
         }
         uint32_t hdrcnt = 4;
         if (special) {
 #pragma unroll
             for (uint32_t k = 0; k != kSPL; ++k) {
-                const bool pay = (paybits >> k) & 1u;
-                const bool exc = (excbits >> k) & 1u;
-                sz4[k] = pay ? 0u : (exc ? 4u : sz4[k]);
-                src4[k] = exc ? kLitAddr4 : src4[k];
-                live[k] = !pay;
+                const uint32_t payM = uint32_t(int32_t(row << (31 - k)) >> 31);  // all ones: payload slot
+                const uint32_t excM = uint32_t(int32_t(row << (27 - k)) >> 31);  // all ones: exception header
+                sz4[k] = ((sz4[k] & ~excM) | (4u & excM)) & ~payM;
+                src4[k] = (src4[k] & ~excM) | (kLitAddr4 & excM);
+                live[k] = ~payM;
             }
+            lord[1] = (row >> 11) & 1u;
+            lord[2] = (row >> 12) & 3u;
+            lord[3] = (row >> 14) & 3u;
             hdrcnt = 4 - uint32_t(__builtin_popcount(paybits));
         }
         uint32_t off4[kSPL];
@@ -400,34 +406,28 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
         const uint32_t rbase = pexcl >> 24;        // ordinal of this lane's first codeword
         const uint32_t remaining = n - produced;
         uint32_t total = readlane(pincl, 63) & 0xFFFFFFu;
+        uint32_t nlive = hdrcnt;
         if (total >= remaining) {  // last tile of the segment: clamp, and find where the stream ends
             total = remaining;
             uint32_t cand = 0;
+            nlive = 0;
 #pragma unroll
             for (uint32_t k = 0; k != kSPL; ++k) {
                 const uint32_t pos = obase + (off4[k] >> 2);
-                const bool act = live[k] && pos < remaining;
+                const bool act = live[k] != 0 && pos < remaining;
                 if (act) {
                     const uint32_t room4 = 4 * (remaining - pos);
                     sz4[k] = sz4[k] < room4 ? sz4[k] : room4;
                     const bool exc = (excbits >> k) & 1u;
                     cand = kSPL * lane + k + 1 + (exc ? (W == 16 ? cur.s[k] + 1 : 2 * cur.s[k] + 2) : 0u);
+                    ++nlive;
                 }
-                live[k] = act;
+                live[k] = act ? ~0u : 0u;
             }
             lsum = obase < remaining ? (obase + lsum < remaining ? lsum : remaining - obase) : 0u;
             const uint64_t am = __ballot(cand != 0);
             end_slot = readlane(cand, 63u - uint32_t(__builtin_clzll(am | 1ull)));
         }
-        // ordinal of codeword k inside the lane (headers before it)
-        uint32_t lord[kSPL];
-        lord[0] = 0;
-#pragma unroll
-        for (uint32_t k = 1; k != kSPL; ++k) lord[k] = lord[k - 1] + (special ? ((~paybits >> (k - 1)) & 1u) : 1u);
-        uint32_t nlive = 0;
-#pragma unroll
-        for (uint32_t k = 0; k != kSPL; ++k) nlive += live[k] ? 1u : 0u;
-
         STAMP(2);  // sizes, scan
         // ---- prefetch: metadata of tile t+1 (its slots are already here), slots of tile t+2. Issued
         // before this tile's cold gathers and stores; waited for together with the gathers, right
@@ -453,22 +453,25 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
             wave_lds_fence();
             // Every slot runs the same instructions: a codeword that is not live in this batch ORs
             // a zero into an in-range flag word and parks its delta in a dummy entry.
-            bool any_cold = false;
+            uint32_t any_cold = 0;
             const uint32_t rel0 = obase - done, ord0 = rbase - rdone;
+            const uint32_t inbM = inb ? ~0u : 0u;
 #pragma unroll
             for (uint32_t k = 0; k != kSPL; ++k) {
-                const bool lv = live[k] && inb;
+                const uint32_t lv = live[k] & inbM;
                 const uint32_t rel = rel0 + (off4[k] >> 2);
                 uint32_t* const fword = reinterpret_cast<uint32_t*>(fw + ((rel >> 2) & 0x1F8u));
-                __hip_atomic_fetch_or(fword, lv ? 1u << (rel & 31u) : 0u, __ATOMIC_RELAXED,
+                __hip_atomic_fetch_or(fword, lv & (1u << (rel & 31u)), __ATOMIC_RELAXED,
                                       __HIP_MEMORY_SCOPE_WAVEFRONT);
-                const uint32_t ord = lv ? ord0 + lord[k] : kTileSlots + k;
+                const uint32_t ord = (lv & (ord0 + lord[k])) | (~lv & (kTileSlots + k));
                 uint32_t* const dslot = reinterpret_cast<uint32_t*>(delta + 4 * ord);
                 *dslot = src4[k] - 4 * rel;  // literal: kLitAddr4 - 4 * rel
                 if (tile_exc) dslot[kLitOff / 4] = excval[k];
-                any_cold = any_cold || (lv && src4[k] >= kColdBase4 && src4[k] != kLitAddr4);
+                // bit 31 set iff the source is cold (>= kColdBase4) and not the literal marker (>= 2^31)
+                any_cold |= lv & (src4[k] + (0x80000000u - kColdBase4)) & ~src4[k];
             }
-            const bool batch_cold = __ballot(any_cold) != 0;
+            const bool any_cold_lane = int32_t(any_cold) < 0;
+            const bool batch_cold = __ballot(any_cold_lane) != 0;
             (void)batch_cold;
             wave_lds_fence();
             {
@@ -636,7 +639,7 @@ __device__ __forceinline__ void decode_kernel_body(const decode_args& a) {
     __syncthreads();
     const uint32_t lane = lane_id();
     const uint32_t wave = uniform(threadIdx.x / kWave);
-    uint32_t* scratch = lds + a.dict.hot_words + kClassWords + wave * kScratchWords;
+    uint32_t* scratch = lds + a.dict.hot_words + kClassTableWords + wave * kScratchWords;
     const uint32_t shard = blockIdx.x % a.n_shards;  // n_shards = min(kQueueShards, gridDim.x)
     uint32_t* counter = a.queue + shard * kQueueStride;
     const uint64_t shard_units = (a.n_units + a.n_shards - 1 - shard) / a.n_shards;
