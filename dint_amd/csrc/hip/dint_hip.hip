@@ -470,8 +470,9 @@ int dint_index_stream(const dint_dict* dd, const uint8_t* enc, size_t enc_bytes,
     return DINT_OK;
 }
 
-int dint_decode_units(const dint_dict* dd, const uint8_t* d_enc, size_t enc_bytes, const dint_unit* d_units,
-                      size_t n_units, uint32_t* d_out, size_t out_capacity, uint64_t* d_end_off, void* stream) {
+static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_bytes, const dint_unit* d_units,
+                         size_t n_units, uint32_t* d_out, size_t out_capacity, uint64_t* d_end_off, void* stream,
+                         uint32_t only_full) {
     if (!dd) return DINT_ERR_ARG;
     if (n_units == 0) return DINT_OK;
     if (!d_enc || !d_units || !d_out || enc_bytes < 8) return DINT_ERR_ARG;  // slots are fetched 8 bytes at a time
@@ -485,6 +486,7 @@ int dint_decode_units(const dint_dict* dd, const uint8_t* d_enc, size_t enc_byte
     a.out = d_out;
     a.out_capacity = out_capacity;
     a.end_off = d_end_off;
+    a.only_full = only_full;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint64_t blocks_needed = (uint64_t(n_units) + kWavesPerBlock - 1) / kWavesPerBlock;
     const uint32_t grid = uint32_t(std::min<uint64_t>(blocks_needed, std::max<uint32_t>(1, dd->compute_units) * kBlocksPerCU));
@@ -507,6 +509,112 @@ int dint_decode_units(const dint_dict* dd, const uint8_t* d_enc, size_t enc_byte
     mut->slot_used[slot] = true;
     mut->timed = true;
     return DINT_OK;
+}
+
+int dint_decode_units(const dint_dict* dd, const uint8_t* d_enc, size_t enc_bytes, const dint_unit* d_units,
+                      size_t n_units, uint32_t* d_out, size_t out_capacity, uint64_t* d_end_off, void* stream) {
+    return launch_decode(dd, d_enc, enc_bytes, d_units, n_units, d_out, out_capacity, d_end_off, stream, 0);
+}
+
+int dint_index_posting_lists(const uint8_t* index, size_t index_bytes, const uint64_t* list_offsets,
+                             size_t n_lists, dint_block_ref** blocks_out, size_t* n_blocks,
+                             uint64_t* total_postings) {
+    if ((!index && index_bytes) || (!list_offsets && n_lists) || !blocks_out || !n_blocks) return DINT_ERR_ARG;
+    std::vector<dint_block_ref> blocks;
+    uint64_t out_pos = 0;
+    for (size_t i = 0; i != n_lists; ++i) {
+        if (list_offsets[i] >= index_bytes) return DINT_ERR_FORMAT;
+        const uint8_t* p = index + list_offsets[i];
+        const uint8_t* end = index + index_bytes;
+        uint32_t n;
+        const uint8_t* base = read_vbyte(p, end, &n);  // document_enumerator ctor, dict_posting_list.hpp:90-107
+        if (!base || n == 0) return DINT_ERR_FORMAT;
+        const uint64_t nb = (uint64_t(n) + kBlock - 1) / kBlock;
+        const uint8_t* maxs = base;
+        const uint8_t* endpoints = maxs + 4 * nb;
+        const uint8_t* data = endpoints + 4 * (nb - 1);
+        if (data > end) return DINT_ERR_FORMAT;
+        uint32_t prev_max = uint32_t(-1);
+        for (uint64_t b = 0; b != nb; ++b) {
+            uint32_t endpoint = 0, mx;
+            if (b) std::memcpy(&endpoint, endpoints + 4 * (b - 1), 4);
+            std::memcpy(&mx, maxs + 4 * b, 4);
+            dint_block_ref r;
+            r.in_off = uint64_t(data - index) + endpoint;
+            r.out_off = out_pos;
+            r.n = (b + 1) * kBlock <= n ? kBlock : n % kBlock;
+            r.base = prev_max + 1;
+            r.max = mx;
+            r.list = uint32_t(i);
+            if (r.in_off > index_bytes) return DINT_ERR_FORMAT;
+            blocks.push_back(r);
+            out_pos += r.n;
+            prev_max = mx;
+        }
+    }
+    auto mem = static_cast<dint_block_ref*>(std::malloc(std::max<size_t>(1, blocks.size()) * sizeof(dint_block_ref)));
+    if (!mem) return DINT_ERR_NOMEM;
+    if (!blocks.empty()) std::memcpy(mem, blocks.data(), blocks.size() * sizeof(dint_block_ref));
+    *blocks_out = mem;
+    *n_blocks = blocks.size();
+    if (total_postings) *total_postings = out_pos;
+    return DINT_OK;
+}
+
+int dint_decode_posting_blocks(const dint_dict* docs_dict, const dint_dict* freqs_dict, const uint8_t* d_index,
+                               size_t index_bytes, const dint_block_ref* d_blocks, size_t n_blocks,
+                               uint32_t* d_docids, uint32_t* d_freqs, size_t out_capacity, void* stream) {
+    if (!docs_dict || (d_freqs && !freqs_dict)) return DINT_ERR_ARG;
+    if (n_blocks == 0) return DINT_OK;
+    if (!d_index || !d_blocks || !d_docids || index_bytes < 8) return DINT_ERR_ARG;
+    if (freqs_dict && (freqs_dict->device != docs_dict->device || freqs_dict->kind != docs_dict->kind))
+        return DINT_ERR_ARG;
+    HIP_TRY(hipSetDevice(docs_dict->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    dint_unit* d_units = nullptr;
+    uint64_t* d_ends = nullptr;
+    int st = DINT_OK;
+    auto cleanup = [&] {
+        (void)hipStreamSynchronize(s);
+        if (d_units) (void)hipFree(d_units);
+        if (d_ends) (void)hipFree(d_ends);
+    };
+#define TRY_OR_CLEAN(call)            \
+    do {                              \
+        if (!hip_ok((call), #call)) { \
+            cleanup();                \
+            return DINT_ERR_HIP;      \
+        }                             \
+    } while (0)
+    TRY_OR_CLEAN(hipMalloc(&d_units, n_blocks * sizeof(dint_unit)));
+    TRY_OR_CLEAN(hipMalloc(&d_ends, n_blocks * sizeof(uint64_t)));
+    const uint32_t tb = 256;
+    const uint32_t grid = uint32_t((n_blocks + tb - 1) / tb);
+    // docs parts: full blocks through the DINT kernel, short ones through the interpolative decoder
+    hipLaunchKernelGGL(blocks_to_units_kernel, dim3(grid), dim3(tb), 0, s, d_blocks, nullptr, uint64_t(n_blocks), d_units);
+    st = launch_decode(docs_dict, d_index, index_bytes, d_units, n_blocks, d_docids, out_capacity, d_ends, s, 1);
+    if (st == DINT_OK) {
+        hipLaunchKernelGGL(interpolative_tails_kernel, dim3(grid), dim3(tb), 0, s, d_index, uint64_t(index_bytes),
+                           d_blocks, nullptr, uint64_t(n_blocks), d_docids, uint64_t(out_capacity), d_ends);
+        if (d_freqs) {  // freqs parts start where the docs parts ended
+            hipLaunchKernelGGL(blocks_to_units_kernel, dim3(grid), dim3(tb), 0, s, d_blocks, d_ends,
+                               uint64_t(n_blocks), d_units);
+            st = launch_decode(freqs_dict, d_index, index_bytes, d_units, n_blocks, d_freqs, out_capacity, nullptr, s, 1);
+            if (st == DINT_OK)
+                hipLaunchKernelGGL(interpolative_tails_kernel, dim3(grid), dim3(tb), 0, s, d_index,
+                                   uint64_t(index_bytes), d_blocks, d_ends, uint64_t(n_blocks), d_freqs,
+                                   uint64_t(out_capacity), nullptr);
+        }
+    }
+    if (st == DINT_OK) {
+        const uint32_t wgrid = uint32_t((n_blocks * kWave + tb - 1) / tb);
+        hipLaunchKernelGGL(finalize_postings_kernel, dim3(wgrid), dim3(tb), 0, s, d_blocks, uint64_t(n_blocks),
+                           d_docids, d_freqs, uint64_t(out_capacity));
+        if (!hip_ok(hipGetLastError(), "in-index kernels")) st = DINT_ERR_HIP;
+    }
+#undef TRY_OR_CLEAN
+    cleanup();
+    return st;
 }
 
 int dint_last_kernel_ms(const dint_dict* dd, float* ms) {

@@ -98,6 +98,7 @@ struct decode_args {
     uint64_t* end_off;  // nullable
     uint32_t* queue;    // kQueueShards counters, kQueueStride words apart, zero at launch
     uint32_t n_shards;  // counters in use
+    uint32_t only_full; // in-index path: decode units of exactly 256 integers only (tails are interpolative)
 };
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -588,7 +589,7 @@ __device__ __forceinline__ void decode_unit_single(const decode_args& a, const u
     const dint_unit* up = a.units + unit_index;
     const uint64_t out_off = up->out_off;
     const uint32_t n = up->n;
-    if (n == 0 || out_off + n > a.out_capacity) return;
+    if (n == 0 || out_off + n > a.out_capacity || (a.only_full && n != 256)) return;
     const uint64_t end = decode_segment<16>(a, lds, cls, scratch, a.dict.first, up->in_off, n, a.out + out_off, lane);
     if (a.end_off && lane == 0) a.end_off[unit_index] = end;
 }
@@ -602,7 +603,7 @@ __device__ __forceinline__ void decode_unit_multi(const decode_args& a, const ui
     const dint_unit* up = a.units + unit_index;
     const uint64_t out_off = up->out_off;
     const uint32_t n = up->n;
-    if (n == 0 || out_off + n > a.out_capacity) return;
+    if (n == 0 || out_off + n > a.out_capacity || (a.only_full && n != 256)) return;
     uint64_t pos = up->in_off;
     for (uint32_t done = 0; done < n;) {
         const uint32_t bsize = n - done < 256u ? n - done : 256u;
@@ -658,8 +659,140 @@ __device__ __forceinline__ void decode_kernel_body(const decode_args& a) {
     }
 }
 
-__global__ __launch_bounds__(kBlockThreads) void decode_single_kernel(decode_args a) { decode_kernel_body<false>(a); }
-__global__ __launch_bounds__(kBlockThreads) void decode_multi_kernel(decode_args a) { decode_kernel_body<true>(a); }
+#ifndef DINT_MIN_WAVES
+#define DINT_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(kBlockThreads, DINT_MIN_WAVES) void decode_single_kernel(decode_args a) {
+    decode_kernel_body<false>(a);
+}
+__global__ __launch_bounds__(kBlockThreads, DINT_MIN_WAVES) void decode_multi_kernel(decode_args a) {
+    decode_kernel_body<true>(a);
+}
+
+// ---- in-index path: helper kernels -------------------------------------------------------------
+
+// unit table for the docs parts (in_off from the block table) or for the freqs parts (in_off =
+// where the docs part ended)
+__global__ void blocks_to_units_kernel(const dint_block_ref* blocks, const uint64_t* docs_end, uint64_t n_blocks,
+                                       dint_unit* units) {
+    const uint64_t b = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    dint_unit u;
+    u.in_off = docs_end ? docs_end[b] : blocks[b].in_off;
+    u.out_off = blocks[b].out_off;
+    u.n = blocks[b].n;
+    u.list = blocks[b].list;
+    units[b] = u;
+}
+
+// Binary interpolative decode of the blocks shorter than 256 (include/ds2i/interpolative_coding.hpp:
+// 79-146, include/ds2i/block_codecs.hpp:130-150), one block per thread: the code is bit-serial and
+// recursive (here: an explicit stack, node - left subtree - right subtree order), and there is at
+// most one such block per posting list. docs parts have sum_of_values = max - base - (n - 1),
+// freqs parts carry their sum as a leading vbyte.
+struct tail_bits {
+    const uint8_t* p;
+    uint64_t limit;  // bytes readable from p
+    uint64_t byte;   // next byte to fetch
+    uint64_t buf;
+    uint32_t avail;
+    uint64_t pos;    // bits consumed
+    __device__ uint32_t read(uint32_t len) {
+        if (!len) return 0;
+        if (avail < len) {
+            uint32_t w = 0;
+            for (uint32_t i = 0; i != 4; ++i)
+                if (byte + i < limit) w |= uint32_t(p[byte + i]) << (8 * i);
+            byte += 4;
+            buf |= uint64_t(w) << avail;
+            avail += 32;
+        }
+        const uint32_t v = uint32_t(buf & ((uint64_t(1) << len) - 1));
+        buf >>= len;
+        avail -= len;
+        pos += len;
+        return v;
+    }
+    __device__ uint32_t read_int(uint32_t u) {
+        const uint32_t b = 31u - uint32_t(__builtin_clz(u));
+        const uint64_t m = (uint64_t(1) << (b + 1)) - u;
+        uint32_t v = read(b);
+        if (v >= m) v = (v << 1) + read(1) - uint32_t(m);
+        return v;
+    }
+};
+
+__global__ void interpolative_tails_kernel(const uint8_t* index, uint64_t index_bytes, const dint_block_ref* blocks,
+                                           const uint64_t* docs_end, uint64_t n_blocks, uint32_t* out,
+                                           uint64_t out_capacity, uint64_t* end_off) {
+    const uint64_t b = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    const uint32_t n = blocks[b].n;
+    if (n == 0 || n >= 256 || blocks[b].out_off + n > out_capacity) return;
+    uint64_t pos = docs_end ? docs_end[b] : blocks[b].in_off;
+    uint32_t sum;
+    if (docs_end) {  // freqs: sum_of_values = -1 -> TightVariableByte sum first
+        sum = 0;
+        for (uint32_t shift = 0; pos < index_bytes; shift += 7) {
+            const uint8_t c = index[pos++];
+            sum += uint32_t(c & 127) << (shift & 31);
+            if (c & 128) break;
+        }
+    } else {
+        sum = blocks[b].max - blocks[b].base - (n - 1);
+    }
+    uint32_t* o = out + blocks[b].out_off;
+    o[n - 1] = sum;
+    uint64_t used = 0;
+    if (n > 1) {
+        tail_bits br{index + pos, index_bytes - pos, 0, 0, 0, 0};
+        struct frame {
+            uint32_t off, n, low, high;
+        } stack[20];
+        int top = 0;
+        stack[top++] = {0, n - 1, 0, sum};
+        while (top) {
+            const frame f = stack[--top];
+            const uint32_t h = f.n / 2;
+            const uint32_t val = f.low + br.read_int(f.high - f.low + 1);
+            o[f.off + h] = val;
+            if (f.n - h - 1) stack[top++] = {f.off + h + 1, f.n - h - 1, val, f.high};
+            if (h) stack[top++] = {f.off, h, f.low, val};
+        }
+        for (uint32_t i = n - 1; i > 0; --i) o[i] -= o[i - 1];
+        used = (br.pos + 7) / 8;
+    }
+    if (end_off) end_off[b] = pos + used;
+}
+
+// gaps -> docIDs (docid_i = base + sum_{j<=i} gap_j + i, dict_posting_list.hpp:111-124) and
+// freq - 1 -> freq; one wave per block, 4 consecutive postings per lane.
+__global__ void finalize_postings_kernel(const dint_block_ref* blocks, uint64_t n_blocks, uint32_t* docids,
+                                         uint32_t* freqs, uint64_t out_capacity) {
+    const uint32_t lane = lane_id();
+    const uint64_t b = (uint64_t(blockIdx.x) * blockDim.x + threadIdx.x) / kWave;
+    if (b >= n_blocks) return;
+    const uint32_t n = blocks[b].n;
+    const uint64_t at = blocks[b].out_off;
+    if (n == 0 || n > 256 || at + n > out_capacity) return;
+    uint32_t g[4], local = 0;
+#pragma unroll
+    for (uint32_t k = 0; k != 4; ++k) {
+        const uint32_t i = 4 * lane + k;
+        g[k] = i < n ? docids[at + i] + 1 : 0;
+        local += g[k];
+    }
+    uint32_t run = blocks[b].base + wave_inclusive_sum(local) - local - 1;
+#pragma unroll
+    for (uint32_t k = 0; k != 4; ++k) {
+        const uint32_t i = 4 * lane + k;
+        run += g[k];
+        if (i < n) {
+            docids[at + i] = run;
+            if (freqs) freqs[at + i] += 1;
+        }
+    }
+}
 
 // test hook: out[i] = inclusive prefix sum of in[0..i] over one wave
 __global__ void debug_wave_scan_kernel(const uint32_t* in, uint32_t* out) {

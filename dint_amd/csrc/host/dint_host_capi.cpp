@@ -8,6 +8,7 @@
 
 #include "dint/dictionaries.hpp"
 #include "dint/encoders.hpp"
+#include "dint/posting_list.hpp"
 #include "dint/statistics.hpp"
 #include "dint/synthetic.hpp"
 #include "dint/vroom_stream.hpp"
@@ -111,6 +112,42 @@ int encode_with(void const* dict_file, size_t dict_len, uint32_t const* gaps, ui
 
 }  // namespace
 
+namespace {
+template <typename Coder, typename Builder>
+int build_index(const void* docs_dict, size_t docs_len, const void* freqs_dict, size_t freqs_len,
+                const uint32_t* docids, const uint32_t* freqs, const uint32_t* lens, uint64_t n_lists, int threads,
+                dinth_blob** index, dinth_blob** offsets) {
+    Builder docs_builder, freqs_builder;
+    docs_builder.load(static_cast<uint8_t const*>(docs_dict), docs_len);
+    freqs_builder.load(static_cast<uint8_t const*>(freqs_dict), freqs_len);
+    docs_builder.prepare_for_encoding();
+    freqs_builder.prepare_for_encoding();
+    std::vector<uint64_t> starts(n_lists + 1, 0);
+    for (uint64_t i = 0; i != n_lists; ++i) starts[i + 1] = starts[i] + lens[i];
+    std::vector<std::vector<uint8_t>> encoded(n_lists);
+    const uint64_t group = 16;
+    dint::parallel_for((n_lists + group - 1) / group, threads, [&](size_t g) {
+        uint64_t end = std::min<uint64_t>(n_lists, (g + 1) * group);
+        for (uint64_t i = g * group; i != end; ++i) {
+            if (lens[i] == 0) continue;
+            dint::write_posting_list<Coder>(docs_builder, freqs_builder, encoded[i], lens[i], docids + starts[i],
+                                            freqs + starts[i]);
+        }
+    });
+    auto idx = new dinth_blob;
+    std::vector<uint64_t> offs(n_lists + 1, 0);
+    for (uint64_t i = 0; i != n_lists; ++i) {
+        offs[i] = idx->bytes.size();
+        idx->bytes.insert(idx->bytes.end(), encoded[i].begin(), encoded[i].end());
+        std::vector<uint8_t>().swap(encoded[i]);
+    }
+    offs[n_lists] = idx->bytes.size();
+    *index = idx;
+    *offsets = blob_of(offs);
+    return DINT_OK;
+}
+}  // namespace
+
 extern "C" {
 
 const void* dinth_blob_data(const dinth_blob* b) { return b ? b->bytes.data() : nullptr; }
@@ -202,6 +239,32 @@ int dinth_encode_vroom(int kind, int greedy, const void* dict_file, size_t dict_
             case DINT_DICT_MULTI_PACKED:
                 return encode_with<multi_opt_dint, multi_packed_builder>(dict_file, dict_len, gaps, lens, n_lists,
                                                                          unit_ints, threads, enc, units);
+            default:
+                return int(DINT_ERR_ARG);
+        }
+    });
+}
+
+int dinth_build_index(int kind, const void* docs_dict_file, size_t docs_dict_len, const void* freqs_dict_file,
+                      size_t freqs_dict_len, const uint32_t* docids, const uint32_t* freqs, const uint32_t* lens,
+                      uint64_t n_lists, int threads, dinth_blob** index, dinth_blob** offsets) {
+    if (!docs_dict_file || !freqs_dict_file || !index || !offsets || (n_lists && (!docids || !freqs || !lens)))
+        return DINT_ERR_ARG;
+    return guarded([&] {
+        using namespace dint;
+        switch (kind) {
+            case DINT_DICT_RECTANGULAR:
+                return build_index<opt_dint_single_dict_block, rectangular_builder>(
+                    docs_dict_file, docs_dict_len, freqs_dict_file, freqs_dict_len, docids, freqs, lens, n_lists,
+                    threads, index, offsets);
+            case DINT_DICT_SINGLE_PACKED:
+                return build_index<opt_dint_single_dict_block, single_packed_builder>(
+                    docs_dict_file, docs_dict_len, freqs_dict_file, freqs_dict_len, docids, freqs, lens, n_lists,
+                    threads, index, offsets);
+            case DINT_DICT_MULTI_PACKED:
+                return build_index<opt_dint_multi_dict_block, multi_packed_builder>(
+                    docs_dict_file, docs_dict_len, freqs_dict_file, freqs_dict_len, docids, freqs, lens, n_lists,
+                    threads, index, offsets);
             default:
                 return int(DINT_ERR_ARG);
         }

@@ -22,7 +22,13 @@ ABI_SYMBOLS = (
     "dint_abi_version", "dint_strerror", "dint_last_hip_error", "dint_device_count",
     "dint_dict_create", "dint_dict_destroy", "dint_dict_info_get", "dint_index_stream", "dint_free",
     "dint_decode_units", "dint_decode_list_host", "dint_last_kernel_ms",
+    "dint_index_posting_lists", "dint_decode_posting_blocks",
 )
+
+#: dint_block_ref (include/dint_hip.h)
+BLOCK_DTYPE = np.dtype([("in_off", "<u8"), ("out_off", "<u8"), ("n", "<u4"), ("base", "<u4"), ("max", "<u4"),
+                        ("list", "<u4")], align=False)
+assert BLOCK_DTYPE.itemsize == 32
 
 
 class DictInfo(C.Structure):
@@ -57,6 +63,8 @@ def _load():
     lib.dint_decode_units.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, vp]
     lib.dint_decode_list_host.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
     lib.dint_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.dint_index_posting_lists.argtypes = [vp, sz, vp, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(u64)]
+    lib.dint_decode_posting_blocks.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, sz, vp]
     lib.dint_debug_wave_scan.argtypes = [vp, vp]
     return lib
 
@@ -158,6 +166,46 @@ class Dictionary:
         _check(_lib.dint_decode_list_host(self._h, enc.ctypes.data + offset, enc.size - offset, out.ctypes.data, n,
                                           C.byref(consumed)), "dint_decode_list_host")
         return out, consumed.value
+
+
+def index_posting_lists(index: np.ndarray, list_offsets: np.ndarray):
+    """Host: flatten the block directories of the posting lists starting at list_offsets[:-1]
+    (dict_posting_list layout) -> (block table BLOCK_DTYPE[], total postings)."""
+    index = np.ascontiguousarray(index, dtype=np.uint8)
+    offs = np.ascontiguousarray(list_offsets, dtype=np.uint64)
+    n_lists = max(0, len(offs) - 1)
+    blocks, n_blocks, total = C.c_void_p(), C.c_size_t(), C.c_uint64()
+    _check(_lib.dint_index_posting_lists(index.ctypes.data, index.size, offs.ctypes.data, n_lists, C.byref(blocks),
+                                         C.byref(n_blocks), C.byref(total)), "dint_index_posting_lists")
+    try:
+        arr = np.empty(n_blocks.value, dtype=BLOCK_DTYPE)
+        if n_blocks.value:
+            C.memmove(arr.ctypes.data, blocks, arr.nbytes)
+    finally:
+        _lib.dint_free(blocks)
+    return arr, total.value
+
+
+def decode_posting_lists(docs_dict: "Dictionary", freqs_dict, index: np.ndarray, blocks: np.ndarray, total: int):
+    """Upload an index + block table, decode every posting on the device, download.
+    -> (docids u32[], freqs u32[] or None)"""
+    import torch
+
+    dev = torch.device("cuda", docs_dict.device)
+    padded = np.concatenate([np.ascontiguousarray(index, dtype=np.uint8), np.zeros(16, dtype=np.uint8)])
+    index_dev = torch.from_numpy(padded).to(dev)
+    blocks_dev = torch.from_numpy(np.ascontiguousarray(blocks).view(np.uint8).copy()).to(dev)
+    docids_dev = torch.empty(max(1, total), dtype=torch.int32, device=dev)
+    freqs_dev = torch.empty(max(1, total), dtype=torch.int32, device=dev) if freqs_dict is not None else None
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _check(_lib.dint_decode_posting_blocks(
+        docs_dict._h, freqs_dict._h if freqs_dict is not None else None, index_dev.data_ptr(), padded.size,
+        blocks_dev.data_ptr(), len(blocks), docids_dev.data_ptr(),
+        freqs_dev.data_ptr() if freqs_dev is not None else None, total, stream), "dint_decode_posting_blocks")
+    torch.cuda.synchronize(dev)
+    docids = docids_dev.cpu().numpy().view(np.uint32)[:total]
+    freqs = freqs_dev.cpu().numpy().view(np.uint32)[:total] if freqs_dev is not None else None
+    return docids, freqs
 
 
 def units_to_device(units: np.ndarray, device):

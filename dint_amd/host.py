@@ -67,6 +67,8 @@ def _load():
     lib.dinth_build_dictionary.argtypes = [i32, vp, vp, u64, u64, i32, C.POINTER(vp)]
     lib.dinth_encode_vroom.argtypes = [i32, i32, vp, C.c_size_t, vp, vp, u64, u32, i32,
                                        C.POINTER(vp), C.POINTER(vp)]
+    lib.dinth_build_index.argtypes = [i32, vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp, u64, i32,
+                                      C.POINTER(vp), C.POINTER(vp)]
     lib.dinth_hash_u32s.restype = u64
     lib.dinth_hash_u32s.argtypes = [vp, C.c_size_t]
     lib.dinth_dict_entry.argtypes = [i32, vp, C.c_size_t, u32, u32, C.POINTER(u32), vp]
@@ -183,6 +185,38 @@ def encode_vroom(kind: int, dict_file: bytes, coll: Collection, unit_ints: int =
                                    gaps.ctypes.data, lens.ctypes.data, len(lens), unit_ints,
                                    threads or default_threads(), C.byref(enc), C.byref(units)))
     return _take_blob(enc, np.uint8), _take_blob(units, UNIT_DTYPE)
+
+
+def gaps_to_docids(coll: Collection) -> np.ndarray:
+    """Invert docids_to_gaps per list: docid[i] = sum(gap[0..i]) + i."""
+    g = coll.gaps.astype(np.uint64)
+    csum = np.cumsum(g + 1) - 1
+    bounds = coll.list_bounds()
+    starts = bounds[:-1][coll.lens > 0].astype(np.int64)
+    base = np.zeros_like(csum)
+    prev = np.r_[0, csum[starts[1:] - 1] + 1] if len(starts) else np.zeros(0, dtype=np.uint64)
+    base[starts] = prev
+    base = np.maximum.accumulate(base)
+    return (csum - base).astype(np.uint32)
+
+
+def synth_freqs(n: int, seed: int = 1) -> np.ndarray:
+    """Term frequencies >= 1, mostly 1-3 with a geometric tail (synthetic)."""
+    r = np.random.default_rng(seed)
+    return r.geometric(0.55, n).astype(np.uint32)
+
+
+def build_index(kind: int, docs_dict: bytes, freqs_dict: bytes, docids: np.ndarray, freqs: np.ndarray,
+                lens: np.ndarray, threads: int | None = None):
+    """In-index layout (dict_posting_list per list). -> (index bytes u8[], list offsets u64[n_lists + 1])"""
+    idx, offs = C.c_void_p(), C.c_void_p()
+    d, f, l = _u32(docids), _u32(freqs), _u32(lens)
+    db = (C.c_char * len(docs_dict)).from_buffer_copy(docs_dict)
+    fb = (C.c_char * len(freqs_dict)).from_buffer_copy(freqs_dict)
+    _check(_lib.dinth_build_index(kind, C.addressof(db), len(docs_dict), C.addressof(fb), len(freqs_dict),
+                                  d.ctypes.data, f.ctypes.data, l.ctypes.data, len(l),
+                                  threads or default_threads(), C.byref(idx), C.byref(offs)))
+    return _take_blob(idx, np.uint8), _take_blob(offs, np.uint64)
 
 
 def hash_u32s(words) -> int:

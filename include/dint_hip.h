@@ -116,6 +116,43 @@ int dint_decode_units(const dint_dict* dict, const uint8_t* d_enc, size_t enc_by
 int dint_decode_list_host(const dint_dict* dict, const uint8_t* in, size_t in_bytes,
                           uint32_t* out, size_t n, size_t* consumed);
 
+/* ---- in-index path: posting lists in the dict_posting_list layout --------------------------- */
+
+/* One 256-posting block (the last block of a list may be shorter) of a posting list laid out as
+ * reference include/dint/dict_posting_list.hpp:10-56:
+ *   vbyte(n) | u32 block_max[B] | u32 block_endpoint[B-1] | { docs part, freqs part } x B
+ * The block-max / endpoint arrays already make every block independently addressable, so no
+ * sidecar is needed here: this table is just those arrays flattened over many lists. */
+typedef struct dint_block_ref {
+    uint64_t in_off;  /* byte offset of the block's docs part in the index buffer            */
+    uint64_t out_off; /* index of the block's first posting in the output arrays             */
+    uint32_t n;       /* postings in the block, 1..256                                        */
+    uint32_t base;    /* docID base: previous block's max + 1 (0 for a list's first block)    */
+    uint32_t max;     /* largest docID of the block                                           */
+    uint32_t list;    /* ordinal of the list                                                  */
+} dint_block_ref;
+
+/* Host: flatten the block directories of n_lists posting lists (list i starts at byte
+ * list_offsets[i] of `index`) into a block table. Replaces the pointer set-up of
+ * document_enumerator's constructor (dict_posting_list.hpp:90-107). Release with dint_free. */
+int dint_index_posting_lists(const uint8_t* index, size_t index_bytes, const uint64_t* list_offsets,
+                             size_t n_lists, dint_block_ref** blocks, size_t* n_blocks,
+                             uint64_t* total_postings);
+
+/* Device: decode every block of the table to docIDs (and, if d_freqs is not NULL, term
+ * frequencies): full blocks through the DINT kernels, blocks shorter than 256 through the
+ * binary-interpolative decoder, then gap -> docID prefix sums. d_index / d_blocks / outputs are
+ * device pointers on the dictionaries' device; both dictionaries must be of the same kind and
+ * live on the same device. The call enqueues on `stream` and returns after synchronising it
+ * (it owns a temporary workspace).
+ * Replaces: document_enumerator::decode_docs_block / decode_freqs_block + the docid
+ * accumulation of next() (dict_posting_list.hpp:111-124, 284-318), i.e. dint_block::decode /
+ * opt_dint_multi_dict_block::decode (include/dint/dint_codecs.hpp:13-49, 460-510) and
+ * interpolative_block::decode (include/ds2i/block_codecs.hpp:130-150), for many blocks per launch. */
+int dint_decode_posting_blocks(const dint_dict* docs_dict, const dint_dict* freqs_dict, const uint8_t* d_index,
+                               size_t index_bytes, const dint_block_ref* d_blocks, size_t n_blocks,
+                               uint32_t* d_docids, uint32_t* d_freqs, size_t out_capacity, void* stream);
+
 /* Sum of per-kernel device time (ms) between the two events the library
  * records around the decode kernel of the most recent dint_decode_units on
  * this dictionary; valid after the stream has been synchronised. */

@@ -63,6 +63,17 @@ int dinth_encode_vroom(int kind, int greedy, const void* dict_file, size_t dict_
                        const uint32_t* gaps, const uint32_t* lens, uint64_t n_lists,
                        uint32_t unit_ints, int threads, dinth_blob** enc, dinth_blob** units);
 
+/* Build an inverted index in the reference's in-index layout: every list is a
+ * dict_posting_list (reference include/dint/dict_posting_list.hpp:10-56: vbyte n, block maxima,
+ * block endpoints, per 256-posting block a docs part and a freqs part; blocks shorter than 256 are
+ * binary-interpolative coded). docids: strictly increasing per list, freqs >= 1, both flat arrays
+ * with lens[i] values per list. *index receives the lists back to back, *offsets a u64[n_lists + 1]
+ * table of their byte offsets (this repo's own container; the reference freezes the same bytes with
+ * succinct::mapper, which is absent here). */
+int dinth_build_index(int kind, const void* docs_dict_file, size_t docs_dict_len, const void* freqs_dict_file,
+                      size_t freqs_dict_len, const uint32_t* docids, const uint32_t* freqs, const uint32_t* lens,
+                      uint64_t n_lists, int threads, dinth_blob** index, dinth_blob** offsets);
+
 /* MurmurHash64A(seed 0) of n u32 words (reference include/dint/hash_utils.hpp:7-80). */
 uint64_t dinth_hash_u32s(const uint32_t* p, size_t n);
 

@@ -333,3 +333,105 @@ double oracle_time_stream(const oracle_dict* d, const uint8_t* enc, size_t enc_b
     if (lists_decoded) *lists_decoded = lists;
     return elapsed;
 }
+
+/* ---- in-index path --------------------------------------------------------------------- */
+
+/* bit_reader, include/ds2i/interpolative_coding.hpp:79-153 */
+typedef struct {
+    const uint8_t* in; /* next u32 to fetch (unaligned) */
+    uint32_t avail;
+    uint64_t buf;
+    size_t pos;
+} bit_reader;
+
+static uint32_t br_read(bit_reader* r, uint32_t len) { /* :93-108 */
+    if (!len) return 0;
+    if (r->avail < len) {
+        r->buf |= (uint64_t)ld32(r->in) << r->avail;
+        r->in += 4;
+        r->avail += 32;
+    }
+    uint32_t val = (uint32_t)(r->buf & (((uint64_t)1 << len) - 1));
+    r->buf >>= len;
+    r->avail -= len;
+    r->pos += len;
+    return val;
+}
+
+static uint32_t br_read_int(bit_reader* r, uint32_t u) { /* :110-122 */
+    uint32_t b = 31u - (uint32_t)__builtin_clz(u); /* succinct::broadword::msb */
+    uint64_t m = ((uint64_t)1 << (b + 1)) - u;
+    uint32_t val = br_read(r, b);
+    if (val >= m) val = (val << 1) + br_read(r, 1) - (uint32_t)m;
+    return val;
+}
+
+static void br_read_interpolative(bit_reader* r, uint32_t* out, size_t n, uint32_t low, uint32_t high) { /* :124-146 */
+    size_t h = n / 2;
+    uint32_t val = low + br_read_int(r, high - low + 1);
+    out[h] = val;
+    if (n == 1) return;
+    if (h) br_read_interpolative(r, out, h, low, val);
+    if (n - h - 1) br_read_interpolative(r, out + h + 1, n - h - 1, val, high);
+}
+
+/* interpolative_block::decode, include/ds2i/block_codecs.hpp:130-150 */
+const uint8_t* oracle_interpolative_decode(const uint8_t* in, uint32_t* out, uint32_t sum_of_values, size_t n) {
+    const uint8_t* inbuf = in;
+    if (sum_of_values == (uint32_t)-1) inbuf = oracle_vbyte_read(inbuf, &sum_of_values);
+    out[n - 1] = sum_of_values;
+    size_t read_bytes = 0;
+    if (n > 1) {
+        bit_reader r = {inbuf, 0, 0, 0};
+        br_read_interpolative(&r, out, n - 1, 0, sum_of_values);
+        for (size_t i = n - 1; i > 0; --i) out[i] -= out[i - 1];
+        read_bytes = (r.pos + 7) / 8;
+    }
+    return inbuf + read_bytes;
+}
+
+/* dint_block::decode (:13-49) and opt_dint_multi_dict_block::decode (:460-510): a full block is
+ * exactly one whole-list decode of 256 integers (single: 16-bit codewords; multi: selector byte
+ * + one block), a shorter one is interpolative. */
+const uint8_t* oracle_block_decode(const oracle_dict* d, const uint8_t* in, uint32_t* out, uint32_t sum_of_values,
+                                   size_t n) {
+    if (__builtin_expect(n < BLOCK, 0)) return oracle_interpolative_decode(in, out, sum_of_values, n);
+    return oracle_decode_list(d, in, out, n);
+}
+
+uint32_t oracle_posting_list_decode(const oracle_dict* docs_dict, const oracle_dict* freqs_dict,
+                                    const uint8_t* list, uint32_t* docids, uint32_t* freqs) {
+    uint32_t n;
+    const uint8_t* base = oracle_vbyte_read(list, &n); /* document_enumerator ctor, :90-107 */
+    if (!docids && !freqs) return n;
+    uint32_t blocks = (n + BLOCK - 1) / BLOCK;
+    const uint8_t* block_maxs = base;
+    const uint8_t* block_endpoints = block_maxs + 4 * (size_t)blocks;
+    const uint8_t* blocks_data = block_endpoints + 4 * (size_t)(blocks - 1);
+    uint32_t docs_buf[BLOCK + 256], freqs_buf[BLOCK + 256];
+    size_t pos = 0;
+    for (uint32_t b = 0; b != blocks; ++b) {
+        /* decode_docs_block, :284-309 */
+        uint32_t endpoint = b ? ld32(block_endpoints + 4 * (size_t)(b - 1)) : 0;
+        const uint8_t* block_data = blocks_data + endpoint;
+        uint32_t cur_size = ((b + 1) * BLOCK <= n) ? BLOCK : (n % BLOCK);
+        uint32_t cur_base = (b ? ld32(block_maxs + 4 * (size_t)(b - 1)) : (uint32_t)-1) + 1;
+        uint32_t cur_max = ld32(block_maxs + 4 * (size_t)b);
+        memset(docs_buf, 0, sizeof docs_buf); /* std::fill, :296 */
+        const uint8_t* freqs_data =
+            oracle_block_decode(docs_dict, block_data, docs_buf, cur_max - cur_base - (cur_size - 1), cur_size);
+        docs_buf[0] += cur_base;
+        /* decode_freqs_block, :311-318 */
+        memset(freqs_buf, 0, sizeof freqs_buf);
+        oracle_block_decode(freqs_dict, freqs_data, freqs_buf, (uint32_t)-1, cur_size);
+        /* next(): m_cur_docid += m_docs_buf[pos] + 1 (:111-124); freq(): buf + 1 (:164-169) */
+        uint32_t docid = docs_buf[0];
+        for (uint32_t i = 0; i != cur_size; ++i) {
+            if (i) docid += docs_buf[i] + 1;
+            if (docids) docids[pos] = docid;
+            if (freqs) freqs[pos] = freqs_buf[i] + 1;
+            ++pos;
+        }
+    }
+    return n;
+}

@@ -70,6 +70,25 @@ uint64_t oracle_decode_stream(const oracle_dict* d, const uint8_t* enc, size_t e
 double oracle_time_stream(const oracle_dict* d, const uint8_t* enc, size_t enc_bytes, uint64_t max_lists,
                           double max_seconds, uint64_t* ints_decoded, uint64_t* lists_decoded);
 
+/* ---- in-index path ------------------------------------------------------------------- */
+
+/* interpolative_block::decode (include/ds2i/block_codecs.hpp:130-150): n <= 256 values whose
+ * prefix sums were binary-interpolative coded; sum_of_values == 0xFFFFFFFF means the sum is
+ * vbyte-coded first. Returns the advanced input pointer. */
+const uint8_t* oracle_interpolative_decode(const uint8_t* in, uint32_t* out, uint32_t sum_of_values, size_t n);
+
+/* dint_block::decode / opt_dint_multi_dict_block::decode (include/dint/dint_codecs.hpp:13-49,
+ * 460-510): one posting-list block; n < 256 -> interpolative. `out` zeroed, n + 256 words. */
+const uint8_t* oracle_block_decode(const oracle_dict* d, const uint8_t* in, uint32_t* out, uint32_t sum_of_values,
+                                   size_t n);
+
+/* dict_posting_list::document_enumerator walked from the first to the last posting
+ * (include/dint/dict_posting_list.hpp:88-342): decode_docs_block / decode_freqs_block for every
+ * block, docid accumulation as next() does. docids/freqs must hold n values (n = first vbyte of
+ * the list; call with NULL outputs to get it). Returns n. */
+uint32_t oracle_posting_list_decode(const oracle_dict* docs_dict, const oracle_dict* freqs_dict,
+                                    const uint8_t* list, uint32_t* docids, uint32_t* freqs);
+
 #ifdef __cplusplus
 }
 #endif

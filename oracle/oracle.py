@@ -40,6 +40,10 @@ def _load():
     lib.oracle_header_read.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.oracle_decode_stream.restype = C.c_uint64
     lib.oracle_decode_stream.argtypes = [vp, vp, C.c_size_t, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.oracle_interpolative_decode.restype = vp
+    lib.oracle_interpolative_decode.argtypes = [vp, vp, C.c_uint32, C.c_size_t]
+    lib.oracle_posting_list_decode.restype = C.c_uint32
+    lib.oracle_posting_list_decode.argtypes = [vp, vp, vp, vp, vp]
     lib.oracle_time_stream.restype = C.c_double
     lib.oracle_time_stream.argtypes = [vp, vp, C.c_size_t, C.c_uint64, C.c_double,
                                        C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -107,3 +111,24 @@ def header_read(enc: np.ndarray, offset: int):
     base = enc.ctypes.data
     end = _lib.oracle_header_read(base + offset, C.byref(n), C.byref(u))
     return n.value, u.value, int(end - base)
+
+
+def interpolative_decode(buf: np.ndarray, offset: int, sum_of_values: int, n: int):
+    """interpolative_block::decode -> (values, bytes consumed)."""
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    padded = np.concatenate([buf, np.zeros(8, dtype=np.uint8)])  # the bit reader fetches whole u32 words
+    out = np.zeros(n + 1, dtype=np.uint32)
+    base = padded.ctypes.data + offset
+    end = _lib.oracle_interpolative_decode(base, out.ctypes.data, sum_of_values & 0xFFFFFFFF, n)
+    return out[:n].copy(), int(end - base)
+
+
+def posting_list_decode(docs_dict: OracleDict, freqs_dict: OracleDict, index: np.ndarray, offset: int):
+    """document_enumerator walked front to back -> (docids, freqs)."""
+    index = np.ascontiguousarray(index, dtype=np.uint8)
+    padded = np.concatenate([index, np.zeros(16, dtype=np.uint8)])
+    base = padded.ctypes.data + offset
+    n = _lib.oracle_posting_list_decode(docs_dict._h, freqs_dict._h, base, None, None)
+    docids, freqs = np.empty(n, dtype=np.uint32), np.empty(n, dtype=np.uint32)
+    _lib.oracle_posting_list_decode(docs_dict._h, freqs_dict._h, base, docids.ctypes.data, freqs.ctypes.data)
+    return docids, freqs

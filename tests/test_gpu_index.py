@@ -1,0 +1,64 @@
+"""In-index path on the GPU: posting lists (dict_posting_list layout) -> docIDs and freqs,
+bit-exact against the oracle's document_enumerator walk and the index builder's input."""
+import numpy as np
+import pytest
+
+import oracle
+from dint_amd import host
+from test_index_cpu import get_index
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def device():
+    import torch
+
+    assert torch.cuda.is_available()
+    from dint_amd import device as dev
+
+    return dev
+
+
+@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.RECTANGULAR, host.MULTI_PACKED])
+@pytest.mark.parametrize("corpus_name", ["small_corpus", "dense_corpus", "sparse_corpus"])
+def test_posting_lists_match_oracle(device, request, kind, corpus_name):
+    corpus = request.getfixturevalue(corpus_name)
+    ix = get_index(corpus, kind)
+    blocks, total = device.index_posting_lists(ix.bytes, ix.offsets)
+    assert total == corpus.coll.num_postings
+    assert int(blocks["n"].sum()) == total and (blocks["n"] <= 256).all()
+    dd = device.Dictionary(kind, ix.docs_dict)
+    fd = device.Dictionary(kind, ix.freqs_dict)
+    docids, freqs = device.decode_posting_lists(dd, fd, ix.bytes, blocks, total)
+    assert np.array_equal(docids, ix.docids)
+    assert np.array_equal(freqs, ix.freqs)
+    # and the oracle's walk of a sample of lists agrees with both
+    od, of = oracle.OracleDict(kind, ix.docs_dict), oracle.OracleDict(kind, ix.freqs_dict)
+    for i in range(0, len(ix.lens), max(1, len(ix.lens) // 50)):
+        if ix.lens[i] == 0:
+            continue
+        d, f = oracle.posting_list_decode(od, of, ix.bytes, int(ix.offsets[i]))
+        lo, hi = int(ix.bounds[i]), int(ix.bounds[i + 1])
+        assert np.array_equal(docids[lo:hi], d) and np.array_equal(freqs[lo:hi], f)
+
+
+def test_docs_only(device, small_corpus):
+    ix = get_index(small_corpus, host.SINGLE_PACKED)
+    blocks, total = device.index_posting_lists(ix.bytes, ix.offsets)
+    dd = device.Dictionary(host.SINGLE_PACKED, ix.docs_dict)
+    docids, freqs = device.decode_posting_lists(dd, None, ix.bytes, blocks, total)
+    assert freqs is None and np.array_equal(docids, ix.docids)
+
+
+def test_block_table_matches_the_list_directories(device, small_corpus):
+    ix = get_index(small_corpus, host.SINGLE_PACKED)
+    blocks, _ = device.index_posting_lists(ix.bytes, ix.offsets)
+    first = np.r_[True, blocks["list"][1:] != blocks["list"][:-1]]
+    assert (blocks["base"][first] == 0).all()
+    # every block's max is the last docID of that block
+    ends = (blocks["out_off"] + blocks["n"] - 1).astype(np.int64)
+    assert np.array_equal(blocks["max"], ix.docids[ends])
+    # bases chain: base = previous max + 1 inside a list
+    same = ~first
+    assert np.array_equal(blocks["base"][same], blocks["max"][np.flatnonzero(same) - 1] + 1)
