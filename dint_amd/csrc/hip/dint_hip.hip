@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "dint_kernels.hpp"
+#include "dint_query_kernels.hpp"
 
 namespace {
 
@@ -270,6 +271,49 @@ const uint8_t* read_vbyte(const uint8_t* in, const uint8_t* end, uint32_t* val) 
 }
 
 }  // namespace
+
+namespace {
+template <class T>
+struct device_buffer {  // grow-only workspace
+    T* p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t need) {
+        if (need <= cap) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = std::max<size_t>(need + need / 2, 1024);
+        if (!hip_ok(hipMalloc(&p, want * sizeof(T)), "hipMalloc(workspace)")) return false;
+        cap = want;
+        return true;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+}  // namespace
+
+struct dint_query_index {
+    const dint_dict* docs = nullptr;
+    const uint8_t* d_index = nullptr;
+    size_t index_bytes = 0;
+    size_t n_blocks = 0;
+    std::vector<uint32_t> list_first;  // n_lists + 1
+    std::vector<uint32_t> list_len;    // postings per list
+    dint_block_ref* d_blocks = nullptr;
+    uint32_t* d_block_max = nullptr;
+    uint32_t* d_needed = nullptr;   // n_blocks, zero between rounds
+    uint32_t* d_rank = nullptr;     // n_blocks
+    uint32_t* d_touched = nullptr;  // n_blocks
+    uint32_t* d_n_touched = nullptr;
+    device_buffer<uint32_t> page_block, page_query, term_first, term_blocks, cand, target, probe;
+    device_buffer<dint_block_ref> sub;
+    device_buffer<dint_unit> units;
+    device_buffer<unsigned long long> counts;
+    std::mutex mutex;
+};
 
 extern "C" {
 
@@ -615,6 +659,195 @@ int dint_decode_posting_blocks(const dint_dict* docs_dict, const dint_dict* freq
 #undef TRY_OR_CLEAN
     cleanup();
     return st;
+}
+
+// ---- conjunctive queries ------------------------------------------------------------------------
+
+void dint_query_index_destroy(dint_query_index* qi) {
+    if (!qi) return;
+    if (qi->docs) (void)hipSetDevice(qi->docs->device);
+    for (void* p : {static_cast<void*>(qi->d_blocks), static_cast<void*>(qi->d_block_max),
+                    static_cast<void*>(qi->d_needed), static_cast<void*>(qi->d_rank),
+                    static_cast<void*>(qi->d_touched), static_cast<void*>(qi->d_n_touched)})
+        if (p) (void)hipFree(p);
+    qi->page_block.release();
+    qi->page_query.release();
+    qi->term_first.release();
+    qi->term_blocks.release();
+    qi->cand.release();
+    qi->target.release();
+    qi->probe.release();
+    qi->sub.release();
+    qi->units.release();
+    qi->counts.release();
+    delete qi;
+}
+
+int dint_query_index_create(const dint_dict* docs_dict, const uint8_t* d_index, size_t index_bytes,
+                            const dint_block_ref* blocks, size_t n_blocks, size_t n_lists, dint_query_index** out) {
+    if (!docs_dict || !out || (!blocks && n_blocks) || (!d_index && n_blocks)) return DINT_ERR_ARG;
+    if (n_blocks >= 0xFFFFFFFFull || n_lists >= 0xFFFFFFFFull || (n_blocks && index_bytes < 8)) return DINT_ERR_ARG;
+    *out = nullptr;
+    auto* qi = new (std::nothrow) dint_query_index();
+    if (!qi) return DINT_ERR_NOMEM;
+    qi->docs = docs_dict;
+    qi->d_index = d_index;
+    qi->index_bytes = index_bytes;
+    qi->n_blocks = n_blocks;
+    qi->list_first.assign(n_lists + 1, 0);
+    qi->list_len.assign(n_lists, 0);
+    std::vector<uint32_t> maxs(n_blocks);
+    uint32_t prev_list = 0;
+    for (size_t b = 0; b != n_blocks; ++b) {
+        const uint32_t l = blocks[b].list;
+        if (l >= n_lists || l < prev_list || blocks[b].n == 0 || blocks[b].n > 256 ||
+            blocks[b].in_off > index_bytes) {  // lists in order, each list's blocks contiguous
+            delete qi;
+            return DINT_ERR_FORMAT;
+        }
+        prev_list = l;
+        qi->list_first[l + 1] += 1;
+        qi->list_len[l] += blocks[b].n;
+        maxs[b] = blocks[b].max;
+    }
+    for (size_t l = 0; l != n_lists; ++l) qi->list_first[l + 1] += qi->list_first[l];
+    const size_t nb = std::max<size_t>(1, n_blocks);
+    bool ok = hip_ok(hipSetDevice(docs_dict->device), "hipSetDevice") &&
+              hip_ok(hipMalloc(&qi->d_blocks, nb * sizeof(dint_block_ref)), "hipMalloc(blocks)") &&
+              hip_ok(hipMalloc(&qi->d_block_max, nb * 4), "hipMalloc(block_max)") &&
+              hip_ok(hipMalloc(&qi->d_needed, nb * 4), "hipMalloc(needed)") &&
+              hip_ok(hipMalloc(&qi->d_rank, nb * 4), "hipMalloc(rank)") &&
+              hip_ok(hipMalloc(&qi->d_touched, nb * 4), "hipMalloc(touched)") &&
+              hip_ok(hipMalloc(&qi->d_n_touched, 4), "hipMalloc(n_touched)") &&
+              hip_ok(hipMemset(qi->d_needed, 0, nb * 4), "hipMemset(needed)");
+    if (ok && n_blocks)
+        ok = hip_ok(hipMemcpy(qi->d_blocks, blocks, n_blocks * sizeof(dint_block_ref), hipMemcpyHostToDevice), "hipMemcpy(blocks)") &&
+             hip_ok(hipMemcpy(qi->d_block_max, maxs.data(), n_blocks * 4, hipMemcpyHostToDevice), "hipMemcpy(block_max)");
+    if (!ok) {
+        dint_query_index_destroy(qi);
+        return DINT_ERR_HIP;
+    }
+    *out = qi;
+    return DINT_OK;
+}
+
+// docs parts of the pages of `sub` -> docIDs, 256 slots per page (no freqs, no sync)
+static int decode_doc_pages(dint_query_index* qi, size_t n_pages, uint32_t* d_out, hipStream_t s) {
+    if (!qi->units.ensure(n_pages)) return DINT_ERR_HIP;
+    const uint32_t tb = 256;
+    const uint32_t grid = uint32_t((n_pages + tb - 1) / tb);
+    const uint64_t cap = uint64_t(n_pages) * kPageSlots;
+    hipLaunchKernelGGL(blocks_to_units_kernel, dim3(grid), dim3(tb), 0, s, qi->sub.p, nullptr, uint64_t(n_pages), qi->units.p);
+    const int st = launch_decode(qi->docs, qi->d_index, qi->index_bytes, qi->units.p, n_pages, d_out, cap, nullptr, s, 1);
+    if (st != DINT_OK) return st;
+    hipLaunchKernelGGL(interpolative_tails_kernel, dim3(grid), dim3(tb), 0, s, qi->d_index, uint64_t(qi->index_bytes),
+                       qi->sub.p, nullptr, uint64_t(n_pages), d_out, cap, nullptr);
+    const uint32_t wgrid = uint32_t((n_pages * kWave + tb - 1) / tb);
+    hipLaunchKernelGGL(finalize_postings_kernel, dim3(wgrid), dim3(tb), 0, s, qi->sub.p, uint64_t(n_pages), d_out,
+                       nullptr, cap);
+    HIP_TRY(hipGetLastError());
+    return DINT_OK;
+}
+
+int dint_and_queries(dint_query_index* qi, const uint32_t* terms, const uint64_t* query_offsets, size_t n_queries,
+                     uint64_t* counts, void* stream) {
+    if (!qi || (n_queries && (!query_offsets || !counts))) return DINT_ERR_ARG;
+    if (n_queries == 0) return DINT_OK;
+    if (n_queries >= 0xFFFFFFFFull) return DINT_ERR_ARG;
+    const size_t n_lists = qi->list_len.size();
+    // per query: distinct terms, rarest list first (queries.hpp:28-31, 49-52)
+    std::vector<std::vector<uint32_t>> plan(n_queries);
+    size_t rounds = 0;
+    std::vector<uint32_t> h_page_block, h_page_query;
+    for (size_t q = 0; q != n_queries; ++q) {
+        if (query_offsets[q + 1] < query_offsets[q] || (query_offsets[q + 1] > query_offsets[q] && !terms)) return DINT_ERR_ARG;
+        std::vector<uint32_t>& t = plan[q];
+        t.assign(terms + query_offsets[q], terms + query_offsets[q + 1]);
+        for (uint32_t term : t)
+            if (term >= n_lists) return DINT_ERR_ARG;
+        std::sort(t.begin(), t.end());
+        t.erase(std::unique(t.begin(), t.end()), t.end());
+        std::stable_sort(t.begin(), t.end(), [&](uint32_t a, uint32_t b) { return qi->list_len[a] < qi->list_len[b]; });
+        counts[q] = 0;
+        if (t.empty()) continue;
+        rounds = std::max(rounds, t.size() - 1);
+        for (uint32_t b = qi->list_first[t[0]]; b != qi->list_first[t[0] + 1]; ++b) {
+            h_page_block.push_back(b);
+            h_page_query.push_back(uint32_t(q));
+        }
+    }
+    const size_t n_pages = h_page_block.size();
+    if (n_pages == 0) return DINT_OK;
+    const uint64_t n_slots = uint64_t(n_pages) * kPageSlots;
+    std::vector<uint32_t> h_first(std::max<size_t>(1, rounds * n_queries), 0), h_blocks(std::max<size_t>(1, rounds * n_queries), 0);
+    for (size_t q = 0; q != n_queries; ++q)
+        for (size_t j = 1; j < plan[q].size(); ++j) {
+            const uint32_t l = plan[q][j];
+            h_first[(j - 1) * n_queries + q] = qi->list_first[l];
+            h_blocks[(j - 1) * n_queries + q] = qi->list_first[l + 1] - qi->list_first[l];
+        }
+
+    std::lock_guard<std::mutex> lock(qi->mutex);
+    HIP_TRY(hipSetDevice(qi->docs->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!qi->page_block.ensure(n_pages) || !qi->page_query.ensure(n_pages) || !qi->sub.ensure(n_pages) ||
+        !qi->cand.ensure(n_slots) || !qi->target.ensure(n_slots) || !qi->term_first.ensure(h_first.size()) ||
+        !qi->term_blocks.ensure(h_blocks.size()) || !qi->counts.ensure(n_queries))
+        return DINT_ERR_HIP;
+    HIP_TRY(hipMemcpyAsync(qi->page_block.p, h_page_block.data(), n_pages * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(qi->page_query.p, h_page_query.data(), n_pages * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(qi->term_first.p, h_first.data(), h_first.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(qi->term_blocks.p, h_blocks.data(), h_blocks.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(qi->counts.p, 0, n_queries * sizeof(unsigned long long), s));
+
+    const uint32_t tb = 256;
+    const uint32_t page_grid = uint32_t((n_pages + tb - 1) / tb);
+    const uint32_t slot_grid = uint32_t(n_pages);  // 256 slots per page = one workgroup
+    // candidates: the rarest list of every query
+    hipLaunchKernelGGL(gather_pages_kernel, dim3(page_grid), dim3(tb), 0, s, qi->d_blocks, qi->page_block.p,
+                       uint64_t(n_pages), qi->sub.p);
+    int st = decode_doc_pages(qi, n_pages, qi->cand.p, s);
+    if (st != DINT_OK) {
+        (void)hipStreamSynchronize(s);
+        return st;
+    }
+    hipLaunchKernelGGL(retire_page_tails_kernel, dim3(slot_grid), dim3(tb), 0, s, qi->sub.p, uint64_t(n_pages), qi->cand.p);
+
+    for (size_t r = 0; r != rounds; ++r) {
+        const uint32_t* first = qi->term_first.p + r * n_queries;
+        const uint32_t* nblk = qi->term_blocks.p + r * n_queries;
+        HIP_TRY(hipMemsetAsync(qi->d_n_touched, 0, 4, s));
+        hipLaunchKernelGGL(and_search_kernel, dim3(slot_grid), dim3(tb), 0, s, qi->cand.p, n_slots, qi->page_query.p,
+                           first, nblk, qi->d_block_max, qi->target.p, qi->d_needed, qi->d_rank, qi->d_touched,
+                           qi->d_n_touched);
+        uint32_t n_touched = 0;
+        HIP_TRY(hipMemcpyAsync(&n_touched, qi->d_n_touched, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (n_touched == 0) continue;  // nothing left to probe in this round
+        if (!qi->sub.ensure(std::max<size_t>(n_pages, n_touched)) || !qi->probe.ensure(uint64_t(n_touched) * kPageSlots)) {
+            (void)hipStreamSynchronize(s);
+            return DINT_ERR_HIP;
+        }
+        const uint32_t tgrid = (n_touched + tb - 1) / tb;
+        hipLaunchKernelGGL(gather_pages_kernel, dim3(tgrid), dim3(tb), 0, s, qi->d_blocks, qi->d_touched,
+                           uint64_t(n_touched), qi->sub.p);
+        st = decode_doc_pages(qi, n_touched, qi->probe.p, s);
+        if (st != DINT_OK) {
+            (void)hipStreamSynchronize(s);
+            return st;
+        }
+        hipLaunchKernelGGL(and_probe_kernel, dim3(slot_grid), dim3(tb), 0, s, qi->cand.p, n_slots, qi->page_query.p,
+                           nblk, qi->d_blocks, qi->target.p, qi->d_rank, qi->probe.p);
+        hipLaunchKernelGGL(and_release_kernel, dim3(tgrid), dim3(tb), 0, s, qi->d_touched, n_touched, qi->d_needed);
+    }
+    hipLaunchKernelGGL(and_count_kernel, dim3(slot_grid), dim3(tb), 0, s, qi->cand.p, n_slots, qi->page_query.p,
+                       qi->counts.p);
+    HIP_TRY(hipGetLastError());
+    std::vector<unsigned long long> h_counts(n_queries);
+    HIP_TRY(hipMemcpyAsync(h_counts.data(), qi->counts.p, n_queries * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (size_t q = 0; q != n_queries; ++q) counts[q] = h_counts[q];
+    return DINT_OK;
 }
 
 int dint_last_kernel_ms(const dint_dict* dd, float* ms) {

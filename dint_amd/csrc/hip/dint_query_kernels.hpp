@@ -1,0 +1,119 @@
+// Conjunctive (AND) queries over the in-index layout, batched: the set-at-a-time form of
+// and_query<false> (reference include/ds2i/queries.hpp:34-84) and of the document_enumerator's
+// next_geq (include/dint/dict_posting_list.hpp:126-147).
+//
+// The reference walks one candidate at a time through per-list cursors. On the device the same
+// result is computed a whole batch of queries at a time:
+//   1. the shortest list of every query is decoded into candidate pages (256 slots per block);
+//   2. for each further term, every live candidate binary-searches that list's block maxima
+//      (the block-max skipping of next_geq), the touched blocks are collected without duplicates,
+//      only those blocks are decoded, and every candidate probes its block;
+//   3. the survivors are counted per query.
+// A block no live candidate falls into is never read, like in the reference.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "dint_hip.h"
+
+namespace dint_dev {
+
+constexpr uint32_t kDeadCandidate = 0xFFFFFFFFu;  // not a docID: docIDs are < num_docs <= 2^32 - 1
+constexpr uint32_t kPageSlots = 256;              // one block per page
+
+// sub[i] = blocks[ids[i]] relocated to page i
+__global__ void gather_pages_kernel(const dint_block_ref* blocks, const uint32_t* ids, uint64_t n_pages,
+                                    dint_block_ref* sub) {
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n_pages) return;
+    dint_block_ref r = blocks[ids[i]];
+    r.out_off = i * kPageSlots;
+    sub[i] = r;
+}
+
+// the slots past a short block's end hold no candidate
+__global__ void retire_page_tails_kernel(const dint_block_ref* sub, uint64_t n_pages, uint32_t* cand) {
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n_pages * kPageSlots) return;
+    if (uint32_t(i % kPageSlots) >= sub[i / kPageSlots].n) cand[i] = kDeadCandidate;
+}
+
+// first index in [0, n) with a[i] >= key (n if none)
+__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* a, uint32_t n, uint32_t key) {
+    uint32_t lo = 0, len = n;
+    while (len) {
+        const uint32_t half = len >> 1;
+        const bool right = a[lo + half] < key;
+        lo = right ? lo + half + 1 : lo;
+        len = right ? len - half - 1 : half;
+    }
+    return lo;
+}
+
+// Round step A: block-max search. term_first/term_blocks give, per query, the block range of
+// this round's list (term_blocks == 0: the query has no such term and its candidates pass).
+// Touched blocks are appended once to `touched`, and rank[block] is their position there.
+__global__ void and_search_kernel(uint32_t* cand, uint64_t n_slots, const uint32_t* page_query,
+                                  const uint32_t* term_first, const uint32_t* term_blocks,
+                                  const uint32_t* block_max, uint32_t* target, uint32_t* needed, uint32_t* rank,
+                                  uint32_t* touched, uint32_t* n_touched) {
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    uint32_t gb = kDeadCandidate;
+    if (i < n_slots) {
+        const uint32_t c = cand[i];
+        if (c != kDeadCandidate) {
+            const uint32_t q = page_query[i / kPageSlots];
+            const uint32_t nb = term_blocks[q];
+            if (nb) {
+                const uint32_t fb = term_first[q];
+                const uint32_t pos = lower_bound_u32(block_max + fb, nb, c);
+                if (pos == nb) {
+                    cand[i] = kDeadCandidate;  // next_geq past the last block: m_universe, :128-131
+                } else {
+                    gb = fb + pos;
+                    target[i] = gb;
+                }
+            }
+        }
+    }
+    // neighbouring candidates are sorted, so they mostly fall into the same block: one claim per run
+    const uint32_t prev = __shfl_up(gb, 1);
+    const bool lead = gb != kDeadCandidate && ((threadIdx.x & 63u) == 0 || prev != gb);
+    if (lead && atomicExch(&needed[gb], 1u) == 0u) {
+        const uint32_t k = atomicAdd(n_touched, 1u);
+        touched[k] = gb;
+        rank[gb] = k;
+    }
+}
+
+// Round step B: each live candidate looks itself up in its (now decoded) block.
+__global__ void and_probe_kernel(uint32_t* cand, uint64_t n_slots, const uint32_t* page_query,
+                                 const uint32_t* term_blocks, const dint_block_ref* blocks, const uint32_t* target,
+                                 const uint32_t* rank, const uint32_t* probe) {
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n_slots) return;
+    const uint32_t c = cand[i];
+    if (c == kDeadCandidate || term_blocks[page_query[i / kPageSlots]] == 0) return;
+    const uint32_t gb = target[i];
+    const uint32_t n = blocks[gb].n;
+    const uint32_t* page = probe + uint64_t(rank[gb]) * kPageSlots;
+    const uint32_t pos = lower_bound_u32(page, n, c);
+    if (pos == n || page[pos] != c) cand[i] = kDeadCandidate;
+}
+
+__global__ void and_release_kernel(const uint32_t* touched, uint32_t n_touched, uint32_t* needed) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_touched) needed[touched[k]] = 0;
+}
+
+// results += 1 per surviving candidate (queries.hpp:72-76); a page belongs to one query
+__global__ void and_count_kernel(const uint32_t* cand, uint64_t n_slots, const uint32_t* page_query,
+                                 unsigned long long* counts) {
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const bool alive = i < n_slots && cand[i] != kDeadCandidate;
+    const uint64_t votes = __ballot(alive);
+    if ((threadIdx.x & 63u) == 0 && votes) atomicAdd(&counts[page_query[i / kPageSlots]], (unsigned long long)__popcll(votes));
+}
+
+}  // namespace dint_dev

@@ -23,6 +23,7 @@ ABI_SYMBOLS = (
     "dint_dict_create", "dint_dict_destroy", "dint_dict_info_get", "dint_index_stream", "dint_free",
     "dint_decode_units", "dint_decode_list_host", "dint_last_kernel_ms",
     "dint_index_posting_lists", "dint_decode_posting_blocks",
+    "dint_query_index_create", "dint_query_index_destroy", "dint_and_queries",
 )
 
 #: dint_block_ref (include/dint_hip.h)
@@ -65,6 +66,10 @@ def _load():
     lib.dint_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.dint_index_posting_lists.argtypes = [vp, sz, vp, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(u64)]
     lib.dint_decode_posting_blocks.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, sz, vp]
+    lib.dint_query_index_create.argtypes = [vp, vp, sz, vp, sz, sz, C.POINTER(vp)]
+    lib.dint_query_index_destroy.restype = None
+    lib.dint_query_index_destroy.argtypes = [vp]
+    lib.dint_and_queries.argtypes = [vp, vp, vp, sz, vp, vp]
     lib.dint_debug_wave_scan.argtypes = [vp, vp]
     return lib
 
@@ -206,6 +211,47 @@ def decode_posting_lists(docs_dict: "Dictionary", freqs_dict, index: np.ndarray,
     docids = docids_dev.cpu().numpy().view(np.uint32)[:total]
     freqs = freqs_dev.cpu().numpy().view(np.uint32)[:total] if freqs_dev is not None else None
     return docids, freqs
+
+
+class QueryIndex:
+    """An index resident on the device, ready for conjunctive queries: the reference's
+    `index` + `and_query<false>` pair (include/ds2i/queries.hpp:34-84), a batch per call."""
+
+    def __init__(self, docs_dict: "Dictionary", index: np.ndarray, list_offsets: np.ndarray):
+        import torch
+
+        self.docs_dict = docs_dict
+        self.blocks, self.total = index_posting_lists(index, list_offsets)
+        self.n_lists = max(0, len(list_offsets) - 1)
+        dev = torch.device("cuda", docs_dict.device)
+        padded = np.concatenate([np.ascontiguousarray(index, dtype=np.uint8), np.zeros(16, dtype=np.uint8)])
+        self._index_dev = torch.from_numpy(padded).to(dev)
+        self._h = C.c_void_p()
+        _check(_lib.dint_query_index_create(docs_dict._h, self._index_dev.data_ptr(), padded.size,
+                                            self.blocks.ctypes.data, len(self.blocks), self.n_lists,
+                                            C.byref(self._h)), "dint_query_index_create")
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.dint_query_index_destroy(h)
+
+    __del__ = close
+
+    def and_queries(self, queries) -> np.ndarray:
+        """queries: sequence of term-id sequences -> u64 result counts, one per query."""
+        import torch
+
+        lens = np.fromiter((len(q) for q in queries), dtype=np.uint64, count=len(queries))
+        offs = np.zeros(len(queries) + 1, dtype=np.uint64)
+        np.cumsum(lens, out=offs[1:])
+        terms = np.ascontiguousarray(np.concatenate([np.asarray(q, dtype=np.uint32) for q in queries])
+                                     if len(queries) else np.zeros(0, np.uint32), dtype=np.uint32)
+        counts = np.zeros(len(queries), dtype=np.uint64)
+        stream = torch.cuda.current_stream(torch.device("cuda", self.docs_dict.device)).cuda_stream
+        _check(_lib.dint_and_queries(self._h, terms.ctypes.data, offs.ctypes.data, len(queries),
+                                     counts.ctypes.data, stream), "dint_and_queries")
+        return counts
 
 
 def units_to_device(units: np.ndarray, device):

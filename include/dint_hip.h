@@ -153,6 +153,28 @@ int dint_decode_posting_blocks(const dint_dict* docs_dict, const dint_dict* freq
                                size_t index_bytes, const dint_block_ref* d_blocks, size_t n_blocks,
                                uint32_t* d_docids, uint32_t* d_freqs, size_t out_capacity, void* stream);
 
+/* ---- conjunctive queries over the in-index layout ------------------------------------------
+ * Replaces: the index + and_query<false> pair of the reference's query path
+ * (include/ds2i/queries.hpp:34-84, driven by src/queries.cpp:15-61 op_perftest), for a batch of
+ * queries per call. The query index keeps a device copy of the block table (with its block
+ * maxima packed for the block-max search of next_geq, dict_posting_list.hpp:126-147) and the
+ * workspaces of the query rounds; it borrows d_index and docs_dict, which must outlive it. */
+typedef struct dint_query_index dint_query_index;
+
+/* blocks: HOST block table of ALL lists as produced by dint_index_posting_lists (lists in order,
+ * each list's blocks contiguous); d_index: the index bytes on docs_dict's device. */
+int dint_query_index_create(const dint_dict* docs_dict, const uint8_t* d_index, size_t index_bytes,
+                            const dint_block_ref* blocks, size_t n_blocks, size_t n_lists,
+                            dint_query_index** out);
+void dint_query_index_destroy(dint_query_index* qi);
+
+/* counts[q] = number of documents that contain every term of query q (duplicate terms count
+ * once, queries.hpp:28-31; an empty query counts 0, :38). terms/query_offsets/counts are HOST
+ * arrays: query q is terms[query_offsets[q] .. query_offsets[q+1]). A term >= n_lists is
+ * DINT_ERR_ARG. The call enqueues on `stream` and returns after synchronising it. */
+int dint_and_queries(dint_query_index* qi, const uint32_t* terms, const uint64_t* query_offsets,
+                     size_t n_queries, uint64_t* counts, void* stream);
+
 /* Sum of per-kernel device time (ms) between the two events the library
  * records around the decode kernel of the most recent dint_decode_units on
  * this dictionary; valid after the stream has been synchronised. */

@@ -435,3 +435,121 @@ uint32_t oracle_posting_list_decode(const oracle_dict* docs_dict, const oracle_d
     }
     return n;
 }
+
+/* ---- AND queries ------------------------------------------------------------------------ */
+
+/* document_enumerator, include/dint/dict_posting_list.hpp:88-342 (docs side only) */
+typedef struct {
+    const oracle_dict* dict;
+    uint32_t n, blocks;
+    const uint8_t *block_maxs, *block_endpoints, *blocks_data;
+    uint64_t universe;
+    uint32_t cur_block, pos_in_block, cur_block_max, cur_block_size, cur_docid;
+    uint32_t docs_buf[BLOCK + 256];
+} oracle_enum;
+
+static uint32_t en_block_max(const oracle_enum* e, uint32_t b) { return ld32(e->block_maxs + 4 * (size_t)b); }
+
+static void en_decode_docs_block(oracle_enum* e, uint32_t block) { /* :284-309 */
+    uint32_t endpoint = block ? ld32(e->block_endpoints + 4 * (size_t)(block - 1)) : 0;
+    const uint8_t* block_data = e->blocks_data + endpoint;
+    e->cur_block_size = ((block + 1) * BLOCK <= e->n) ? BLOCK : (e->n % BLOCK);
+    uint32_t cur_base = (block ? en_block_max(e, block - 1) : (uint32_t)-1) + 1;
+    e->cur_block_max = en_block_max(e, block);
+    memset(e->docs_buf, 0, sizeof e->docs_buf);
+    oracle_block_decode(e->dict, block_data, e->docs_buf, e->cur_block_max - cur_base - (e->cur_block_size - 1),
+                        e->cur_block_size);
+    e->docs_buf[0] += cur_base;
+    e->cur_block = block;
+    e->pos_in_block = 0;
+    e->cur_docid = e->docs_buf[0];
+}
+
+static void en_init(oracle_enum* e, const oracle_dict* d, const uint8_t* data, uint64_t universe) { /* :90-109 */
+    e->dict = d;
+    const uint8_t* base = oracle_vbyte_read(data, &e->n);
+    e->blocks = (e->n + BLOCK - 1) / BLOCK;
+    e->block_maxs = base;
+    e->block_endpoints = base + 4 * (size_t)e->blocks;
+    e->blocks_data = e->block_endpoints + 4 * (size_t)(e->blocks - 1);
+    e->universe = universe;
+    en_decode_docs_block(e, 0);
+}
+
+static void en_next(oracle_enum* e) { /* :111-124 */
+    ++e->pos_in_block;
+    if (e->pos_in_block == e->cur_block_size) {
+        if (e->cur_block + 1 == e->blocks) {
+            e->cur_docid = (uint32_t)e->universe;
+            return;
+        }
+        en_decode_docs_block(e, e->cur_block + 1);
+    } else {
+        e->cur_docid += e->docs_buf[e->pos_in_block] + 1;
+    }
+}
+
+static void en_next_geq(oracle_enum* e, uint64_t lower_bound) { /* :126-147 */
+    if (lower_bound > e->cur_block_max) {
+        if (lower_bound > en_block_max(e, e->blocks - 1)) {
+            e->cur_docid = (uint32_t)e->universe;
+            return;
+        }
+        uint32_t block = e->cur_block + 1;
+        while (en_block_max(e, block) < lower_bound) ++block;
+        en_decode_docs_block(e, block);
+    }
+    while (e->cur_docid < lower_bound) e->cur_docid += e->docs_buf[++e->pos_in_block] + 1;
+}
+
+static int cmp_u32(const void* a, const void* b) {
+    uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b;
+    return x < y ? -1 : x > y;
+}
+static int cmp_enum_size(const void* a, const void* b) {
+    const oracle_enum* x = *(oracle_enum* const*)a;
+    const oracle_enum* y = *(oracle_enum* const*)b;
+    return x->n < y->n ? -1 : x->n > y->n;
+}
+
+/* and_query<false>, include/ds2i/queries.hpp:34-84 */
+uint64_t oracle_and_query(const oracle_dict* docs_dict, const uint8_t* index, const uint64_t* list_offsets,
+                          uint64_t num_docs, const uint32_t* terms_in, size_t n_terms) {
+    if (!n_terms) return 0;
+    uint32_t* terms = (uint32_t*)malloc(n_terms * 4);
+    memcpy(terms, terms_in, n_terms * 4);
+    qsort(terms, n_terms, 4, cmp_u32); /* remove_duplicate_terms, :28-31 */
+    size_t m = 0;
+    for (size_t i = 0; i != n_terms; ++i)
+        if (!m || terms[i] != terms[m - 1]) terms[m++] = terms[i];
+    oracle_enum* store = (oracle_enum*)malloc(m * sizeof(oracle_enum));
+    oracle_enum** enums = (oracle_enum**)malloc(m * sizeof(oracle_enum*));
+    for (size_t i = 0; i != m; ++i) {
+        en_init(&store[i], docs_dict, index + list_offsets[terms[i]], num_docs);
+        enums[i] = &store[i];
+    }
+    qsort(enums, m, sizeof(oracle_enum*), cmp_enum_size); /* sort by increasing frequency, :49-52 */
+    uint64_t results = 0;
+    uint64_t candidate = enums[0]->cur_docid;
+    size_t i = 1;
+    while (candidate < num_docs) {
+        for (; i < m; ++i) {
+            en_next_geq(enums[i], candidate);
+            if (enums[i]->cur_docid != candidate) {
+                candidate = enums[i]->cur_docid;
+                i = 0;
+                break;
+            }
+        }
+        if (i == m) {
+            results += 1;
+            en_next(enums[0]);
+            candidate = enums[0]->cur_docid;
+            i = 1;
+        }
+    }
+    free(terms);
+    free(store);
+    free(enums);
+    return results;
+}

@@ -89,6 +89,13 @@ const uint8_t* oracle_block_decode(const oracle_dict* d, const uint8_t* in, uint
 uint32_t oracle_posting_list_decode(const oracle_dict* docs_dict, const oracle_dict* freqs_dict,
                                     const uint8_t* list, uint32_t* docids, uint32_t* freqs);
 
+/* and_query<false>::operator() (include/ds2i/queries.hpp:34-84) over document_enumerators with
+ * the reference's next_geq / next (include/dint/dict_posting_list.hpp:111-147): block-max
+ * skipping, lazy per-block decode. Lists are addressed through list_offsets (this repo's index
+ * container); num_docs is the universe. Returns the number of documents that contain every term. */
+uint64_t oracle_and_query(const oracle_dict* docs_dict, const uint8_t* index, const uint64_t* list_offsets,
+                          uint64_t num_docs, const uint32_t* terms, size_t n_terms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,8 @@ def _load():
     lib.oracle_interpolative_decode.argtypes = [vp, vp, C.c_uint32, C.c_size_t]
     lib.oracle_posting_list_decode.restype = C.c_uint32
     lib.oracle_posting_list_decode.argtypes = [vp, vp, vp, vp, vp]
+    lib.oracle_and_query.restype = C.c_uint64
+    lib.oracle_and_query.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_size_t]
     lib.oracle_time_stream.restype = C.c_double
     lib.oracle_time_stream.argtypes = [vp, vp, C.c_size_t, C.c_uint64, C.c_double,
                                        C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -132,3 +134,27 @@ def posting_list_decode(docs_dict: OracleDict, freqs_dict: OracleDict, index: np
     docids, freqs = np.empty(n, dtype=np.uint32), np.empty(n, dtype=np.uint32)
     _lib.oracle_posting_list_decode(docs_dict._h, freqs_dict._h, base, docids.ctypes.data, freqs.ctypes.data)
     return docids, freqs
+
+
+def and_query(docs_dict: OracleDict, index: np.ndarray, list_offsets: np.ndarray, num_docs: int, terms) -> int:
+    """and_query<false>: number of documents containing every term (block-max skipping enumerators)."""
+    index = np.ascontiguousarray(index, dtype=np.uint8)
+    padded = np.concatenate([index, np.zeros(16, dtype=np.uint8)])
+    offs = np.ascontiguousarray(list_offsets, dtype=np.uint64)
+    t = np.ascontiguousarray(terms, dtype=np.uint32)
+    return int(_lib.oracle_and_query(docs_dict._h, padded.ctypes.data, offs.ctypes.data, num_docs, t.ctypes.data, t.size))
+
+
+class OracleIndex:
+    """An index padded once for the enumerators' word-wise reads; and_query per call without copies."""
+
+    def __init__(self, docs_dict: OracleDict, index: np.ndarray, list_offsets: np.ndarray, num_docs: int):
+        self.docs_dict = docs_dict
+        self._padded = np.concatenate([np.ascontiguousarray(index, dtype=np.uint8), np.zeros(16, dtype=np.uint8)])
+        self._offs = np.ascontiguousarray(list_offsets, dtype=np.uint64)
+        self.num_docs = num_docs
+
+    def and_query(self, terms) -> int:
+        t = np.ascontiguousarray(terms, dtype=np.uint32)
+        return int(_lib.oracle_and_query(self.docs_dict._h, self._padded.ctypes.data, self._offs.ctypes.data,
+                                         self.num_docs, t.ctypes.data, t.size))

@@ -1,0 +1,43 @@
+"""Query workloads for the AND-query tests.
+
+tests/golden/queries.txt is the query log the reference's own tests ship
+(test/test_data/queries: 500 queries of 1-11 term ids, one per line); its
+term ids address the reference's test collection, so they are folded onto
+the synthetic corpora with `term % n_lists`."""
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def reference_queries(n_lists: int):
+    out = []
+    with open(os.path.join(_HERE, "golden", "queries.txt")) as f:
+        for line in f:
+            terms = [int(t) % n_lists for t in line.split()]
+            if terms:
+                out.append(np.array(terms, dtype=np.uint32))
+    return out
+
+
+def heavy_queries(lens: np.ndarray, n_queries: int, seed: int = 5, pool: int = 48, max_terms: int = 6):
+    """Queries over the longest lists, so that intersections are non-empty and span many blocks."""
+    r = np.random.default_rng(seed)
+    big = np.argsort(-lens.astype(np.int64), kind="stable")[:pool]
+    out = []
+    for _ in range(n_queries):
+        k = int(r.integers(1, max_terms + 1))
+        out.append(r.choice(big, k, replace=True).astype(np.uint32))  # duplicates on purpose
+    return out
+
+
+def intersect(docids: np.ndarray, bounds: np.ndarray, terms) -> int:
+    """Plain set intersection of the lists' docIDs (the builder's input, no codec involved)."""
+    terms = np.unique(np.asarray(terms))
+    if terms.size == 0:
+        return 0
+    cur = docids[int(bounds[terms[0]]):int(bounds[terms[0] + 1])]
+    for t in terms[1:]:
+        cur = np.intersect1d(cur, docids[int(bounds[t]):int(bounds[t + 1])], assume_unique=True)
+    return int(cur.size)

@@ -1,0 +1,95 @@
+"""AND queries on the GPU through the C ABI (dint_and_queries): result counts identical to the
+oracle's and_query and to plain set intersection of the index builder's input."""
+import numpy as np
+import pytest
+
+import oracle
+from dint_amd import host
+from queries import heavy_queries, intersect, reference_queries
+from test_index_cpu import get_index
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def device():
+    import torch
+
+    assert torch.cuda.is_available()
+    from dint_amd import device as dev
+
+    return dev
+
+
+def _query_index(device, ix, kind):
+    dd = device.Dictionary(kind, ix.docs_dict)
+    return device.QueryIndex(dd, ix.bytes, ix.offsets)
+
+
+@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.RECTANGULAR, host.MULTI_PACKED])
+@pytest.mark.parametrize("corpus_name", ["small_corpus", "dense_corpus", "sparse_corpus"])
+def test_batch_matches_oracle(device, request, kind, corpus_name):
+    corpus = request.getfixturevalue(corpus_name)
+    ix = get_index(corpus, kind)
+    qi = _query_index(device, ix, kind)
+    qs = reference_queries(len(ix.lens)) + heavy_queries(ix.lens, 200)
+    got = qi.and_queries(qs)
+    want = np.array([intersect(ix.docids, ix.bounds, q) for q in qs], dtype=np.uint64)
+    assert np.array_equal(got, want)
+    assert int(want.sum()) > 1000
+    od = oracle.OracleDict(kind, ix.docs_dict)
+    nd = int(ix.docids.max()) + 1
+    for i in range(0, len(qs), 7):
+        assert int(got[i]) == oracle.and_query(od, ix.bytes, ix.offsets, nd, qs[i])
+    qi.close()
+
+
+def test_one_query_at_a_time_and_workspace_reuse(device, small_corpus):
+    """op_perftest runs the queries one by one (src/queries.cpp:15-61)."""
+    kind = host.SINGLE_PACKED
+    ix = get_index(small_corpus, kind)
+    qi = _query_index(device, ix, kind)
+    qs = heavy_queries(ix.lens, 40, seed=9)
+    batch = qi.and_queries(qs)
+    for q, want in zip(qs, batch):
+        assert int(qi.and_queries([q])[0]) == int(want)
+    assert np.array_equal(qi.and_queries(qs), batch)
+
+
+def test_edges(device, dense_corpus):
+    kind = host.SINGLE_PACKED
+    ix = get_index(dense_corpus, kind)
+    qi = _query_index(device, ix, kind)
+    longest, shortest = int(np.argmax(ix.lens)), int(np.argmin(ix.lens))
+    got = qi.and_queries([[], [longest], [longest] * 4, [shortest, longest], [shortest]])
+    assert got[0] == 0
+    assert got[1] == ix.lens[longest] and got[2] == ix.lens[longest]
+    assert got[3] == intersect(ix.docids, ix.bounds, [shortest, longest])
+    assert got[4] == ix.lens[shortest]
+    assert qi.and_queries([]).size == 0
+    assert np.array_equal(qi.and_queries([[], []]), [0, 0])
+    with pytest.raises(device.DintError):
+        qi.and_queries([[len(ix.lens)]])  # no such list
+
+
+def test_disjoint_and_identical_lists(device):
+    """Hand-made lists: disjoint ranges (every probe misses past the last block), interleaved
+    evens/odds (every probe lands in a block and misses), and a list ANDed with a superset."""
+    kind = host.SINGLE_PACKED
+    a = np.arange(0, 3000, dtype=np.uint32)                  # 0..2999
+    b = np.arange(5000, 9000, dtype=np.uint32)               # disjoint, beyond a
+    ev = np.arange(0, 20000, 2, dtype=np.uint32)
+    od_ = np.arange(1, 20000, 2, dtype=np.uint32)
+    sup = np.arange(0, 20000, dtype=np.uint32)
+    lists = [a, b, ev, od_, sup]
+    docids = np.concatenate(lists)
+    lens = np.array([len(x) for x in lists], dtype=np.uint32)
+    gaps = np.concatenate([host.docids_to_gaps(x) for x in lists])
+    coll = host.Collection(gaps, lens)
+    freqs = np.ones(docids.size, dtype=np.uint32)
+    dd = host.build_dictionary(kind, coll)
+    fd = host.build_dictionary(kind, host.Collection(freqs - 1, lens))
+    idx, offs = host.build_index(kind, dd, fd, docids, freqs, lens)
+    qi = device.QueryIndex(device.Dictionary(kind, dd), idx, offs)
+    got = qi.and_queries([[0, 1], [1, 0], [2, 3], [2, 4], [3, 4, 2], [0, 4], [0, 2], [1, 3, 4]])
+    assert list(got) == [0, 0, 0, len(ev), 0, len(a), 1500, 2000]

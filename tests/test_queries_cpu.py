@@ -1,0 +1,48 @@
+"""AND queries on the CPU: the oracle's and_query (block-max skipping cursors, a restatement of
+include/ds2i/queries.hpp:34-84 + dict_posting_list.hpp:111-147) against plain set intersection
+of the index builder's input."""
+import numpy as np
+import pytest
+
+import oracle
+from dint_amd import host
+from queries import heavy_queries, intersect, reference_queries
+from test_index_cpu import get_index
+
+
+def _num_docs(ix):
+    return int(ix.docids.max()) + 1
+
+
+def test_reference_query_log_shape():
+    qs = reference_queries(1 << 30)
+    assert len(qs) == 500
+    assert min(len(q) for q in qs) == 1 and max(len(q) for q in qs) == 11
+
+
+@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.RECTANGULAR, host.MULTI_PACKED])
+def test_oracle_and_query_is_set_intersection(small_corpus, kind):
+    ix = get_index(small_corpus, kind)
+    od = oracle.OracleDict(kind, ix.docs_dict)
+    nd = _num_docs(ix)
+    qs = reference_queries(len(ix.lens))[:150] + heavy_queries(ix.lens, 60)
+    hits = 0
+    for q in qs:
+        got = oracle.and_query(od, ix.bytes, ix.offsets, nd, q)
+        assert got == intersect(ix.docids, ix.bounds, q)
+        hits += got
+    assert hits > 1000  # the workload does exercise non-empty intersections
+
+
+def test_oracle_and_query_edges(dense_corpus):
+    kind = host.SINGLE_PACKED
+    ix = get_index(dense_corpus, kind)
+    od = oracle.OracleDict(kind, ix.docs_dict)
+    nd = _num_docs(ix)
+    longest = int(np.argmax(ix.lens))
+    shortest = int(np.argmin(ix.lens))
+    assert oracle.and_query(od, ix.bytes, ix.offsets, nd, []) == 0  # queries.hpp:38
+    assert oracle.and_query(od, ix.bytes, ix.offsets, nd, [longest]) == int(ix.lens[longest])
+    assert oracle.and_query(od, ix.bytes, ix.offsets, nd, [longest] * 4) == int(ix.lens[longest])  # :28-31
+    assert oracle.and_query(od, ix.bytes, ix.offsets, nd, [shortest, longest]) == intersect(
+        ix.docids, ix.bounds, [shortest, longest])

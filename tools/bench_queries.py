@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""AND-query timing (BASELINE config 5): the reference's op_perftest shape
+(src/queries.cpp:15-61 — every query run on its own, first pass untimed, avg/q50/q90/q95 in µs)
+plus the batch rate the device path is built for, with the oracle's and_query timed beside it.
+
+    python tools/bench_queries.py [--postings 1e8] [--type single_packed_dint] [--runs 3]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--postings", type=float, default=1e8)
+    ap.add_argument("--type", default="single_packed_dint")
+    ap.add_argument("--runs", type=int, default=3)
+    ap.add_argument("--cpu-queries", type=int, default=500)
+    args = ap.parse_args()
+
+    import torch
+    from dint_amd import device, host
+    from queries import heavy_queries, reference_queries
+    import oracle
+
+    kind = host.KIND_BY_TYPE[args.type]
+    coll = host.synth_collection(int(args.postings), seed=11)
+    docids = host.gaps_to_docids(coll)
+    freqs = np.ones(coll.num_postings, dtype=np.uint32)
+    dd = host.build_dictionary(kind, coll, max_sample_ints=50_000_000)
+    fd = host.build_dictionary(kind, host.Collection(freqs[:1000] - 1, np.array([1000], dtype=np.uint32)))
+    idx, offs = host.build_index(kind, dd, fd, docids, freqs, coll.lens)
+    n_lists = len(coll.lens)
+    workloads = {
+        "reference_log_mod_lists": reference_queries(n_lists),
+        "longest_lists": heavy_queries(coll.lens, 500, pool=256, max_terms=5),
+    }
+    ddev = device.Dictionary(kind, dd)
+    qi = device.QueryIndex(ddev, idx, offs)
+    od = oracle.OracleDict(kind, dd)
+    oi = oracle.OracleIndex(od, idx, offs, int(docids.max()) + 1)
+    out = {"postings": coll.num_postings, "lists": n_lists, "blocks": int(len(qi.blocks)), "type": args.type,
+           "index_bytes": int(idx.size)}
+    for name, qs in workloads.items():
+        counts = qi.and_queries(qs)  # warm-up (and the first, untimed pass)
+        t_batch = []
+        for _ in range(args.runs):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            qi.and_queries(qs)
+            t_batch.append(time.perf_counter() - t0)
+        single = []
+        for q in qs:
+            qi.and_queries([q])
+        for q in qs:
+            t0 = time.perf_counter()
+            qi.and_queries([q])
+            single.append((time.perf_counter() - t0) * 1e6)
+        single = np.sort(np.array(single))
+        cpu_q = qs[:args.cpu_queries]
+        cpu = []
+        for q in cpu_q:
+            t0 = time.perf_counter()
+            oi.and_query(q)
+            cpu.append((time.perf_counter() - t0) * 1e6)
+        cpu_counts = np.array([oi.and_query(q) for q in cpu_q[:50]], dtype=np.uint64)
+        assert np.array_equal(cpu_counts, counts[:len(cpu_counts)])
+        cpu = np.sort(np.array(cpu))
+        pct = lambda a, p: float(a[min(len(a) - 1, int(p * len(a) / 100))])
+        out[name] = {
+            "queries": len(qs), "results": int(counts.sum()),
+            "gpu_batch_us_per_query": min(t_batch) * 1e6 / len(qs),
+            "gpu_single": {"avg": float(single.mean()), "q50": pct(single, 50), "q90": pct(single, 90), "q95": pct(single, 95)},
+            "cpu_oracle": {"avg": float(cpu.mean()), "q50": pct(cpu, 50), "q90": pct(cpu, 90), "q95": pct(cpu, 95), "cores": 1},
+        }
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
