@@ -8,7 +8,9 @@
 //    64 * kSPL 16-bit slots; lane l owns the kSPL CONSECUTIVE slots kSPL*l ..
 //    (one unaligned load), so (lane, k) order is stream order is output order;
 //  * per slot one metadata word ((size-1) << 24 | payload offset): LDS for the hot
-//    codewords, L2 for the cold ones, looked up one tile ahead of use;
+//    codewords (any subset of the dictionary: a bitmap + rank remap in LDS maps a codeword to
+//    its hot slot, so the host can pick the most USED codewords, not a prefix), L2 for the
+//    cold ones, looked up one tile ahead of use;
 //  * header/payload classification costs nothing unless a tile holds a 0 or 1
 //    slot (or an exception straddles in); then a short per-lane state machine is
 //    iterated until the lane-to-lane carries agree (one or two rounds);
@@ -26,7 +28,7 @@
 //    dict_posting_list.hpp:296).
 //
 // LDS (160 KB/CU, one 1024-thread workgroup per CU):
-//   [ hot meta | 256 zero words | hot payloads ]  <= kHotImageWords, shared by 16 waves
+//   [ 256 zero words | remap pairs | hot meta | hot payloads ]  <= kHotImageWords, shared by 16 waves
 //   [ slot classification table, 4 KB ]
 //   16 x [ {flag word, rank base} pairs | per-codeword delta table | literal table ]
 #pragma once
@@ -61,7 +63,7 @@ constexpr uint32_t kScratchWords = kFwWords + 2 * kDeltaWords;
 constexpr uint32_t kClassTableWords = 328;            // slot classification table: 648 u16 rows, padded
 constexpr uint32_t kHotImageWords = kLdsWords - kClassTableWords - kWavesPerBlock * kScratchWords;
 constexpr uint32_t kZeroWords = 256;                  // longest run codeword
-constexpr uint32_t kColdBase = 1u << 24;              // source offsets >= this live in global memory
+constexpr uint32_t kColdBase = 1u << 23;              // source offsets >= this live in global memory
 constexpr uint32_t kColdBase4 = 4 * kColdBase;        // the same in bytes
 constexpr uint32_t kLitAddr4 = 0xC0000000u;           // source byte "address" of an exception literal
 constexpr uint32_t kQueueShards = 8;                  // dynamic unit queue: one counter per shard
@@ -69,17 +71,17 @@ constexpr uint32_t kQueueStride = 32;                 // words between counters 
 
 // One dictionary of the (possibly multi-) dictionary file.
 struct dict_desc {
-    uint32_t meta_base;  // first slot of this dictionary in gmeta
-    uint32_t hot_base;   // LDS word offset of its hot meta table
-    uint32_t hot_k;      // codewords < hot_k have meta + payload in the LDS image
-    uint32_t pad;
+    uint32_t meta_base;    // first slot of this dictionary in gmeta
+    uint32_t hot_base;     // LDS word offset of its hot meta table (indexed by hot rank)
+    uint32_t remap_base;   // LDS word offset of its remap: per 32 codewords {hot bitmap, hot rank of the first}
+    uint32_t remap_limit;  // codewords >= this (a multiple of 32) are cold without a look
 };
 
 // Device view of a dictionary file.
 struct dict_view {
-    const uint32_t* gmeta;      // per codeword slot: (size-1) << 24 | word offset into gtable
+    const uint32_t* gmeta;      // per codeword slot: (size-1) << 24 | kColdBase | word offset into gtable
     const uint32_t* gtable;     // [256 zeros][payload words...]
-    const uint32_t* lds_image;  // [256 zeros]{[hot meta of dictionary d]}[hot payloads], hot_words long
+    const uint32_t* lds_image;  // [256 zeros]{[remap of d]}{[hot meta of d]}[hot payloads], hot_words long
     const dict_desc* descs;     // one per dictionary (multi: 6)
     uint32_t gmeta_words;
     uint32_t gtable_words;
@@ -171,22 +173,6 @@ __device__ __forceinline__ void unpack_slots(uint64_t raw, tile_regs& t) {
     for (uint32_t k = 0; k != kSPL; ++k) t.s[k] = uint32_t(raw >> (W * k)) & ((1u << W) - 1u);
 }
 
-// Metadata word of a codeword: LDS for the hot codewords, L2 for the cold ones.
-// Two address spaces, two instructions: an unconditional DS read and a global
-// read under the cold lanes' exec mask (a pointer select would turn both into
-// one slow flat load).
-__device__ __forceinline__ uint32_t lookup_meta(const dict_view& d, const uint32_t* lds, const dict_desc& dd,
-                                                uint32_t v) {
-#ifdef DINT_EXP_NOCOLD
-    v = v < dd.hot_k ? v : 7 + v % (dd.hot_k - 7);
-#endif
-    const bool hot = v < dd.hot_k;
-    uint32_t m = lds[hot ? dd.hot_base + v : 0u];
-    asm volatile("" : "+v"(m));  // keep the DS read a DS read
-    if (!hot) m = d.gmeta[dd.meta_base + v];
-    return m;
-}
-
 // Slot classification table. Whether a slot is a codeword header or an exception
 // payload depends on its predecessors; per lane (4 consecutive slots) the outcome is a
 // function of how many payload slots the previous lane still owes (st_in) and of the
@@ -254,7 +240,8 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
     const uint8_t* const lds_bytes = reinterpret_cast<const uint8_t*>(lds);
     const uint16_t* const rows = cls + (W == 16 ? 0 : kRows16);
 
-    const uint32_t hot_k = dd.hot_k;
+    const uint32_t remap_limit = dd.remap_limit;
+    const uint8_t* const remap_bytes = reinterpret_cast<const uint8_t*>(lds + dd.remap_base);
     const __amdgpu_buffer_rsrc_t rs_meta =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.dict.gmeta), 0, int(a.dict.gmeta_words * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_table =
@@ -266,13 +253,17 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out_u, 0, int(uniform(n) * 4), 0x00020000);
 
     auto meta_of = [&](uint32_t v) -> uint32_t {
-#ifdef DINT_EXP_NOCOLD
-        v = v < hot_k ? v : 7 + v % (hot_k - 7);
-#endif
-        // LDS for the hot codewords (unconditional read: cold lanes read word 0), L2 for the cold ones
-        const bool hot = v < hot_k;
-        uint32_t m = lds[hot ? dd.hot_base + v : 0u];
-        asm volatile("" : "+v"(m));  // keep the DS read a DS read (no pointer select -> flat load)
+        // hot? one {bitmap, rank} pair per 32 codewords; the hot meta table is indexed by rank.
+        // Unconditional DS reads (lanes past the remap read pair 0 and are forced cold), then the
+        // L2 read under the cold lanes' exec mask: two address spaces, never a pointer select
+        // (that would become one slow flat load).
+        const bool in = v < remap_limit;
+        const u32x2 pr = *reinterpret_cast<const u32x2*>(remap_bytes + (in ? (v >> 5) * 8u : 0u));
+        const uint32_t bit = v & 31u;
+        const bool hot = in && ((pr.x >> bit) & 1u) != 0;
+        const uint32_t rank = pr.y + uint32_t(__builtin_popcount(pr.x & ((1u << bit) - 1u)));
+        uint32_t m = lds[hot ? dd.hot_base + rank : 0u];
+        asm volatile("" : "+v"(m));  // keep the DS read a DS read
         if (!hot) m = __builtin_amdgcn_raw_buffer_load_b32(rs_meta, 4 * (dd.meta_base + v), 0, 0);
         return m;
     };
@@ -373,10 +364,7 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
         for (uint32_t k = 0; k != kSPL; ++k) {
             const uint32_t m = cur.m[k];
             sz4[k] = ((m >> 22) & 0x3FCu) + 4u;
-            src4[k] = ((m << 2) & 0x3FFFFFCu) + (cur.s[k] < hot_k ? 0u : kColdBase4);
-#ifdef DINT_EXP_NOCOLD
-            src4[k] = (m << 2) & 0x3FFFFFCu;
-#endif
+            src4[k] = (m << 2) & 0x3FFFFFCu;  // cold metas carry kColdBase in their offset field
             live[k] = ~0u;
             lord[k] = k;
         }
@@ -614,8 +602,8 @@ __device__ __forceinline__ void decode_unit_multi(const decode_args& a, const ui
         dict_desc dd;
         dd.meta_base = uniform(a.dict.descs[d].meta_base);
         dd.hot_base = uniform(a.dict.descs[d].hot_base);
-        dd.hot_k = uniform(a.dict.descs[d].hot_k);
-        dd.pad = 0;
+        dd.remap_base = uniform(a.dict.descs[d].remap_base);
+        dd.remap_limit = uniform(a.dict.descs[d].remap_limit);
         uint32_t* const out = a.out + out_off + done;
         if (narrow) pos = decode_segment<8>(a, lds, cls, scratch, dd, pos + 1, bsize, out, lane);
         else pos = decode_segment<16>(a, lds, cls, scratch, dd, pos + 1, bsize, out, lane);

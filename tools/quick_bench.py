@@ -23,20 +23,21 @@ dev = torch.device("cuda:0")
 enc_dev = torch.from_numpy(enc).to(dev)
 units_dev = device.units_to_device(units, dev)
 out_dev = torch.empty(coll.num_postings, dtype=torch.int32, device=dev)
-for i in range(6):
-    d.decode_units(enc_dev, units_dev, len(units), out_dev)
-    torch.cuda.synchronize()
-    ms = d.last_kernel_ms()
-    gb = (coll.num_postings * 4 + enc.size) / 1e9
-    print(f"run {i}: {ms:.3f} ms  {coll.num_postings / ms / 1e6:.2f} G ints/s  {gb / ms * 1e3:.1f} GB/s algorithmic", flush=True)
-import ctypes as C
-if hasattr(device._lib, "dint_debug_read_stamps"):
-    buf = (C.c_ulonglong * 16)()
-    device._lib.dint_debug_read_stamps(buf)
-    tot = sum(buf[:8]) or 1
-    names = ["0 slots wait + meta issue", "1 classification", "2 sizes/scan (meta wait)", "3 batch build", "4 expansion LDS",
-             "5 cold wait (+store ack)", "6 stores + rotate", "7 segment prologue"]
-    for i in range(8):
-        print(f"  phase {names[i]:28s} {100.0 * buf[i] / tot:6.2f} %")
+def runs(tag, n=5):
+    for i in range(n):
+        d.decode_units(enc_dev, units_dev, len(units), out_dev)
+        torch.cuda.synchronize()
+        ms = d.last_kernel_ms()
+        gb = (coll.num_postings * 4 + enc.size) / 1e9
+        print(f"{tag} run {i}: {ms:.3f} ms  {coll.num_postings / ms / 1e6:.2f} G ints/s  {gb / ms * 1e3:.1f} GB/s algorithmic", flush=True)
+runs("prefix hot set")
+ok0 = np.array_equal(out_dev.cpu().numpy().view(np.uint32), coll.gaps)
+t = time.time()
+d.index_stream(enc, unit_ints)
+print("index_stream (usage counts)", round(time.time() - t, 1), "s")
+d.tune()
+print("tuned: hot entries", d.info().hot_entries, "lds bytes", d.info().lds_bytes)
+out_dev.zero_()
+runs("usage hot set")
 ok = np.array_equal(out_dev.cpu().numpy().view(np.uint32), coll.gaps)
-print("bit-exact vs encoder input:", ok)
+print("bit-exact vs encoder input:", ok0, ok)
