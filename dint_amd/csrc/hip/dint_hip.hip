@@ -143,10 +143,6 @@ struct dint_dict {
     // host copies used by dint_index_stream
     std::vector<uint32_t> h_start;  // per dictionary first meta slot (+ end)
     std::vector<uint32_t> h_size;   // per meta slot
-    parsed_dict parsed;             // kept for dint_dict_tune
-    // codeword uses seen by the host pre-passes (dint_index_stream), per meta slot
-    mutable std::vector<uint64_t> observed;
-    mutable std::mutex observed_mutex;
     // device buffers
     uint32_t* d_gmeta = nullptr;
     uint32_t* d_gtable = nullptr;
@@ -170,18 +166,17 @@ namespace {
 
 // Device layout of a dictionary file.
 //   gtable   = [256 zeros][the file's payload words][16 words of padding];
-//   gmeta[i] = (size-1) << 24 | kColdBase | word offset into gtable (runs -> offset 0), one
+//   gmeta[i] = (size-1) << 24 | kColdBase | word offset into gtable (runs: just the size), one
 //              word per offsets slot of the file (multi: the 6 dictionaries back to back);
-// both staged once. The LDS image is rebuilt by every (re)tune:
-//   [256 zeros]{remap of dictionary d}{hot meta of dictionary d}[hot payloads]
-//   remap    = per 32 codewords {bitmap of hot ones, hot rank of the first}, up to remap_limit;
-//   hot meta = (size-1) << 24 | word offset inside the image (runs -> the zeros), by rank;
+//   LDS image = [256 zeros]{[hot meta of dictionary d: hot_k[d] words]}[hot payloads];
+//   hot meta = (size-1) << 24 | word offset inside the image (runs -> the zeros);
 //   payloads = the union of the hot entries' table intervals, each word once (the packed
 //              formats nest short entries inside long ones: single_dictionary.hpp:109-160).
-// Which codewords are hot: with usage counts (dint_dict_tune) the ones with the most uses per
-// LDS word; without, a prefix of each dictionary — the DSF builder appends entries in
-// decreasing corpus n-gram frequency (dictionary_builders.hpp:61-72) — with the budget split
-// evenly between the dictionaries of a multi file.
+// Hot = codewords below hot_k[d]: the DSF builder appends entries in decreasing corpus n-gram
+// frequency (dictionary_builders.hpp:61-72), so "index < K" is the hotness test, one compare
+// in the kernel. (Picking the hot set by measured USE counts behind a bitmap + rank remap was
+// tried: 67% instead of 60% of the lookups on chip, paid for by the longer lookup — no gain.)
+// The image budget is split evenly between the dictionaries of a multi file.
 struct hot_layout {
     std::vector<uint32_t> image;
     std::vector<dict_desc> descs;
@@ -193,118 +188,39 @@ uint32_t entry_payload_words(parsed_dict const& pd, uint32_t d, uint32_t i) {
     return (i >= kReserved && sz <= kMaxEntry) ? sz : 0;  // runs and the exception rows copy zeros
 }
 
-int choose_hot_set(parsed_dict const& pd, const uint64_t* usage, hot_layout& out) {
+int choose_hot_set(parsed_dict const& pd, hot_layout& out) {
     const uint32_t nd = pd.num_dicts;
-    const uint64_t budget_all = uint64_t(kHotImageWords) - kZeroWords - 4;
-    std::vector<uint32_t> n_entries(nd), limit(nd, 0);
-    for (uint32_t d = 0; d != nd; ++d) n_entries[d] = std::min<uint32_t>(pd.start[d + 1] - pd.start[d], kEntries);
+    const uint64_t share = (uint64_t(kHotImageWords) - kZeroWords - 4) / nd;
     std::vector<uint8_t> covered(pd.table.size(), 0);
-    std::vector<std::vector<uint8_t>> hot(nd);
-    for (uint32_t d = 0; d != nd; ++d) hot[d].assign(n_entries[d], 0);
-    auto marginal = [&](uint32_t d, uint32_t i) -> uint32_t {
-        const uint32_t pw = entry_payload_words(pd, d, i);
-        uint32_t add = 1;
-        const uint32_t o = pd.off[pd.start[d] + i];
-        for (uint32_t w = 0; w != pw; ++w) add += covered[o + w] ? 0u : 1u;
-        return add;
-    };
-    auto take = [&](uint32_t d, uint32_t i) {
-        const uint32_t pw = entry_payload_words(pd, d, i);
-        const uint32_t o = pd.off[pd.start[d] + i];
-        for (uint32_t w = 0; w != pw; ++w) covered[o + w] = 1;
-        hot[d][i] = 1;
-    };
-    uint64_t used = 0;
-    if (usage) {
-        // remap reach: the whole dictionary for one dictionary; for several, the prefix that
-        // holds 99% of each one's uses, the remaps together within a quarter of the image
-        struct cand {
-            double density;
-            uint32_t d, i;
-        };
-        std::vector<cand> cands;
-        for (uint32_t d = 0; d != nd; ++d) {
-            const uint64_t* u = usage + pd.start[d];
-            uint32_t reach = n_entries[d];
-            if (nd > 1) {
-                uint64_t total = 0, run = 0;
-                for (uint32_t i = kReserved; i < n_entries[d]; ++i) total += u[i];
-                reach = kReserved;
-                for (uint32_t i = kReserved; i < n_entries[d] && run * 100 < total * 99; ++i) {
-                    run += u[i];
-                    reach = i + 1;
-                }
-                reach = std::min<uint32_t>(reach, uint32_t(budget_all / 4 / nd / 2 * 32));
-            }
-            limit[d] = std::min<uint32_t>((reach + 31) / 32 * 32, (n_entries[d] + 31) / 32 * 32);
-            used += limit[d] / 32 * 2;
-            for (uint32_t i = 2; i < std::min(limit[d], n_entries[d]); ++i)
-                if (u[i]) cands.push_back({double(u[i]) / (1 + entry_payload_words(pd, d, i)), d, i});
+    std::vector<uint32_t> hot_k(nd, 0);
+    // pass 1: how many codewords of each dictionary fit its share
+    for (uint32_t d = 0; d != nd; ++d) {
+        const uint32_t n_entries = std::min<uint32_t>(pd.start[d + 1] - pd.start[d], kEntries);
+        uint64_t words = 0;
+        uint32_t k = 0;
+        for (; k != n_entries; ++k) {
+            const uint32_t pw = entry_payload_words(pd, d, k);
+            const uint32_t o = pd.off[pd.start[d] + k];
+            uint32_t add = 1;
+            for (uint32_t w = 0; w != pw; ++w) add += covered[o + w] ? 0u : 1u;
+            if (words + add > share) break;
+            words += add;
+            for (uint32_t w = 0; w != pw; ++w) covered[o + w] = 1;
         }
-        std::sort(cands.begin(), cands.end(), [](cand const& a, cand const& b) {
-            return a.density != b.density ? a.density > b.density : (a.d != b.d ? a.d < b.d : a.i < b.i);
-        });
-        for (cand const& c : cands) {
-            const uint32_t add = marginal(c.d, c.i);
-            if (used + add > budget_all) continue;
-            used += add;
-            take(c.d, c.i);
-        }
-        // leftover room: unused low codewords, in index order
-        for (uint32_t d = 0; d != nd; ++d)
-            for (uint32_t i = 2; i < std::min(limit[d], n_entries[d]); ++i) {
-                if (hot[d][i]) continue;
-                const uint32_t add = marginal(d, i);
-                if (used + add > budget_all) break;
-                used += add;
-                take(d, i);
-            }
-    } else {
-        const uint64_t share = budget_all / nd;
-        for (uint32_t d = 0; d != nd; ++d) {
-            uint64_t words = 0;
-            uint32_t k = 0;
-            for (; k != n_entries[d]; ++k) {
-                const uint64_t remap = ((k + 1 + 31) / 32) * 2;
-                const uint32_t add = marginal(d, k);
-                if (words + add + remap > share) break;
-                words += add;
-                take(d, k);
-            }
-            limit[d] = (k + 31) / 32 * 32;
-        }
+        hot_k[d] = k;
     }
-    // lay the image out
+    // pass 2: lay the image out
     std::vector<uint32_t>& image = out.image;
     image.assign(kZeroWords, 0);
     out.descs.assign(nd, dict_desc{});
     out.hot_entries = 0;
     for (uint32_t d = 0; d != nd; ++d) {
         out.descs[d].meta_base = pd.start[d];
-        out.descs[d].remap_base = uint32_t(image.size());
-        out.descs[d].remap_limit = limit[d];
-        uint32_t rank = 0;
-        for (uint32_t w = 0; w != limit[d] / 32; ++w) {
-            uint32_t bits = 0;
-            for (uint32_t b = 0; b != 32; ++b) {
-                const uint32_t i = 32 * w + b;
-                if (i < n_entries[d] && hot[d][i]) bits |= 1u << b;
-            }
-            image.push_back(bits);
-            image.push_back(rank);
-            rank += uint32_t(__builtin_popcount(bits));
-        }
-        if (limit[d] == 0) {  // lanes past the remap still read pair 0
-            image.push_back(0);
-            image.push_back(0);
-        }
-        out.hot_entries += rank;
-    }
-    for (uint32_t d = 0; d != nd; ++d) {
+        out.descs[d].hot_k = hot_k[d];
         out.descs[d].hot_base = uint32_t(image.size());
-        uint32_t n_hot = 0;
-        for (uint32_t i = 0; i != n_entries[d]; ++i) n_hot += hot[d][i];
-        image.resize(image.size() + std::max<uint32_t>(1, n_hot), 0);
+        out.descs[d].pad = 0;
+        image.resize(image.size() + std::max<uint32_t>(1, hot_k[d]), 0);
+        out.hot_entries += hot_k[d];
     }
     std::vector<uint32_t> where(pd.table.size(), 0);
     for (size_t w = 0; w != pd.table.size(); ++w)
@@ -312,15 +228,12 @@ int choose_hot_set(parsed_dict const& pd, const uint64_t* usage, hot_layout& out
             where[w] = uint32_t(image.size());
             image.push_back(pd.table[w]);
         }
-    for (uint32_t d = 0; d != nd; ++d) {
-        uint32_t rank = 0;
-        for (uint32_t i = 0; i != n_entries[d]; ++i) {
-            if (!hot[d][i]) continue;
+    for (uint32_t d = 0; d != nd; ++d)
+        for (uint32_t i = 0; i != hot_k[d]; ++i) {
             const uint32_t sz = pd.size[pd.start[d] + i];
             const uint32_t o = entry_payload_words(pd, d, i) ? where[pd.off[pd.start[d] + i]] : 0u;  // 0: the zero region
-            image[out.descs[d].hot_base + rank++] = ((sz - 1) << 24) | o;
+            image[out.descs[d].hot_base + i] = ((sz - 1) << 24) | o;
         }
-    }
     while (image.size() % 4) image.push_back(0);
     if (image.size() > kHotImageWords) return DINT_ERR_FORMAT;
     return DINT_OK;
@@ -346,11 +259,11 @@ int stage_dictionary(dint_dict& dd, parsed_dict const& pd) {
     for (size_t i = 0; i != slots; ++i) {
         const uint32_t sz = pd.size[i];
         if (sz == 0 || sz > 256) return DINT_ERR_FORMAT;
-        const uint32_t o = sz > kMaxEntry ? 0 : pd.off[i] + kZeroWords;
-        gmeta[i] = ((sz - 1) << 24) | kColdBase | o;
+        // runs copy zeros: their source is the zero region at the start of the LDS image, never cold
+        gmeta[i] = ((sz - 1) << 24) | (sz > kMaxEntry ? 0u : (kColdBase | (pd.off[i] + kZeroWords)));
     }
     hot_layout lay;
-    const int st = choose_hot_set(pd, nullptr, lay);
+    const int st = choose_hot_set(pd, lay);
     if (st != DINT_OK) return st;
 
     HIP_TRY(hipSetDevice(dd.device));
@@ -496,9 +409,7 @@ int dint_dict_create(int kind, const void* file_bytes, size_t len, int device, d
         return DINT_ERR_HIP;
     }
     dd->compute_units = uint32_t(prop.multiProcessorCount);
-    dd->observed.assign(pd.size.size(), 0);
     int st = stage_dictionary(*dd, pd);
-    dd->parsed = std::move(pd);
     if (st != DINT_OK) {
         dint_dict_destroy(dd);
         return st;
@@ -532,38 +443,6 @@ void dint_dict_destroy(dint_dict* dd) {
     delete dd;
 }
 
-int dint_dict_tune(dint_dict* dd, const uint64_t* usage, size_t n_counts) {
-    if (!dd) return DINT_ERR_ARG;
-    std::vector<uint64_t> seen;
-    if (usage) {
-        if (n_counts != dd->h_size.size()) return DINT_ERR_ARG;
-    } else {
-        std::lock_guard<std::mutex> lock(dd->observed_mutex);
-        seen = dd->observed;
-        usage = seen.data();
-    }
-    hot_layout lay;
-    const int st = choose_hot_set(dd->parsed, usage, lay);
-    if (st != DINT_OK) return st;
-    if (std::getenv("DINT_DEBUG")) {  // share of the codeword uses that will find their entry in LDS
-        uint64_t all = 0, hot = 0;
-        for (uint32_t d = 0; d != dd->parsed.num_dicts; ++d) {
-            const uint32_t base = dd->parsed.start[d];
-            const uint32_t* remap = lay.image.data() + lay.descs[d].remap_base;
-            for (uint32_t i = 2; i < dd->parsed.start[d + 1] - base && i < kEntries; ++i) {
-                all += usage[base + i];
-                if (i < lay.descs[d].remap_limit && ((remap[2 * (i / 32)] >> (i % 32)) & 1u)) hot += usage[base + i];
-            }
-        }
-        std::fprintf(stderr, "dint_dict_tune: %u hot codewords, %.4f of %llu observed uses on chip\n", lay.hot_entries,
-                     all ? double(hot) / double(all) : 0.0, (unsigned long long)all);
-    }
-    std::lock_guard<std::mutex> lock(dd->launch_mutex);
-    HIP_TRY(hipSetDevice(dd->device));
-    HIP_TRY(hipDeviceSynchronize());  // no decode may be reading the old image
-    return upload_hot_set(*dd, lay);
-}
-
 int dint_dict_info_get(const dint_dict* dd, dint_dict_info* info) {
     if (!dd || !info) return DINT_ERR_ARG;
     info->kind = dd->kind;
@@ -588,7 +467,7 @@ int dint_index_stream(const dint_dict* dd, const uint8_t* enc, size_t enc_bytes,
     uint64_t out_pos = 0, lists = 0;
     const bool multi = dd->kind == DINT_DICT_MULTI_PACKED;
     const uint32_t cut = unit_ints ? unit_ints : ~0u;
-    std::vector<uint64_t> use(dd->h_size.size(), 0);  // codeword uses, for dint_dict_tune
+
     while (p != end) {
         uint32_t n, universe;
         p = read_vbyte(p, end, &n);
@@ -612,7 +491,6 @@ int dint_index_stream(const dint_dict* dd, const uint8_t* enc, size_t enc_bytes,
                 uint32_t idx = ld16(p);
                 if (idx >= 2) {
                     i += size[idx];
-                    ++use[idx];
                     p += 2;
                 } else {
                     i += 1;
@@ -647,7 +525,6 @@ int dint_index_stream(const dint_dict* dd, const uint8_t* enc, size_t enc_bytes,
                     if (idx >= 2) {
                         if (idx >= limit) return DINT_ERR_FORMAT;
                         i += dd->h_size[base + idx];
-                        ++use[base + idx];
                         p += narrow ? 1 : 2;
                     } else {
                         i += 1;
@@ -671,10 +548,6 @@ int dint_index_stream(const dint_dict* dd, const uint8_t* enc, size_t enc_bytes,
     *n_units = units.size();
     if (total_ints) *total_ints = out_pos;
     if (n_lists) *n_lists = lists;
-    {
-        std::lock_guard<std::mutex> lock(dd->observed_mutex);
-        for (size_t i = 0; i != use.size(); ++i) dd->observed[i] += use[i];
-    }
     return DINT_OK;
 }
 

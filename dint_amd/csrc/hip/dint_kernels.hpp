@@ -8,9 +8,7 @@
 //    64 * kSPL 16-bit slots; lane l owns the kSPL CONSECUTIVE slots kSPL*l ..
 //    (one unaligned load), so (lane, k) order is stream order is output order;
 //  * per slot one metadata word ((size-1) << 24 | payload offset): LDS for the hot
-//    codewords (any subset of the dictionary: a bitmap + rank remap in LDS maps a codeword to
-//    its hot slot, so the host can pick the most USED codewords, not a prefix), L2 for the
-//    cold ones, looked up one tile ahead of use;
+//    codewords (a prefix of the dictionary), L2 for the cold ones, looked up one tile ahead;
 //  * header/payload classification costs nothing unless a tile holds a 0 or 1
 //    slot (or an exception straddles in); then a short per-lane state machine is
 //    iterated until the lane-to-lane carries agree (one or two rounds);
@@ -19,18 +17,22 @@
 //    position in a per-wave flag bitmap (ds_or) and stores `source - position` in
 //    a table indexed by its ordinal; a small scan over the bitmap's word
 //    popcounts gives per-word rank bases. Then each lane takes 4 consecutive
-//    output integers: flag word + rank base -> 4 ranks -> 4 table reads -> 4
-//    gathers (LDS: hot payloads and the zero region of the runs; L2: cold
-//    payloads; literal table: exceptions) -> one 16-byte store, so every global
-//    store instruction covers 1 KB of consecutive output. Exactly n integers are
+//    output integers: flag word + rank base -> 4 ranks -> 4 table reads -> 4 LDS
+//    gathers -> one 16-byte store, so every global store instruction covers 1 KB of
+//    consecutive output. Every source is in LDS by then: hot payloads and the zero region
+//    of the runs live there; the COLD payloads of a batch are fetched once per codeword
+//    (a compact worklist, one 16-byte load per lane and quad, while the batch tables are
+//    being built) into per-wave staging cells, where the exception literals go too. The
+//    per-CU vector memory path (TA/TCP) is the scarce resource of this kernel: per-output
+//    4-byte gathers from L2 kept it busy 90% of the time (profiles/r01_pmc_ta_v8.txt). Exactly n integers are
 //    written per unit, nothing past them (the reference needs a pre-zeroed buffer
 //    and a 256-word overflow area, include/dint/dint_codecs.hpp:11,
 //    dict_posting_list.hpp:296).
 //
 // LDS (160 KB/CU, one 1024-thread workgroup per CU):
-//   [ 256 zero words | remap pairs | hot meta | hot payloads ]  <= kHotImageWords, shared by 16 waves
+//   [ 256 zero words | hot meta | hot payloads ]  <= kHotImageWords, shared by 16 waves
 //   [ slot classification table, 4 KB ]
-//   16 x [ {flag word, rank base} pairs | per-codeword delta table | literal table ]
+//   16 x [ {flag word, rank base} pairs | per-codeword delta table | staging cells ]
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -56,32 +58,33 @@ constexpr uint32_t kTileSlots = kWave * kSPL;         // 256 slots per tile
 constexpr uint32_t kGroups = 4;                       // 256-output groups expanded together
 constexpr uint32_t kCap = kGroups * 256;              // outputs per expansion batch (>= kSPL * 256)
 // per wave: 64 {flag word, rank base} pairs (+ spare), per-codeword delta table (+ 4 dummy
-// entries for codewords that are not live in a batch), literal table of the same shape
+// entries for codewords that are not live in a batch), staging cells
 constexpr uint32_t kFwWords = 2 * 64 + 4;              // 64 pairs: flag positions are taken mod 2048
 constexpr uint32_t kDeltaWords = kTileSlots + 4;
-constexpr uint32_t kScratchWords = kFwWords + 2 * kDeltaWords;
+constexpr uint32_t kStageQuads = 128;                  // 16-byte cells: cold payloads and exception literals of a batch
+constexpr uint32_t kStageWords = 4 * kStageQuads;      // (its first half doubles as the fetch worklist)
+constexpr uint32_t kScratchWords = kFwWords + kDeltaWords + kStageWords;
 constexpr uint32_t kClassTableWords = 328;            // slot classification table: 648 u16 rows, padded
 constexpr uint32_t kHotImageWords = kLdsWords - kClassTableWords - kWavesPerBlock * kScratchWords;
 constexpr uint32_t kZeroWords = 256;                  // longest run codeword
 constexpr uint32_t kColdBase = 1u << 23;              // source offsets >= this live in global memory
 constexpr uint32_t kColdBase4 = 4 * kColdBase;        // the same in bytes
-constexpr uint32_t kLitAddr4 = 0xC0000000u;           // source byte "address" of an exception literal
 constexpr uint32_t kQueueShards = 8;                  // dynamic unit queue: one counter per shard
 constexpr uint32_t kQueueStride = 32;                 // words between counters (own 128-byte line each)
 
 // One dictionary of the (possibly multi-) dictionary file.
 struct dict_desc {
     uint32_t meta_base;    // first slot of this dictionary in gmeta
-    uint32_t hot_base;     // LDS word offset of its hot meta table (indexed by hot rank)
-    uint32_t remap_base;   // LDS word offset of its remap: per 32 codewords {hot bitmap, hot rank of the first}
-    uint32_t remap_limit;  // codewords >= this (a multiple of 32) are cold without a look
+    uint32_t hot_base;     // LDS word offset of its hot meta table
+    uint32_t hot_k;        // codewords < hot_k have meta + payload in the LDS image
+    uint32_t pad;
 };
 
 // Device view of a dictionary file.
 struct dict_view {
     const uint32_t* gmeta;      // per codeword slot: (size-1) << 24 | kColdBase | word offset into gtable
     const uint32_t* gtable;     // [256 zeros][payload words...]
-    const uint32_t* lds_image;  // [256 zeros]{[remap of d]}{[hot meta of d]}[hot payloads], hot_words long
+    const uint32_t* lds_image;  // [256 zeros]{[hot meta of dictionary d]}[hot payloads], hot_words long
     const dict_desc* descs;     // one per dictionary (multi: 6)
     uint32_t gmeta_words;
     uint32_t gtable_words;
@@ -144,11 +147,23 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 // kSPL consecutive W-bit slots of one lane (W = 16: 8 bytes, W = 8: 4 bytes) from an
-// arbitrary byte address. Never reads past the buffer: the tail
-// lanes load the final bytes and shift (bytes past the end read as zero).
+// arbitrary byte address. `tile_byte` is the (wave-uniform) offset of the tile's
+// first slot: when the whole tile lies inside the buffer — every tile but the stream's last —
+// this is one plain load whose result nothing touches until the tile is unpacked, two tiles
+// later. Otherwise it never reads past the buffer: the tail lanes load the final bytes and
+// shift (bytes past the end read as zero), which waits for the data on the spot.
 template <int W>
-__device__ __forceinline__ uint64_t load_lane_slots(const uint8_t* enc, uint64_t byte_off, uint64_t enc_bytes) {
+__device__ __forceinline__ uint64_t load_lane_slots(const uint8_t* enc, uint64_t tile_byte, uint32_t lane,
+                                                    uint64_t enc_bytes) {
     constexpr uint32_t kBytes = kSPL * W / 8;
+    const uint64_t byte_off = tile_byte + uint64_t(kBytes) * lane;
+    if (tile_byte + uint64_t(kBytes) * kWave <= enc_bytes) {  // wave-uniform
+        if (W == 16) {
+            const u32x2 r = reinterpret_cast<const u32x2_a1*>(enc + byte_off)->v;
+            return (uint64_t(r.y) << 32) | r.x;
+        }
+        return reinterpret_cast<const u32_a1*>(enc + byte_off)->v;
+    }
     const uint64_t last_valid = enc_bytes - kBytes;  // enc_bytes >= 8 is checked by the host
     const uint64_t o = byte_off < last_valid ? byte_off : last_valid;
     const uint64_t over = byte_off - o;  // 0 for all but the tail lanes
@@ -233,15 +248,15 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
                                                    uint32_t n, uint32_t* const out, uint32_t lane) {
     constexpr uint32_t kSlotBytes = W / 8;
     constexpr uint32_t kTileBytes = kTileSlots * kSlotBytes;
-    // per-wave scratch (byte offsets): {flag word, rank base} pairs | delta table | literal table
+    // per-wave scratch (byte offsets): {flag word, rank base} pairs | delta table | staging cells
     uint8_t* const fw = reinterpret_cast<uint8_t*>(scratch);                  // 64 pairs of 8 bytes (+1 spare)
     uint8_t* const delta = reinterpret_cast<uint8_t*>(scratch + kFwWords);    // 256 entries + 4 dummies
-    constexpr uint32_t kLitOff = 4 * kDeltaWords;                             // literal table = delta + kLitOff
+    uint8_t* const stage = reinterpret_cast<uint8_t*>(scratch + kFwWords + kDeltaWords);  // 128 cells of 16 bytes
     const uint8_t* const lds_bytes = reinterpret_cast<const uint8_t*>(lds);
+    const uint32_t stage_off = uint32_t(stage - lds_bytes);                   // the cells as gather sources
     const uint16_t* const rows = cls + (W == 16 ? 0 : kRows16);
 
-    const uint32_t remap_limit = dd.remap_limit;
-    const uint8_t* const remap_bytes = reinterpret_cast<const uint8_t*>(lds + dd.remap_base);
+    const uint32_t hot_k = dd.hot_k;
     const __amdgpu_buffer_rsrc_t rs_meta =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.dict.gmeta), 0, int(a.dict.gmeta_words * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_table =
@@ -253,31 +268,34 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out_u, 0, int(uniform(n) * 4), 0x00020000);
 
     auto meta_of = [&](uint32_t v) -> uint32_t {
-        // hot? one {bitmap, rank} pair per 32 codewords; the hot meta table is indexed by rank.
-        // Unconditional DS reads (lanes past the remap read pair 0 and are forced cold), then the
-        // L2 read under the cold lanes' exec mask: two address spaces, never a pointer select
-        // (that would become one slow flat load).
-        const bool in = v < remap_limit;
-        const u32x2 pr = *reinterpret_cast<const u32x2*>(remap_bytes + (in ? (v >> 5) * 8u : 0u));
-        const uint32_t bit = v & 31u;
-        const bool hot = in && ((pr.x >> bit) & 1u) != 0;
-        const uint32_t rank = pr.y + uint32_t(__builtin_popcount(pr.x & ((1u << bit) - 1u)));
-        uint32_t m = lds[hot ? dd.hot_base + rank : 0u];
+        // LDS for the hot codewords (unconditional read: cold lanes read word 0), L2 for the cold
+        // ones under their exec mask: two address spaces, never a pointer select (that would
+        // become one slow flat load)
+        const bool hot = v < hot_k;
+        uint32_t m = lds[hot ? dd.hot_base + v : 0u];
         asm volatile("" : "+v"(m));  // keep the DS read a DS read
+#ifdef DINT_EXP_NOMETA  // timing experiment: no L2 metadata reads (results are wrong)
+        if (!hot) m = (lds[dd.hot_base + 7u + (v & 1023u)] & 0xFF000000u) | kColdBase | (v & 0xFFFFu);
+#else
         if (!hot) m = __builtin_amdgcn_raw_buffer_load_b32(rs_meta, 4 * (dd.meta_base + v), 0, 0);
+#endif
         return m;
     };
 
     // pipeline: tile t in `cur` (slots + metadata), tile t+1 in `nxt`, tile t+2's slots in flight
-    uint64_t slot_byte = in_off + uint64_t(kSlotBytes * kSPL) * lane;
+    const uint64_t in_off_u = (uint64_t(uniform(uint32_t(in_off >> 32))) << 32) | uniform(uint32_t(in_off));
+    uint64_t slot_byte = in_off_u;  // first byte of the tile whose slots are loaded next (wave-uniform)
     tile_regs cur, nxt;
-    unpack_slots<W>(load_lane_slots<W>(a.enc, slot_byte, a.enc_bytes), cur);
+    unpack_slots<W>(load_lane_slots<W>(a.enc, slot_byte, lane, a.enc_bytes), cur);
     slot_byte += kTileBytes;
-    uint64_t raw1 = load_lane_slots<W>(a.enc, slot_byte, a.enc_bytes);
+    uint64_t raw1 = load_lane_slots<W>(a.enc, slot_byte, lane, a.enc_bytes);
     slot_byte += kTileBytes;
-    uint64_t raw2 = load_lane_slots<W>(a.enc, slot_byte, a.enc_bytes);
+    uint64_t raw2 = load_lane_slots<W>(a.enc, slot_byte, lane, a.enc_bytes);
 #pragma unroll
     for (uint32_t k = 0; k != kSPL; ++k) cur.m[k] = meta_of(cur.s[k]);
+    // Everything loaded so far has landed before the loop is entered: inside it, a wait may only
+    // ever sit right before a tile's stores (see the prefetch note below), never after them.
+    asm volatile("" ::"v"(raw1), "v"(raw2), "v"(cur.m[0]), "v"(cur.m[1]), "v"(cur.m[2]), "v"(cur.m[3]));
 
     // lane constants of the expansion: this lane owns outputs 4*lane .. 4*lane+3 of every group
     const uint32_t sh = (4 * lane) & 31u;                 // bit position of its nibble in its flag word
@@ -359,7 +377,7 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
         STAMP(1);  // classification
         // ---- 2. sizes, offsets, ordinals (sizes and sources in BYTES of output / payload) --------
         // live[k]: all ones when slot k is a codeword header that belongs to this segment
-        uint32_t sz4[kSPL], src4[kSPL], live[kSPL], lord[kSPL];
+        uint32_t sz4[kSPL], src4[kSPL], live[kSPL], lord[kSPL], lit[kSPL];
 #pragma unroll
         for (uint32_t k = 0; k != kSPL; ++k) {
             const uint32_t m = cur.m[k];
@@ -367,6 +385,7 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
             src4[k] = (m << 2) & 0x3FFFFFCu;  // cold metas carry kColdBase in their offset field
             live[k] = ~0u;
             lord[k] = k;
+            lit[k] = 0;
         }
         uint32_t hdrcnt = 4;
         if (special) {
@@ -375,7 +394,7 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
                 const uint32_t payM = uint32_t(int32_t(row << (31 - k)) >> 31);  // all ones: payload slot
                 const uint32_t excM = uint32_t(int32_t(row << (27 - k)) >> 31);  // all ones: exception header
                 sz4[k] = ((sz4[k] & ~excM) | (4u & excM)) & ~payM;
-                src4[k] = (src4[k] & ~excM) | (kLitAddr4 & excM);
+                lit[k] = excM;
                 live[k] = ~payM;
             }
             lord[1] = (row >> 11) & 1u;
@@ -417,34 +436,91 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
             const uint64_t am = __ballot(cand != 0);
             end_slot = readlane(cand, 63u - uint32_t(__builtin_clzll(am | 1ull)));
         }
-        STAMP(2);  // sizes, scan
+        // staging demand of each slot: 16-byte cells | (1 << 16 if they are fetched from the table).
+        // Cold codewords (meta from L2: kColdBase set) take ceil(size / 4) cells, exception literals
+        // one; hot codewords and runs (zero region) none.
+        uint32_t pk[kSPL], cpre[kSPL];
+#pragma unroll
+        for (uint32_t k = 0; k != kSPL; ++k) {
+            const uint32_t coldM = live[k] & ~lit[k] & (0u - ((src4[k] >> 25) & 1u));
+            pk[k] = (coldM & ((1u << 16) | ((sz4[k] + 12u) >> 4))) | (live[k] & lit[k] & 1u);
+        }
+        cpre[0] = 0;
+#pragma unroll
+        for (uint32_t k = 1; k != kSPL; ++k) cpre[k] = cpre[k - 1] + pk[k - 1];
+        const uint32_t cl = cpre[kSPL - 1] + pk[kSPL - 1];
+        const bool tile_staged = __ballot(cl != 0) != 0;
+        uint32_t cexcl = 0;
+        if (tile_staged) cexcl = wave_inclusive_sum(cl) - cl;
+        const uint32_t qb = cexcl & 0xFFFFu, wb = cexcl >> 16;  // first cell / first fetch of this lane
+        STAMP(2);  // sizes, scans
         // ---- prefetch: metadata of tile t+1 (its slots are already here), slots of tile t+2. Issued
-        // before this tile's cold gathers and stores; waited for together with the gathers, right
+        // before this tile's cold fetches and stores; waited for together with the fetches, right
         // before the stores (vmcnt is one in-order counter for loads AND stores on gfx950: a wait
         // placed after the stores would also wait for their acknowledgements).
         unpack_slots<W>(raw1, nxt);
 #pragma unroll
         for (uint32_t k = 0; k != kSPL; ++k) nxt.m[k] = meta_of(nxt.s[k]);
         slot_byte += kTileBytes;
-        const uint64_t raw3 = load_lane_slots<W>(a.enc, slot_byte, a.enc_bytes);
+        const uint64_t raw3 = load_lane_slots<W>(a.enc, slot_byte, lane, a.enc_bytes);
         STAMP(0);
-        // ---- 3./4. batches of <= kCap outputs (normally one: the whole tile) ------------------------
-        uint32_t done = 0, rdone = 0;
-        while (done < total) {
-            const bool inb = lsum != 0 && obase >= done && (obase + lsum - done) <= kCap;
+        // ---- 3./4. batches of <= kCap outputs and <= kStageQuads cells (normally one: the whole tile)
+        // (a do-while: the compiler must see that the wait inside precedes the register rotation
+        // below on every path, or it waits again there — after the stores, for their acknowledgements)
+        uint32_t done = 0, rdone = 0, qdone = 0, wdone = 0;
+        do {
+            const bool inb = lsum != 0 && obase >= done && (obase + lsum - done) <= kCap &&
+                             (qb + (cl & 0xFFFFu) - qdone) <= kStageQuads;
             const uint64_t bm = __ballot(inb);
             const uint32_t last = 63u - uint32_t(__builtin_clzll(bm | 1ull));
             const uint32_t bend = readlane(obase + lsum, last);
             const uint32_t rend = readlane(rbase + nlive, last);
-            const uint32_t bt = bend - done;  // outputs in this batch, 1..kCap
+            const uint32_t qend = readlane(qb + (cl & 0xFFFFu), last);
+            const uint32_t wend = readlane(wb + (cl >> 16), last);
+            const uint32_t bt = bend - done;        // outputs in this batch, 1..kCap
+            const uint32_t nfetch = wend - wdone;   // cold codewords to fetch, <= kStageQuads
+            const uint32_t inbM = inb ? ~0u : 0u;
 
+            // (a) worklist of the cold codewords {table byte offset, cell | quads << 16}, then each
+            // lane takes up to two of them and fetches their first two quads (sizes 1..8); the
+            // fetches fly while the batch tables are built
+            uint32_t srcb[kSPL];
+#pragma unroll
+            for (uint32_t k = 0; k != kSPL; ++k) srcb[k] = src4[k];
+            u32x2 e0 = {0u, 0u}, e1 = {0u, 0u};
+            u32x4 q00 = {0u, 0u, 0u, 0u}, q01 = q00, q10 = q00, q11 = q00;
+            if (tile_staged) {
+#pragma unroll
+                for (uint32_t k = 0; k != kSPL; ++k) {
+                    const uint32_t lv = live[k] & inbM;
+                    const uint32_t cell = qb - qdone + (cpre[k] & 0xFFFFu);
+                    if (lv != 0 && (pk[k] & 0xFFFFu) != 0) srcb[k] = stage_off + 16u * cell;
+                    if (lv != 0 && (pk[k] >> 16) != 0) {
+                        const u32x2 e = {src4[k] - kColdBase4, cell | (pk[k] << 16)};
+                        *reinterpret_cast<u32x2*>(stage + 8u * (wb - wdone + (cpre[k] >> 16))) = e;
+                    }
+                }
+                wave_lds_fence();
+                if (lane < nfetch) e0 = *reinterpret_cast<const u32x2*>(stage + 8u * lane);
+                if (lane + 64u < nfetch) e1 = *reinterpret_cast<const u32x2*>(stage + 8u * (lane + 64u));
+                wave_lds_fence();
+#ifndef DINT_EXP_NOFETCH  // timing experiment: no cold payload reads (results are wrong)
+                if (lane < nfetch) {
+                    q00 = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e0.x, 0, 0);
+                    if (((e0.y >> 16) & 7u) > 1u) q01 = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e0.x + 16u, 0, 0);
+                }
+                if (lane + 64u < nfetch) {
+                    q10 = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e1.x, 0, 0);
+                    if (((e1.y >> 16) & 7u) > 1u) q11 = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e1.x + 16u, 0, 0);
+                }
+#endif
+            }
+
+            // (b) flags and deltas. Every slot runs the same instructions: a codeword that is not
+            // live in this batch ORs a zero into an in-range flag word and parks its delta in a dummy.
             *reinterpret_cast<uint32_t*>(fw + 8 * lane) = 0;  // clear all 64 flag words
             wave_lds_fence();
-            // Every slot runs the same instructions: a codeword that is not live in this batch ORs
-            // a zero into an in-range flag word and parks its delta in a dummy entry.
-            uint32_t any_cold = 0;
             const uint32_t rel0 = obase - done, ord0 = rbase - rdone;
-            const uint32_t inbM = inb ? ~0u : 0u;
 #pragma unroll
             for (uint32_t k = 0; k != kSPL; ++k) {
                 const uint32_t lv = live[k] & inbM;
@@ -453,15 +529,8 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
                 __hip_atomic_fetch_or(fword, lv & (1u << (rel & 31u)), __ATOMIC_RELAXED,
                                       __HIP_MEMORY_SCOPE_WAVEFRONT);
                 const uint32_t ord = (lv & (ord0 + lord[k])) | (~lv & (kTileSlots + k));
-                uint32_t* const dslot = reinterpret_cast<uint32_t*>(delta + 4 * ord);
-                *dslot = src4[k] - 4 * rel;  // literal: kLitAddr4 - 4 * rel
-                if (tile_exc) dslot[kLitOff / 4] = excval[k];
-                // bit 31 set iff the source is cold (>= kColdBase4) and not the literal marker (>= 2^31)
-                any_cold |= lv & (src4[k] + (0x80000000u - kColdBase4)) & ~src4[k];
+                *reinterpret_cast<uint32_t*>(delta + 4 * ord) = srcb[k] - 4 * rel;
             }
-            const bool any_cold_lane = int32_t(any_cold) < 0;
-            const bool batch_cold = __ballot(any_cold_lane) != 0;
-            (void)batch_cold;
             wave_lds_fence();
             {
                 uint32_t* const pair = reinterpret_cast<uint32_t*>(fw + 8 * lane);
@@ -469,11 +538,52 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
                 const uint32_t pi = wave_inclusive_sum(pc);
                 pair[1] = pi - pc - 1u;  // flags before this word, minus one
             }
+            STAMP(3);  // batch build: worklist, flags, deltas, rank bases
+
+            // (c) the fetched quads and the exception literals go into their cells
+            if (tile_staged) {
+                if (lane < nfetch) {
+                    uint8_t* const c = stage + 16u * (e0.y & 0xFFFFu);
+                    *reinterpret_cast<u32x4*>(c) = q00;
+                    if (((e0.y >> 16) & 7u) > 1u) *reinterpret_cast<u32x4*>(c + 16) = q01;
+                }
+                if (lane + 64u < nfetch) {
+                    uint8_t* const c = stage + 16u * (e1.y & 0xFFFFu);
+                    *reinterpret_cast<u32x4*>(c) = q10;
+                    if (((e1.y >> 16) & 7u) > 1u) *reinterpret_cast<u32x4*>(c + 16) = q11;
+                }
+                // size-16 cold codewords (rare): quads 2 and 3, fetched and waited for on the spot
+                const bool big0 = lane < nfetch && ((e0.y >> 16) & 7u) > 2u;
+                const bool big1 = lane + 64u < nfetch && ((e1.y >> 16) & 7u) > 2u;
+#ifdef DINT_EXP_NOFETCH
+                if (false) {
+#else
+                if (__ballot(big0 || big1) != 0) {
+#endif
+                    if (big0) {
+                        uint8_t* const c = stage + 16u * (e0.y & 0xFFFFu);
+                        *reinterpret_cast<u32x4*>(c + 32) = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e0.x + 32u, 0, 0);
+                        if (((e0.y >> 16) & 7u) > 3u)
+                            *reinterpret_cast<u32x4*>(c + 48) = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e0.x + 48u, 0, 0);
+                    }
+                    if (big1) {
+                        uint8_t* const c = stage + 16u * (e1.y & 0xFFFFu);
+                        *reinterpret_cast<u32x4*>(c + 32) = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e1.x + 32u, 0, 0);
+                        if (((e1.y >> 16) & 7u) > 3u)
+                            *reinterpret_cast<u32x4*>(c + 48) = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e1.x + 48u, 0, 0);
+                    }
+                }
+                if (tile_exc) {
+#pragma unroll
+                    for (uint32_t k = 0; k != kSPL; ++k)
+                        if ((live[k] & inbM & lit[k]) != 0)
+                            *reinterpret_cast<uint32_t*>(stage + 16u * (qb - qdone + (cpre[k] & 0xFFFFu))) = excval[k];
+                }
+            }
             wave_lds_fence();
 
-            STAMP(3);  // batch build: flags, deltas, rank bases
-            // expansion: each lane takes 4 consecutive outputs of every 256-output group. Pass 1 runs
-            // the LDS chains and issues the cold gathers of ALL groups; then one wait; pass 2 stores.
+            // (d) expansion: each lane takes 4 consecutive outputs of every 256-output group; every
+            // source is an LDS byte address by now
             const uint32_t obyte = 4 * (produced + done);  // byte offset of the batch in the segment's output
             uint32_t x[kGroups][4];
             static_assert(kCap == kGroups * 4 * kWave, "one round per batch");
@@ -490,39 +600,17 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
                     r[2] = base + uint32_t(__builtin_popcount(nib & 7u));
                     r[3] = base + uint32_t(__builtin_popcount(nib & 15u));
                     const uint32_t pos4 = g * 16 * kWave + 16 * lane;  // byte position of this lane's first output
-                    uint32_t ad[4];
 #pragma unroll
                     for (int k = 0; k != 4; ++k) {
-                        ad[k] = *reinterpret_cast<const uint32_t*>(delta + 4 * r[k]) + pos4 + 4 * k;
-                        // cold / literal sources are far out of LDS range: such reads return nothing used
-                        x[g][k] = *reinterpret_cast<const uint32_t*>(lds_bytes + ad[k]);
+                        const uint32_t ad = *reinterpret_cast<const uint32_t*>(delta + 4 * r[k]) + pos4 + 4 * k;
+                        x[g][k] = *reinterpret_cast<const uint32_t*>(lds_bytes + ad);
                     }
-                    asm volatile("" : "+v"(x[g][0]), "+v"(x[g][1]), "+v"(x[g][2]), "+v"(x[g][3]));
-                    if (tile_exc) {
-#pragma unroll
-                        for (int k = 0; k != 4; ++k) {
-                            if (ad[k] == kLitAddr4)
-                                x[g][k] = *reinterpret_cast<const uint32_t*>(delta + 4 * r[k] + kLitOff);
-                        }
-                    }
-#ifndef DINT_EXP_NOCOLD
-                    if (batch_cold) {
-#pragma unroll
-                        for (int k = 0; k != 4; ++k) {
-                            if (ad[k] >= kColdBase4 && ad[k] != kLitAddr4)
-                                x[g][k] = __builtin_amdgcn_raw_buffer_load_b32(rs_table, ad[k] - kColdBase4, 0, 0);
-                        }
-                    }
-#endif
                 }
             }
-            STAMP(4);  // expansion LDS chains, cold gathers issued
+            STAMP(4);  // expansion LDS chains
             // the prefetched registers must have landed before the first store is issued
             asm volatile("" ::"v"(raw3), "v"(nxt.m[0]), "v"(nxt.m[1]), "v"(nxt.m[2]), "v"(nxt.m[3]));
-#ifdef DINT_STAMPS
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-            STAMP(5);  // cold gathers + prefetch returned
+            STAMP(5);
 #pragma unroll
             for (uint32_t g = 0; g != kGroups; ++g) {
                 if (g * 4 * kWave < bt) {
@@ -550,7 +638,9 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
             wave_lds_fence();
             done = bend;
             rdone = rend;
-        }
+            qdone = qend;
+            wdone = wend;
+        } while (done < total);
 
         produced += total;
         carry = carry_out;
@@ -602,8 +692,8 @@ __device__ __forceinline__ void decode_unit_multi(const decode_args& a, const ui
         dict_desc dd;
         dd.meta_base = uniform(a.dict.descs[d].meta_base);
         dd.hot_base = uniform(a.dict.descs[d].hot_base);
-        dd.remap_base = uniform(a.dict.descs[d].remap_base);
-        dd.remap_limit = uniform(a.dict.descs[d].remap_limit);
+        dd.hot_k = uniform(a.dict.descs[d].hot_k);
+        dd.pad = 0;
         uint32_t* const out = a.out + out_off + done;
         if (narrow) pos = decode_segment<8>(a, lds, cls, scratch, dd, pos + 1, bsize, out, lane);
         else pos = decode_segment<16>(a, lds, cls, scratch, dd, pos + 1, bsize, out, lane);

@@ -20,8 +20,7 @@ _LIB_PATH = os.environ.get("DINT_HIP_LIB") or os.path.join(_HERE, "libdint_hip.s
 #: every symbol include/dint_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
     "dint_abi_version", "dint_strerror", "dint_last_hip_error", "dint_device_count",
-    "dint_dict_create", "dint_dict_destroy", "dint_dict_info_get", "dint_dict_tune", "dint_index_stream",
-    "dint_free",
+    "dint_dict_create", "dint_dict_destroy", "dint_dict_info_get", "dint_index_stream", "dint_free",
     "dint_decode_units", "dint_decode_list_host", "dint_last_kernel_ms",
     "dint_index_posting_lists", "dint_decode_posting_blocks",
     "dint_query_index_create", "dint_query_index_destroy", "dint_and_queries",
@@ -58,7 +57,6 @@ def _load():
     lib.dint_dict_destroy.restype = None
     lib.dint_dict_destroy.argtypes = [vp]
     lib.dint_dict_info_get.argtypes = [vp, C.POINTER(DictInfo)]
-    lib.dint_dict_tune.argtypes = [vp, vp, sz]
     lib.dint_index_stream.argtypes = [vp, vp, sz, u32, C.POINTER(vp), C.POINTER(sz), C.POINTER(u64),
                                       C.POINTER(u64)]
     lib.dint_free.restype = None
@@ -128,15 +126,6 @@ class Dictionary:
         info = DictInfo()
         _check(_lib.dint_dict_info_get(self._h, C.byref(info)), "dint_dict_info_get")
         return info
-
-    def tune(self, usage: np.ndarray | None = None) -> None:
-        """Keep the most used codewords in LDS: `usage` counts per meta slot, or (None) the counts
-        index_stream has collected on this dictionary. Results are unaffected."""
-        if usage is None:
-            _check(_lib.dint_dict_tune(self._h, None, 0), "dint_dict_tune")
-        else:
-            u = np.ascontiguousarray(usage, dtype=np.uint64)
-            _check(_lib.dint_dict_tune(self._h, u.ctypes.data, u.size), "dint_dict_tune")
 
     # -- H3: sidecar ---------------------------------------------------------
     def index_stream(self, enc: np.ndarray, unit_ints: int = 4096):

@@ -84,22 +84,12 @@ int dint_dict_create(int kind, const void* file_bytes, size_t len, int device, d
 void dint_dict_destroy(dint_dict* dict);
 int dint_dict_info_get(const dint_dict* dict, dint_dict_info* info);
 
-/* Optional: choose which codewords sit in LDS by how often they are USED rather than by their
- * position in the file. usage[slot] = number of uses of meta slot `slot` (single: the codeword
- * index; multi: dictionary d's codeword i at start[d] + i), n_counts = number of slots of the
- * file; usage == NULL takes the counts dint_index_stream has collected on this dictionary so
- * far. Results never change, only which lookups stay on chip. Synchronises the device; must not
- * race with decodes on this dictionary. (No reference counterpart: the CPU decoder keeps the
- * whole table in cache-backed memory, include/dint/dictionary_types.hpp.) */
-int dint_dict_tune(dint_dict* dict, const uint64_t* usage, size_t n_counts);
-
 /* Untimed host pre-pass over a whole vroom stream in host memory: reads every
  * list header, walks the codewords WITHOUT copying dictionary payloads, and
  * cuts each list into units of about `unit_ints` integers at codeword
  * boundaries (multi: at 256-integer block boundaries).
  * Replaces: the per-list framing loop of vroom_env/decode.cpp:139-150.
- * `*units` is malloc'ed; release with dint_free. As a side effect the walk counts the uses of
- * every codeword on `dict` (see dint_dict_tune). */
+ * `*units` is malloc'ed; release with dint_free. */
 int dint_index_stream(const dint_dict* dict, const uint8_t* enc, size_t enc_bytes,
                       uint32_t unit_ints, dint_unit** units, size_t* n_units,
                       uint64_t* total_ints, uint64_t* n_lists);

@@ -172,37 +172,3 @@ def test_multi_blocks_use_both_codeword_widths(small_corpus):
     enc, units = small_corpus.encoded(host.MULTI_PACKED)
     sels = enc[units["in_off"].astype(np.int64)]
     assert (sels < 6).any() and (sels >= 6).any() and (sels < 12).all()
-
-
-@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.RECTANGULAR, host.MULTI_PACKED])
-def test_usage_tuned_hot_set_changes_nothing_but_residency(device, small_corpus, kind):
-    """dint_dict_tune re-picks the LDS-resident codewords by use count: same integers out."""
-    enc, _ = small_corpus.encoded(kind)
-    d = device.Dictionary(kind, small_corpus.dict_file(kind))
-    units, total, _ = d.index_stream(enc, 1024)  # also collects the usage counts
-    before = device.decode_stream(d, enc, units, total)[0]
-    hot_before = d.info().hot_entries
-    d.tune()
-    assert d.info().hot_entries > 0
-    after = device.decode_stream(d, enc, units, total)[0]
-    assert np.array_equal(before, small_corpus.coll.gaps) and np.array_equal(after, before)
-    # explicit counts: everything cold but the run codewords, then a single hot codeword
-    n_slots = _meta_slots(kind, small_corpus.dict_file(kind))
-    usage = np.zeros(n_slots, dtype=np.uint64)
-    d.tune(usage)
-    assert np.array_equal(device.decode_stream(d, enc, units, total)[0], before)
-    usage[n_slots // 3] = 5
-    d.tune(usage)
-    assert np.array_equal(device.decode_stream(d, enc, units, total)[0], before)
-    with pytest.raises(device.DintError):
-        d.tune(usage[:-1])
-    assert hot_before > 0
-
-
-def _meta_slots(kind, dict_file):
-    w = np.frombuffer(dict_file[:16], dtype=np.uint32)
-    if kind == host.RECTANGULAR:
-        return 65536
-    if kind == host.SINGLE_PACKED:
-        return max(int(w[1]), 65536)
-    return int(w[2])

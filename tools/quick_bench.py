@@ -30,14 +30,6 @@ def runs(tag, n=5):
         ms = d.last_kernel_ms()
         gb = (coll.num_postings * 4 + enc.size) / 1e9
         print(f"{tag} run {i}: {ms:.3f} ms  {coll.num_postings / ms / 1e6:.2f} G ints/s  {gb / ms * 1e3:.1f} GB/s algorithmic", flush=True)
-runs("prefix hot set")
-ok0 = np.array_equal(out_dev.cpu().numpy().view(np.uint32), coll.gaps)
-t = time.time()
-d.index_stream(enc, unit_ints)
-print("index_stream (usage counts)", round(time.time() - t, 1), "s")
-d.tune()
-print("tuned: hot entries", d.info().hot_entries, "lds bytes", d.info().lds_bytes)
-out_dev.zero_()
-runs("usage hot set")
+runs("decode")
 ok = np.array_equal(out_dev.cpu().numpy().view(np.uint32), coll.gaps)
-print("bit-exact vs encoder input:", ok0, ok)
+print("bit-exact vs encoder input:", ok)
