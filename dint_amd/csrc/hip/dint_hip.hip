@@ -941,16 +941,6 @@ int dint_decode_list_host(const dint_dict* dd, const uint8_t* in, size_t in_byte
     return st;
 }
 
-#ifdef DINT_STAMPS
-// Diagnostic build only: read and clear the per-phase wave-cycle sums.
-int dint_debug_read_stamps(unsigned long long* out16) {
-    HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(dint_dev::g_stamps), 16 * sizeof(unsigned long long)));
-    unsigned long long zeros[16] = {};
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(dint_dev::g_stamps), zeros, sizeof zeros));
-    return DINT_OK;
-}
-#endif
-
 // Test hook (not part of the decode ABI): inclusive wave prefix sum of 64 host words.
 int dint_debug_wave_scan(const uint32_t* in64, uint32_t* out64) {
     if (!in64 || !out64) return DINT_ERR_ARG;

@@ -55,13 +55,17 @@ constexpr uint32_t kBlocksPerCU = DINT_BLOCKS_PER_CU;
 constexpr uint32_t kLdsWords = 160 * 1024 / 4 / kBlocksPerCU;
 constexpr uint32_t kSPL = 4;                          // slots per lane per tile
 constexpr uint32_t kTileSlots = kWave * kSPL;         // 256 slots per tile
-constexpr uint32_t kGroups = 4;                       // 256-output groups expanded together
-constexpr uint32_t kCap = kGroups * 256;              // outputs per expansion batch (>= kSPL * 256)
+constexpr uint32_t kGroups = 4;                       // 256-output groups expanded together (one round)
+constexpr uint32_t kRounds = 2;                       // rounds per batch (single-dictionary segments)
+constexpr uint32_t kMaxCap = 2048;                    // outputs per expansion batch at most: the flag bitmap's bits
 // per wave: 64 {flag word, rank base} pairs (+ spare), per-codeword delta table (+ 4 dummy
 // entries for codewords that are not live in a batch), staging cells
 constexpr uint32_t kFwWords = 2 * 64 + 4;              // 64 pairs: flag positions are taken mod 2048
 constexpr uint32_t kDeltaWords = kTileSlots + 4;
-constexpr uint32_t kStageQuads = 128;                  // 16-byte cells: cold payloads and exception literals of a batch
+#ifndef DINT_STAGE_QUADS
+#define DINT_STAGE_QUADS 128
+#endif
+constexpr uint32_t kStageQuads = DINT_STAGE_QUADS;     // 16-byte cells: cold payloads and exception literals of a batch
 constexpr uint32_t kStageWords = 4 * kStageQuads;      // (its first half doubles as the fetch worklist)
 constexpr uint32_t kScratchWords = kFwWords + kDeltaWords + kStageWords;
 constexpr uint32_t kClassTableWords = 328;            // slot classification table: 648 u16 rows, padded
@@ -226,26 +230,21 @@ __device__ __forceinline__ void build_class_table(uint16_t* table) {
     }
 }
 
-#ifdef DINT_STAMPS
-// Diagnostic build only: wave-cycles per phase, summed over all waves (never in the shipped kernel).
-__device__ unsigned long long g_stamps[16];
-#define STAMP(i)                                                  \
-    do {                                                          \
-        __builtin_amdgcn_sched_barrier(0);                        \
-        const uint64_t now_ = __builtin_amdgcn_s_memtime();       \
-        __builtin_amdgcn_s_waitcnt(0xC07F);                       \
-        tacc[i] += now_ - tprev;                                  \
-        tprev = now_;                                             \
-        __builtin_amdgcn_sched_barrier(0);                        \
-    } while (0)
+// Section marks for tools/isa_count.py (comments in the assembly under -DDINT_MARKS; nothing otherwise).
+#ifdef DINT_MARKS
+#define MARK(name) asm volatile("; MARK " name)
 #else
-#define STAMP(i) do {} while (0)
+#define MARK(name) do {} while (0)
 #endif
 
-template <int W>
+// ROUNDS x GROUPS x 256 = outputs per expansion batch: 2 x 4 for the long single-dictionary
+// segments; a multi-dictionary segment is one block of at most 256 integers, 1 x 1.
+template <int W, uint32_t ROUNDS, uint32_t GROUPS>
 __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const uint32_t* lds, const uint16_t* cls,
                                                    uint32_t* scratch, const dict_desc& dd, uint64_t in_off,
                                                    uint32_t n, uint32_t* const out, uint32_t lane) {
+    constexpr uint32_t kCap = ROUNDS * GROUPS * 256;
+    static_assert(kCap <= kMaxCap, "the flag bitmap holds 2048 positions");
     constexpr uint32_t kSlotBytes = W / 8;
     constexpr uint32_t kTileBytes = kTileSlots * kSlotBytes;
     // per-wave scratch (byte offsets): {flag word, rank base} pairs | delta table | staging cells
@@ -267,19 +266,22 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
                                                         uniform(uint32_t(out_bits)));
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out_u, 0, int(uniform(n) * 4), 0x00020000);
 
-    auto meta_of = [&](uint32_t v) -> uint32_t {
-        // LDS for the hot codewords (unconditional read: cold lanes read word 0), L2 for the cold
-        // ones under their exec mask: two address spaces, never a pointer select (that would
-        // become one slow flat load)
-        const bool hot = v < hot_k;
-        uint32_t m = lds[hot ? dd.hot_base + v : 0u];
-        asm volatile("" : "+v"(m));  // keep the DS read a DS read
+    // Metadata of the four slots of a lane: LDS for the hot codewords (unconditional reads, all four
+    // in flight together: cold lanes read word 0), then L2 for the cold ones under their exec mask.
+    // Two address spaces, never a pointer select (that would become one slow flat load).
+    auto load_metas = [&](tile_regs& t) {
+#pragma unroll
+        for (uint32_t k = 0; k != kSPL; ++k) t.m[k] = lds[t.s[k] < hot_k ? dd.hot_base + t.s[k] : 0u];
+        asm volatile("" : "+v"(t.m[0]), "+v"(t.m[1]), "+v"(t.m[2]), "+v"(t.m[3]));  // keep the DS reads DS reads
+#pragma unroll
+        for (uint32_t k = 0; k != kSPL; ++k) {
 #ifdef DINT_EXP_NOMETA  // timing experiment: no L2 metadata reads (results are wrong)
-        if (!hot) m = (lds[dd.hot_base + 7u + (v & 1023u)] & 0xFF000000u) | kColdBase | (v & 0xFFFFu);
+            if (t.s[k] >= hot_k)
+                t.m[k] = (lds[dd.hot_base + 7u + (t.s[k] & 1023u)] & 0xFF000000u) | kColdBase | (t.s[k] & 0xFFFFu);
 #else
-        if (!hot) m = __builtin_amdgcn_raw_buffer_load_b32(rs_meta, 4 * (dd.meta_base + v), 0, 0);
+            if (t.s[k] >= hot_k) t.m[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_meta, 4 * (dd.meta_base + t.s[k]), 0, 0);
 #endif
-        return m;
+        }
     };
 
     // pipeline: tile t in `cur` (slots + metadata), tile t+1 in `nxt`, tile t+2's slots in flight
@@ -291,8 +293,7 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
     uint64_t raw1 = load_lane_slots<W>(a.enc, slot_byte, lane, a.enc_bytes);
     slot_byte += kTileBytes;
     uint64_t raw2 = load_lane_slots<W>(a.enc, slot_byte, lane, a.enc_bytes);
-#pragma unroll
-    for (uint32_t k = 0; k != kSPL; ++k) cur.m[k] = meta_of(cur.s[k]);
+    load_metas(cur);
     // Everything loaded so far has landed before the loop is entered: inside it, a wait may only
     // ever sit right before a tile's stores (see the prefetch note below), never after them.
     asm volatile("" ::"v"(raw1), "v"(raw2), "v"(cur.m[0]), "v"(cur.m[1]), "v"(cur.m[2]), "v"(cur.m[3]));
@@ -306,16 +307,65 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
     uint32_t carry = 0;            // payload slots an exception of the previous tile still owns
     uint64_t tile_base = in_off;   // byte offset of slot 0 of the current tile
     uint32_t end_slot = 0;
-#ifdef DINT_STAMPS
-    uint64_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t tprev = __builtin_amdgcn_s_memtime();
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-#endif
-    STAMP(7);  // segment prologue (unit descriptor, first slot + metadata loads)
+    MARK("loop_top");
 
     while (produced < n) {
         const uint32_t next_lo = uint32_t(raw1);  // first slots of the next tile (exception spill)
 
+        // Perturbation experiments (timing only): which resource does the kernel sit on? Pad every tile
+        // with N independent instructions of one class and watch the time.
+#ifdef DINT_EXP_PAD_VALU
+        {
+            uint32_t pad = lane;
+#pragma unroll
+            for (int i = 0; i != DINT_EXP_PAD_VALU; ++i) asm volatile("v_add_u32 %0, %0, 1" : "+v"(pad));
+            asm volatile("" ::"v"(pad));
+        }
+#endif
+#ifdef DINT_EXP_PAD_SALU
+        {
+            uint32_t pad = 0;
+#pragma unroll
+            for (int i = 0; i != DINT_EXP_PAD_SALU; ++i) asm volatile("s_add_u32 %0, %0, 1" : "+s"(pad));
+            asm volatile("" ::"s"(pad));
+        }
+#endif
+#ifdef DINT_EXP_PAD_LDS
+        {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int i = 0; i != DINT_EXP_PAD_LDS; ++i) {
+                uint32_t v = lds[(lane * 33u + i * 67u) & 1023u];
+                asm volatile("" : "+v"(v));
+                acc += v;
+            }
+            asm volatile("" ::"v"(acc));
+        }
+#endif
+#ifdef DINT_EXP_PAD_LDS_IND  // independent reads: LDS throughput, hardly any latency
+        {
+            uint32_t v[DINT_EXP_PAD_LDS_IND];
+#pragma unroll
+            for (int i = 0; i != DINT_EXP_PAD_LDS_IND; ++i) v[i] = lds[(lane * 33u + i * 67u) & 1023u];
+            uint32_t acc = 0;
+#pragma unroll
+            for (int i = 0; i != DINT_EXP_PAD_LDS_IND; ++i) { asm volatile("" : "+v"(v[i])); acc |= v[i]; }
+            asm volatile("" ::"v"(acc));
+        }
+#endif
+#ifdef DINT_EXP_PAD_LDS_IND128
+        {
+            u32x4 v[DINT_EXP_PAD_LDS_IND128];
+#pragma unroll
+            for (int i = 0; i != DINT_EXP_PAD_LDS_IND128; ++i)
+                v[i] = *reinterpret_cast<const u32x4*>(lds + ((lane * 4u + i * 260u) & 4095u));
+            uint32_t acc = 0;
+#pragma unroll
+            for (int i = 0; i != DINT_EXP_PAD_LDS_IND128; ++i) { asm volatile("" : "+v"(v[i])); acc |= v[i].x ^ v[i].w; }
+            asm volatile("" ::"v"(acc));
+        }
+#endif
+        MARK("1_classify");
         // ---- 1. classification: table lookup, repeated until the lane-to-lane carries agree ----
         uint32_t smin = cur.s[0];
 #pragma unroll
@@ -374,7 +424,7 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
             }
         }
 
-        STAMP(1);  // classification
+        MARK("2_sizes");
         // ---- 2. sizes, offsets, ordinals (sizes and sources in BYTES of output / payload) --------
         // live[k]: all ones when slot k is a codeword header that belongs to this segment
         uint32_t sz4[kSPL], src4[kSPL], live[kSPL], lord[kSPL], lit[kSPL];
@@ -453,24 +503,24 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
         uint32_t cexcl = 0;
         if (tile_staged) cexcl = wave_inclusive_sum(cl) - cl;
         const uint32_t qb = cexcl & 0xFFFFu, wb = cexcl >> 16;  // first cell / first fetch of this lane
-        STAMP(2);  // sizes, scans
+        MARK("3_prefetch");
         // ---- prefetch: metadata of tile t+1 (its slots are already here), slots of tile t+2. Issued
         // before this tile's cold fetches and stores; waited for together with the fetches, right
         // before the stores (vmcnt is one in-order counter for loads AND stores on gfx950: a wait
         // placed after the stores would also wait for their acknowledgements).
         unpack_slots<W>(raw1, nxt);
-#pragma unroll
-        for (uint32_t k = 0; k != kSPL; ++k) nxt.m[k] = meta_of(nxt.s[k]);
+        load_metas(nxt);
         slot_byte += kTileBytes;
         const uint64_t raw3 = load_lane_slots<W>(a.enc, slot_byte, lane, a.enc_bytes);
-        STAMP(0);
+        MARK("4_batch_select");
         // ---- 3./4. batches of <= kCap outputs and <= kStageQuads cells (normally one: the whole tile)
         // (a do-while: the compiler must see that the wait inside precedes the register rotation
         // below on every path, or it waits again there — after the stores, for their acknowledgements)
         uint32_t done = 0, rdone = 0, qdone = 0, wdone = 0;
         do {
             const bool inb = lsum != 0 && obase >= done && (obase + lsum - done) <= kCap &&
-                             (qb + (cl & 0xFFFFu) - qdone) <= kStageQuads;
+                             (qb + (cl & 0xFFFFu) - qdone) <= kStageQuads &&
+                             (kStageQuads <= 2 * kWave || (wb + (cl >> 16) - wdone) <= 2 * kWave);  // two fetches per lane
             const uint64_t bm = __ballot(inb);
             const uint32_t last = 63u - uint32_t(__builtin_clzll(bm | 1ull));
             const uint32_t bend = readlane(obase + lsum, last);
@@ -481,6 +531,7 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
             const uint32_t nfetch = wend - wdone;   // cold codewords to fetch, <= kStageQuads
             const uint32_t inbM = inb ? ~0u : 0u;
 
+            MARK("5_worklist");
             // (a) worklist of the cold codewords {table byte offset, cell | quads << 16}, then each
             // lane takes up to two of them and fetches their first two quads (sizes 1..8); the
             // fetches fly while the batch tables are built
@@ -495,27 +546,28 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
                     const uint32_t lv = live[k] & inbM;
                     const uint32_t cell = qb - qdone + (cpre[k] & 0xFFFFu);
                     if (lv != 0 && (pk[k] & 0xFFFFu) != 0) srcb[k] = stage_off + 16u * cell;
-                    if (lv != 0 && (pk[k] >> 16) != 0) {
-                        const u32x2 e = {src4[k] - kColdBase4, cell | (pk[k] << 16)};
-                        *reinterpret_cast<u32x2*>(stage + 8u * (wb - wdone + (cpre[k] >> 16))) = e;
-                    }
+                    // every slot writes an entry: the ones with nothing to fetch park it past the list
+                    const bool fetch = lv != 0 && (pk[k] >> 16) != 0;
+                    const u32x2 e = {src4[k] - kColdBase4, cell | (pk[k] << 16)};
+                    *reinterpret_cast<u32x2*>(stage + 8u * (fetch ? wb - wdone + (cpre[k] >> 16) : kStageQuads + k)) = e;
                 }
                 wave_lds_fence();
                 if (lane < nfetch) e0 = *reinterpret_cast<const u32x2*>(stage + 8u * lane);
-                if (lane + 64u < nfetch) e1 = *reinterpret_cast<const u32x2*>(stage + 8u * (lane + 64u));
+                if (nfetch > 64u && lane + 64u < nfetch) e1 = *reinterpret_cast<const u32x2*>(stage + 8u * (lane + 64u));
                 wave_lds_fence();
 #ifndef DINT_EXP_NOFETCH  // timing experiment: no cold payload reads (results are wrong)
                 if (lane < nfetch) {
                     q00 = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e0.x, 0, 0);
                     if (((e0.y >> 16) & 7u) > 1u) q01 = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e0.x + 16u, 0, 0);
                 }
-                if (lane + 64u < nfetch) {
+                if (nfetch > 64u && lane + 64u < nfetch) {
                     q10 = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e1.x, 0, 0);
                     if (((e1.y >> 16) & 7u) > 1u) q11 = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e1.x + 16u, 0, 0);
                 }
 #endif
             }
 
+            MARK("6_flags");
             // (b) flags and deltas. Every slot runs the same instructions: a codeword that is not
             // live in this batch ORs a zero into an in-range flag word and parks its delta in a dummy.
             *reinterpret_cast<uint32_t*>(fw + 8 * lane) = 0;  // clear all 64 flag words
@@ -538,7 +590,7 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
                 const uint32_t pi = wave_inclusive_sum(pc);
                 pair[1] = pi - pc - 1u;  // flags before this word, minus one
             }
-            STAMP(3);  // batch build: worklist, flags, deltas, rank bases
+            MARK("7_stage_write");
 
             // (c) the fetched quads and the exception literals go into their cells
             if (tile_staged) {
@@ -547,14 +599,14 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
                     *reinterpret_cast<u32x4*>(c) = q00;
                     if (((e0.y >> 16) & 7u) > 1u) *reinterpret_cast<u32x4*>(c + 16) = q01;
                 }
-                if (lane + 64u < nfetch) {
+                if (nfetch > 64u && lane + 64u < nfetch) {
                     uint8_t* const c = stage + 16u * (e1.y & 0xFFFFu);
                     *reinterpret_cast<u32x4*>(c) = q10;
                     if (((e1.y >> 16) & 7u) > 1u) *reinterpret_cast<u32x4*>(c + 16) = q11;
                 }
                 // size-16 cold codewords (rare): quads 2 and 3, fetched and waited for on the spot
                 const bool big0 = lane < nfetch && ((e0.y >> 16) & 7u) > 2u;
-                const bool big1 = lane + 64u < nfetch && ((e1.y >> 16) & 7u) > 2u;
+                const bool big1 = nfetch > 64u && lane + 64u < nfetch && ((e1.y >> 16) & 7u) > 2u;
 #ifdef DINT_EXP_NOFETCH
                 if (false) {
 #else
@@ -582,57 +634,54 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
             }
             wave_lds_fence();
 
-            // (d) expansion: each lane takes 4 consecutive outputs of every 256-output group; every
-            // source is an LDS byte address by now
-            const uint32_t obyte = 4 * (produced + done);  // byte offset of the batch in the segment's output
-            uint32_t x[kGroups][4];
-            static_assert(kCap == kGroups * 4 * kWave, "one round per batch");
+            MARK("8_expand");
+            // (d) expansion, GROUPS * 256 outputs per round: each lane takes 4 consecutive outputs of
+            // every 256-output group; every source is an LDS byte address by now. Stores are whole
+            // 16-byte quads: the descriptor clips what lies past the segment's n integers (range
+            // checking is per dword), and what a quad writes past this batch's end inside the segment
+            // is rewritten by the batches and tiles that follow (same wave, program order).
 #pragma unroll
-            for (uint32_t g = 0; g != kGroups; ++g) {
-                if (g * 4 * kWave < bt) {  // wave-uniform
-                    const u32x2 pr = *reinterpret_cast<const u32x2*>(fw + g * 64 + pair_byte);
-                    const uint32_t w = pr.x;
-                    const uint32_t base = pr.y + uint32_t(__builtin_popcount(w & below));
-                    const uint32_t nib = w >> sh;
-                    uint32_t r[4];
-                    r[0] = base + (nib & 1u);
-                    r[1] = base + uint32_t(__builtin_popcount(nib & 3u));
-                    r[2] = base + uint32_t(__builtin_popcount(nib & 7u));
-                    r[3] = base + uint32_t(__builtin_popcount(nib & 15u));
-                    const uint32_t pos4 = g * 16 * kWave + 16 * lane;  // byte position of this lane's first output
+            for (uint32_t rd = 0; rd != ROUNDS; ++rd) {
+                if (rd * GROUPS * 4 * kWave < bt) {  // wave-uniform
+                    const uint32_t obyte = 4 * (produced + done) + rd * GROUPS * 16 * kWave;  // output byte offset of the round
+                    uint32_t x[GROUPS][4];
 #pragma unroll
-                    for (int k = 0; k != 4; ++k) {
-                        const uint32_t ad = *reinterpret_cast<const uint32_t*>(delta + 4 * r[k]) + pos4 + 4 * k;
-                        x[g][k] = *reinterpret_cast<const uint32_t*>(lds_bytes + ad);
-                    }
-                }
-            }
-            STAMP(4);  // expansion LDS chains
-            // the prefetched registers must have landed before the first store is issued
-            asm volatile("" ::"v"(raw3), "v"(nxt.m[0]), "v"(nxt.m[1]), "v"(nxt.m[2]), "v"(nxt.m[3]));
-            STAMP(5);
+                    for (uint32_t g = 0; g != GROUPS; ++g) {
+                        if ((rd * GROUPS + g) * 4 * kWave < bt) {  // wave-uniform
+                            const u32x2 pr = *reinterpret_cast<const u32x2*>(fw + (rd * GROUPS + g) * 64 + pair_byte);
+                            const uint32_t w = pr.x;
+                            const uint32_t base = pr.y + uint32_t(__builtin_popcount(w & below));
+                            const uint32_t nib = w >> sh;
+                            uint32_t r[4];
+                            r[0] = base + (nib & 1u);
+                            r[1] = base + uint32_t(__builtin_popcount(nib & 3u));
+                            r[2] = base + uint32_t(__builtin_popcount(nib & 7u));
+                            r[3] = base + uint32_t(__builtin_popcount(nib & 15u));
+                            const uint32_t pos4 = (rd * GROUPS + g) * 16 * kWave + 16 * lane;  // byte position in the batch
 #pragma unroll
-            for (uint32_t g = 0; g != kGroups; ++g) {
-                if (g * 4 * kWave < bt) {
-                    const uint32_t pos4 = g * 16 * kWave + 16 * lane;
-#ifdef DINT_EXP_NOSTORE
-                    if (x[g][0] == 0xDEADBEEFu && x[g][1] == 0x12345u) out[g] = x[g][2] + x[g][3];
-#else
-                    if ((g + 1) * 4 * kWave <= bt) {  // wave-uniform: a full group
-                        const u32x4 xv = {x[g][0], x[g][1], x[g][2], x[g][3]};
-                        __builtin_amdgcn_raw_buffer_store_b128(xv, rs_out, pos4, obyte, 0);
-                    } else {
-                        const uint32_t p0 = g * 4 * kWave + 4 * lane;
-                        if (p0 + 4 <= bt) {
-                            const u32x4 xv = {x[g][0], x[g][1], x[g][2], x[g][3]};
-                            __builtin_amdgcn_raw_buffer_store_b128(xv, rs_out, pos4, obyte, 0);
-                        } else if (p0 < bt) {
-                            __builtin_amdgcn_raw_buffer_store_b32(x[g][0], rs_out, pos4, obyte, 0);
-                            if (p0 + 1 < bt) __builtin_amdgcn_raw_buffer_store_b32(x[g][1], rs_out, pos4 + 4, obyte, 0);
-                            if (p0 + 2 < bt) __builtin_amdgcn_raw_buffer_store_b32(x[g][2], rs_out, pos4 + 8, obyte, 0);
+                            for (int k = 0; k != 4; ++k) {
+                                const uint32_t ad = *reinterpret_cast<const uint32_t*>(delta + 4 * r[k]) + pos4 + 4 * k;
+                                x[g][k] = *reinterpret_cast<const uint32_t*>(lds_bytes + ad);
+                            }
                         }
                     }
+                    MARK("9_stores");
+                    // the prefetched registers must have landed before the first store is issued
+                    if (rd == 0) asm volatile("" ::"v"(raw3), "v"(nxt.m[0]), "v"(nxt.m[1]), "v"(nxt.m[2]), "v"(nxt.m[3]));
+#pragma unroll
+                    for (uint32_t g = 0; g != GROUPS; ++g) {
+                        const uint32_t p0 = (rd * GROUPS + g) * 4 * kWave + 4 * lane;
+                        if ((rd * GROUPS + g) * 4 * kWave < bt) {  // wave-uniform
+#ifdef DINT_EXP_NOSTORE
+                            if (x[g][0] == 0xDEADBEEFu && x[g][1] == 0x12345u) out[g] = x[g][2] + x[g][3];
+#else
+                            if (p0 < bt) {
+                                const u32x4 xv = {x[g][0], x[g][1], x[g][2], x[g][3]};
+                                __builtin_amdgcn_raw_buffer_store_b128(xv, rs_out, 16 * g * kWave + 16 * lane, obyte, 0);
+                            }
 #endif
+                        }
+                    }
                 }
             }
             wave_lds_fence();
@@ -642,6 +691,7 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
             wdone = wend;
         } while (done < total);
 
+        MARK("10_rotate");
         produced += total;
         carry = carry_out;
         if (produced < n) tile_base += kTileBytes;
@@ -650,13 +700,8 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
         cur = nxt;
         raw1 = raw2;
         raw2 = raw3;
-        STAMP(6);  // store issue, rotate
     }
-#ifdef DINT_STAMPS
-    if (lane == 0) {
-        for (int i = 0; i != 8; ++i) atomicAdd(&g_stamps[i], (unsigned long long)tacc[i]);
-    }
-#endif
+    MARK("epilogue");
     return tile_base + uint64_t(kSlotBytes) * end_slot;
 }
 
@@ -668,7 +713,7 @@ __device__ __forceinline__ void decode_unit_single(const decode_args& a, const u
     const uint64_t out_off = up->out_off;
     const uint32_t n = up->n;
     if (n == 0 || out_off + n > a.out_capacity || (a.only_full && n != 256)) return;
-    const uint64_t end = decode_segment<16>(a, lds, cls, scratch, a.dict.first, up->in_off, n, a.out + out_off, lane);
+    const uint64_t end = decode_segment<16, kRounds, kGroups>(a, lds, cls, scratch, a.dict.first, up->in_off, n, a.out + out_off, lane);
     if (a.end_off && lane == 0) a.end_off[unit_index] = end;
 }
 
@@ -695,8 +740,8 @@ __device__ __forceinline__ void decode_unit_multi(const decode_args& a, const ui
         dd.hot_k = uniform(a.dict.descs[d].hot_k);
         dd.pad = 0;
         uint32_t* const out = a.out + out_off + done;
-        if (narrow) pos = decode_segment<8>(a, lds, cls, scratch, dd, pos + 1, bsize, out, lane);
-        else pos = decode_segment<16>(a, lds, cls, scratch, dd, pos + 1, bsize, out, lane);
+        if (narrow) pos = decode_segment<8, 1, 1>(a, lds, cls, scratch, dd, pos + 1, bsize, out, lane);
+        else pos = decode_segment<16, 1, 1>(a, lds, cls, scratch, dd, pos + 1, bsize, out, lane);
         done += bsize;
     }
     if (a.end_off && lane == 0) a.end_off[unit_index] = pos;
