@@ -115,6 +115,9 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 struct __attribute__((packed, aligned(4))) u32x4_a4 {
     u32x4 v;
 };
+struct __attribute__((packed, aligned(1))) u32x4_a1 {
+    u32x4 v;
+};
 struct __attribute__((packed, aligned(1))) u32x2_a1 {
     u32x2 v;
 };
@@ -237,12 +240,48 @@ __device__ __forceinline__ void build_class_table(uint16_t* table) {
 #define MARK(name) do {} while (0)
 #endif
 
+// Segment chaining (multi-dictionary units): a block's bytes are known only when the previous block
+// has been parsed, so a block on its own pays the full memory latency of its selector and its slots
+// before it can start. Chained, the first kChainBytes of the next block (16 per lane, from the byte
+// after its selector on) and its selector are requested as soon as the current block's end is known
+// — after the scans, before its expansion and stores — and are re-laid-out lane to lane
+// (ds_bpermute) into the first two tiles of the next segment.
+constexpr uint32_t kChainBytes = 16 * kWave;
+struct chain_io {
+    u32x4 data;     // bytes [16 * lane, 16 * lane + 16) of the segment's slot stream
+    uint32_t sel;   // the byte before them (the block's selector) in bits 0-7
+    bool more;      // in: a block follows this one
+    bool valid;     // out: data / sel hold the next block's bytes
+};
+
+__device__ __forceinline__ void chain_request(const uint8_t* enc, uint64_t selector_byte, uint32_t lane, chain_io& ch) {
+    ch.sel = enc[selector_byte];
+    ch.data = reinterpret_cast<const u32x4_a1*>(enc + selector_byte + 1 + 16u * lane)->v;
+    ch.valid = true;
+}
+
+// slots of tile t (0 or 1) of a chained segment, in the lane layout load_lane_slots produces
+template <int W>
+__device__ __forceinline__ uint64_t chain_tile(const u32x4& d, uint32_t t, uint32_t lane) {
+    if (W == 16) {  // lane l: bytes [512 t + 8 l, + 8) = half (l & 1) of lane 32 t + l / 2
+        const int src = int(32 * t + (lane >> 1));
+        const uint32_t x = __shfl(d.x, src), y = __shfl(d.y, src), z = __shfl(d.z, src), w = __shfl(d.w, src);
+        const bool hi = (lane & 1u) != 0;
+        return (uint64_t(hi ? w : y) << 32) | (hi ? z : x);
+    }
+    // lane l: bytes [256 t + 4 l, + 4) = dword (l & 3) of lane 16 t + l / 4
+    const int src = int(16 * t + (lane >> 2));
+    const uint32_t x = __shfl(d.x, src), y = __shfl(d.y, src), z = __shfl(d.z, src), w = __shfl(d.w, src);
+    const uint32_t c = lane & 3u;
+    return c == 0 ? x : c == 1 ? y : c == 2 ? z : w;
+}
+
 // ROUNDS x GROUPS x 256 = outputs per expansion batch: 2 x 4 for the long single-dictionary
 // segments; a multi-dictionary segment is one block of at most 256 integers, 1 x 1.
-template <int W, uint32_t ROUNDS, uint32_t GROUPS>
+template <int W, uint32_t ROUNDS, uint32_t GROUPS, bool CHAINED>
 __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const uint32_t* lds, const uint16_t* cls,
                                                    uint32_t* scratch, const dict_desc& dd, uint64_t in_off,
-                                                   uint32_t n, uint32_t* const out, uint32_t lane) {
+                                                   uint32_t n, uint32_t* const out, uint32_t lane, chain_io& ch) {
     constexpr uint32_t kCap = ROUNDS * GROUPS * 256;
     static_assert(kCap <= kMaxCap, "the flag bitmap holds 2048 positions");
     constexpr uint32_t kSlotBytes = W / 8;
@@ -288,11 +327,19 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
     const uint64_t in_off_u = (uint64_t(uniform(uint32_t(in_off >> 32))) << 32) | uniform(uint32_t(in_off));
     uint64_t slot_byte = in_off_u;  // first byte of the tile whose slots are loaded next (wave-uniform)
     tile_regs cur, nxt;
-    unpack_slots<W>(load_lane_slots<W>(a.enc, slot_byte, lane, a.enc_bytes), cur);
-    slot_byte += kTileBytes;
-    uint64_t raw1 = load_lane_slots<W>(a.enc, slot_byte, lane, a.enc_bytes);
-    slot_byte += kTileBytes;
-    uint64_t raw2 = load_lane_slots<W>(a.enc, slot_byte, lane, a.enc_bytes);
+    uint64_t raw1, raw2 = 0;
+    if (CHAINED) {  // tiles 0 and 1 arrived with the previous block (or were requested by the caller)
+        unpack_slots<W>(chain_tile<W>(ch.data, 0, lane), cur);
+        raw1 = chain_tile<W>(ch.data, 1, lane);
+        slot_byte += kTileBytes;  // the pipeline is one tile shorter: tile t+2's slots are requested in tile t
+    } else {
+        unpack_slots<W>(load_lane_slots<W>(a.enc, slot_byte, lane, a.enc_bytes), cur);
+        slot_byte += kTileBytes;
+        raw1 = load_lane_slots<W>(a.enc, slot_byte, lane, a.enc_bytes);
+        slot_byte += kTileBytes;
+        raw2 = load_lane_slots<W>(a.enc, slot_byte, lane, a.enc_bytes);
+    }
+    ch.valid = false;
     load_metas(cur);
     // Everything loaded so far has landed before the loop is entered: inside it, a wait may only
     // ever sit right before a tile's stores (see the prefetch note below), never after them.
@@ -465,7 +512,8 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
         const uint32_t remaining = n - produced;
         uint32_t total = readlane(pincl, 63) & 0xFFFFFFu;
         uint32_t nlive = hdrcnt;
-        if (total >= remaining) {  // last tile of the segment: clamp, and find where the stream ends
+        const bool last_tile = total >= remaining;
+        if (last_tile) {  // last tile of the segment: clamp, and find where the stream ends
             total = remaining;
             uint32_t cand = 0;
             nlive = 0;
@@ -508,10 +556,21 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
         // before this tile's cold fetches and stores; waited for together with the fetches, right
         // before the stores (vmcnt is one in-order counter for loads AND stores on gfx950: a wait
         // placed after the stores would also wait for their acknowledgements).
-        unpack_slots<W>(raw1, nxt);
-        load_metas(nxt);
-        slot_byte += kTileBytes;
-        const uint64_t raw3 = load_lane_slots<W>(a.enc, slot_byte, lane, a.enc_bytes);
+        // The last tile of a segment has no successor to prefetch; a chained one asks for the next block.
+        uint64_t raw3 = 0;
+        if (!last_tile) {
+            unpack_slots<W>(raw1, nxt);
+            load_metas(nxt);
+            slot_byte += kTileBytes;
+            raw3 = load_lane_slots<W>(a.enc, slot_byte, lane, a.enc_bytes);
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k != kSPL; ++k) nxt.s[k] = nxt.m[k] = 0;
+            if (CHAINED) {
+                const uint64_t end_byte = tile_base + uint64_t(kSlotBytes) * end_slot;
+                if (ch.more && end_byte + 1 + kChainBytes <= a.enc_bytes) chain_request(a.enc, end_byte, lane, ch);
+            }
+        }
         MARK("4_batch_select");
         // ---- 3./4. batches of <= kCap outputs and <= kStageQuads cells (normally one: the whole tile)
         // (a do-while: the compiler must see that the wait inside precedes the register rotation
@@ -667,7 +726,10 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
                     }
                     MARK("9_stores");
                     // the prefetched registers must have landed before the first store is issued
-                    if (rd == 0) asm volatile("" ::"v"(raw3), "v"(nxt.m[0]), "v"(nxt.m[1]), "v"(nxt.m[2]), "v"(nxt.m[3]));
+                    if (rd == 0) {
+                        asm volatile("" ::"v"(raw3), "v"(nxt.m[0]), "v"(nxt.m[1]), "v"(nxt.m[2]), "v"(nxt.m[3]));
+                        if (CHAINED) asm volatile("" ::"v"(ch.sel), "v"(ch.data.x), "v"(ch.data.y), "v"(ch.data.z), "v"(ch.data.w));
+                    }
 #pragma unroll
                     for (uint32_t g = 0; g != GROUPS; ++g) {
                         const uint32_t p0 = (rd * GROUPS + g) * 4 * kWave + 4 * lane;
@@ -698,7 +760,7 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
 
         // ---- rotate the pipeline ---------------------------------------------------
         cur = nxt;
-        raw1 = raw2;
+        raw1 = CHAINED ? raw3 : raw2;
         raw2 = raw3;
     }
     MARK("epilogue");
@@ -713,7 +775,9 @@ __device__ __forceinline__ void decode_unit_single(const decode_args& a, const u
     const uint64_t out_off = up->out_off;
     const uint32_t n = up->n;
     if (n == 0 || out_off + n > a.out_capacity || (a.only_full && n != 256)) return;
-    const uint64_t end = decode_segment<16, kRounds, kGroups>(a, lds, cls, scratch, a.dict.first, up->in_off, n, a.out + out_off, lane);
+    chain_io none{};
+    const uint64_t end =
+        decode_segment<16, kRounds, kGroups, false>(a, lds, cls, scratch, a.dict.first, up->in_off, n, a.out + out_off, lane, none);
     if (a.end_off && lane == 0) a.end_off[unit_index] = end;
 }
 
@@ -728,10 +792,20 @@ __device__ __forceinline__ void decode_unit_multi(const decode_args& a, const ui
     const uint32_t n = up->n;
     if (n == 0 || out_off + n > a.out_capacity || (a.only_full && n != 256)) return;
     uint64_t pos = up->in_off;
+    chain_io ch{};
     for (uint32_t done = 0; done < n;) {
         const uint32_t bsize = n - done < 256u ? n - done : 256u;
-        const uint64_t sp = pos < a.enc_bytes ? pos : a.enc_bytes - 1;
-        const uint32_t sel = uniform(a.enc[sp]);
+        pos = (uint64_t(uniform(uint32_t(pos >> 32))) << 32) | uniform(uint32_t(pos));
+        // chained unless the block sits in the last kChainBytes of the buffer
+        const bool chained = pos + 1 + kChainBytes <= a.enc_bytes;
+        if (chained && !ch.valid) chain_request(a.enc, pos, lane, ch);  // first block of the unit
+        uint32_t sel;
+        if (chained) {
+            sel = uniform(ch.sel) & 0xFFu;
+        } else {
+            const uint64_t sp = pos < a.enc_bytes ? pos : a.enc_bytes - 1;
+            sel = uniform(a.enc[sp]);
+        }
         const bool narrow = sel >= 6;
         const uint32_t d = (narrow ? sel - 6 : sel) % 6;
         dict_desc dd;
@@ -740,8 +814,14 @@ __device__ __forceinline__ void decode_unit_multi(const decode_args& a, const ui
         dd.hot_k = uniform(a.dict.descs[d].hot_k);
         dd.pad = 0;
         uint32_t* const out = a.out + out_off + done;
-        if (narrow) pos = decode_segment<8, 1, 1>(a, lds, cls, scratch, dd, pos + 1, bsize, out, lane);
-        else pos = decode_segment<16, 1, 1>(a, lds, cls, scratch, dd, pos + 1, bsize, out, lane);
+        ch.more = done + bsize < n;
+        if (chained) {
+            if (narrow) pos = decode_segment<8, 1, 1, true>(a, lds, cls, scratch, dd, pos + 1, bsize, out, lane, ch);
+            else pos = decode_segment<16, 1, 1, true>(a, lds, cls, scratch, dd, pos + 1, bsize, out, lane, ch);
+        } else {
+            if (narrow) pos = decode_segment<8, 1, 1, false>(a, lds, cls, scratch, dd, pos + 1, bsize, out, lane, ch);
+            else pos = decode_segment<16, 1, 1, false>(a, lds, cls, scratch, dd, pos + 1, bsize, out, lane, ch);
+        }
         done += bsize;
     }
     if (a.end_off && lane == 0) a.end_off[unit_index] = pos;
