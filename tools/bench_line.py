@@ -1,0 +1,5 @@
+import json,sys
+for l in sys.stdin:
+    l=l.strip()
+    if l.startswith('{'):
+        d=json.loads(l); print(d["config"]["postings_per_gpu"], "steps", d["steps"], "value", d["value"], "ms/step", d["ms_per_step"], "kernel_ms", d["roofline"]["kernel_ms"], "frac", d["roofline"]["frac"])
