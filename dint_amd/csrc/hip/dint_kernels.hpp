@@ -65,8 +65,14 @@ constexpr uint32_t kBlocksPerCU = DINT_BLOCKS_PER_CU;
 constexpr uint32_t kLdsWords = 160 * 1024 / 4 / kBlocksPerCU;
 constexpr uint32_t kSPL = 4;                          // slots per lane per tile
 constexpr uint32_t kTileSlots = kWave * kSPL;         // 256 slots per tile
-constexpr uint32_t kGroups = 4;                       // 256-output groups expanded together (one round)
-constexpr uint32_t kRounds = 2;                       // rounds per batch (single-dictionary segments)
+#ifndef DINT_GROUPS
+#define DINT_GROUPS 2
+#endif
+#ifndef DINT_UNIT_CHAIN
+#define DINT_UNIT_CHAIN 0  // 1: single-dictionary units request their successor's first tiles (measured: no gain)
+#endif
+constexpr uint32_t kGroups = DINT_GROUPS;             // 256-output groups expanded together (one round)
+constexpr uint32_t kRounds = 8 / kGroups;             // rounds per batch (single-dictionary segments)
 constexpr uint32_t kMaxCap = 2048;                    // outputs per expansion batch at most: the flag bitmap's bits
 // per wave: 64 {flag word, rank base} pairs (+ spare), per-codeword delta table (+ 4 dummy
 // entries for codewords that are not live in a batch), staging cells
@@ -258,9 +264,11 @@ __device__ __forceinline__ void build_class_table(uint16_t* table) {
 #define MARK(name) do {} while (0)
 #endif
 
-// Segment chaining (multi-dictionary units): a block's bytes are known only when the previous block
+// Segment chaining. Multi-dictionary units: a block's bytes are known only when the previous block
 // has been parsed, so a block on its own pays the full memory latency of its selector and its slots
-// before it can start. Chained, the first kChainBytes of the next block (16 per lane, from the byte
+// before it can start. Single-dictionary units: nine in ten posting lists are shorter than one tile
+// (Gov2-shaped lengths), each is its own unit, and a wave knows its next unit while it decodes the
+// current one. Chained, the first kChainBytes of the next block (16 per lane, from the byte
 // after its selector on) and its selector are requested as soon as the current block's end is known
 // — after the scans, before its expansion and stores — and are re-laid-out lane to lane
 // (ds_bpermute) into the first two tiles of the next segment.
@@ -268,8 +276,9 @@ constexpr uint32_t kChainBytes = 16 * kWave;
 struct chain_io {
     u32x4 data;     // bytes [16 * lane, 16 * lane + 16) of the segment's slot stream
     uint32_t sel;   // the byte before them (the block's selector) in bits 0-7
-    bool more;      // in: a block follows this one
-    bool valid;     // out: data / sel hold the next block's bytes
+    uint64_t next_off;  // in: where the next segment's selector byte is, or ~0: right after this segment
+    bool more;      // in: a segment follows this one
+    bool valid;     // out: data / sel hold the next segment's bytes
 };
 
 __device__ __forceinline__ void chain_request(const uint8_t* enc, uint64_t selector_byte, uint32_t lane, chain_io& ch) {
@@ -365,12 +374,11 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
 
     // lane constants of the expansion: this lane owns outputs 4*lane .. 4*lane+3 of every group
     const uint32_t sh = (4 * lane) & 31u;                 // bit position of its nibble in its flag word
-    const uint32_t below = (1u << sh) - 1u;               // flag bits before that nibble
     const uint32_t pair_byte = (lane >> 3) * 8;           // its {flag, base} pair inside a group's 8 pairs
 
     uint32_t produced = 0;
     uint32_t carry = 0;            // payload slots an exception of the previous tile still owns
-    uint64_t tile_base = in_off;   // byte offset of slot 0 of the current tile
+    uint64_t tile_base = in_off_u; // byte offset of slot 0 of the current tile (wave-uniform)
     uint32_t end_slot = 0;
     MARK("loop_top");
 
@@ -438,9 +446,7 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
         const bool special = __ballot(smin < 2) != 0 || carry != 0;
         uint32_t paybits = 0, excbits = 0, row = 0;
         uint32_t carry_out = 0;
-        uint32_t excval[kSPL];
-#pragma unroll
-        for (uint32_t k = 0; k != kSPL; ++k) excval[k] = 0;
+        uint32_t excval[kSPL];  // set and read only when tile_exc
         bool tile_exc = false;
         if (special) {
             // base-3 digits of the four slots: 2 - min(slot, 2)
@@ -585,8 +591,8 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
 #pragma unroll
             for (uint32_t k = 0; k != kSPL; ++k) nxt.s[k] = nxt.m[k] = 0;
             if (CHAINED) {
-                const uint64_t end_byte = tile_base + uint64_t(kSlotBytes) * end_slot;
-                if (ch.more && end_byte + 1 + kChainBytes <= a.enc_bytes) chain_request(a.enc, end_byte, lane, ch);
+                const uint64_t nb = ch.next_off != ~0ull ? ch.next_off : tile_base + uint64_t(kSlotBytes) * end_slot;
+                if (ch.more && nb + 1 + kChainBytes <= a.enc_bytes) chain_request(a.enc, nb, lane, ch);
             }
         }
         MARK("4_batch_select");
@@ -615,8 +621,9 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
             uint32_t srcb[kSPL];
 #pragma unroll
             for (uint32_t k = 0; k != kSPL; ++k) srcb[k] = src4[k];
-            u32x2 e0 = {0u, 0u}, e1 = {0u, 0u};
-            u32x4 q00 = {0u, 0u, 0u, 0u}, q01 = q00, q10 = q00, q11 = q00;
+            // (deliberately uninitialised: each is written and read under the same lane predicate)
+            u32x2 e0, e1;
+            u32x4 q00, q01, q10, q11;
             if (tile_staged) {
 #pragma unroll
                 for (uint32_t k = 0; k != kSPL; ++k) {
@@ -731,7 +738,7 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
                         if ((rd * GROUPS + g) * 4 * kWave < bt) {  // wave-uniform
                             const u32x2 pr = *reinterpret_cast<const u32x2*>(fw + (rd * GROUPS + g) * 64 + pair_byte);
                             const uint32_t w = pr.x;
-                            const uint32_t base = pr.y + uint32_t(__builtin_popcount(w & below));
+                            const uint32_t base = pr.y + uint32_t(__builtin_popcount(__builtin_amdgcn_ubfe(w, 0u, sh)));  // flags below its nibble
                             const uint32_t nib = w >> sh;
                             uint32_t r[4];
                             r[0] = base + (nib & 1u);
@@ -792,14 +799,28 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
 // A single-dictionary unit (rectangular or packed: the streams are byte-identical,
 // only the dictionary source layout differed on the host) is one 16-bit segment.
 __device__ __forceinline__ void decode_unit_single(const decode_args& a, const uint32_t* lds, const uint16_t* cls,
-                                                   uint32_t* scratch, uint64_t unit_index, uint32_t lane) {
+                                                   uint32_t* scratch, uint64_t unit_index, uint32_t lane, chain_io& ch,
+                                                   uint64_t next_in_off) {
     const dint_unit* up = a.units + unit_index;
     const uint64_t out_off = up->out_off;
     const uint32_t n = up->n;
-    if (n == 0 || out_off + n > a.out_capacity || (a.only_full && n != 256)) return;
-    chain_io none{};
-    const uint64_t end =
-        decode_segment<16, kRounds, kGroups, false>(a, lds, cls, scratch, a.dict.first, up->in_off, n, a.out + out_off, lane, none);
+    if (n == 0 || out_off + n > a.out_capacity || (a.only_full && n != 256)) {
+        ch.valid = false;
+        return;
+    }
+    const uint64_t in_off = (uint64_t(uniform(uint32_t(up->in_off >> 32))) << 32) | uniform(uint32_t(up->in_off));
+    // chained unless the unit sits in the last kChainBytes of the buffer: its first two tiles were
+    // requested by this wave's previous unit (or are requested here), and it requests the next unit's
+    const bool chained = DINT_UNIT_CHAIN && in_off >= 1 && in_off + kChainBytes <= a.enc_bytes;
+    ch.more = next_in_off != ~0ull && next_in_off >= 1;
+    ch.next_off = next_in_off - 1;  // chain_request reads the byte before the data as a "selector"
+    uint64_t end;
+    if (chained) {
+        if (!ch.valid) chain_request(a.enc, in_off - 1, lane, ch);
+        end = decode_segment<16, kRounds, kGroups, true>(a, lds, cls, scratch, a.dict.first, in_off, n, a.out + out_off, lane, ch);
+    } else {
+        end = decode_segment<16, kRounds, kGroups, false>(a, lds, cls, scratch, a.dict.first, in_off, n, a.out + out_off, lane, ch);
+    }
     if (a.end_off && lane == 0) a.end_off[unit_index] = end;
 }
 
@@ -837,6 +858,7 @@ __device__ __forceinline__ void decode_unit_multi(const decode_args& a, const ui
         dd.pad = 0;
         uint32_t* const out = a.out + out_off + done;
         ch.more = done + bsize < n;
+        ch.next_off = ~0ull;  // the next block starts where this one ends
         if (chained) {
             if (narrow) pos = decode_segment<8, 1, 1, true>(a, lds, cls, scratch, dd, pos + 1, bsize, out, lane, ch);
             else pos = decode_segment<16, 1, 1, true>(a, lds, cls, scratch, dd, pos + 1, bsize, out, lane, ch);
@@ -874,12 +896,18 @@ __device__ __forceinline__ void decode_kernel_body(const decode_args& a) {
         if (lane == 0) j = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return uniform(j);
     };
+    chain_io ch{};
     uint32_t j = draw();
     while (j < shard_units) {
         const uint32_t j_next = draw();
         const uint64_t u = uint64_t(shard) + uint64_t(a.n_shards) * j;
-        if (MULTI) decode_unit_multi(a, lds, cls, scratch, u, lane);
-        else decode_unit_single(a, lds, cls, scratch, u, lane);
+        if (MULTI) {
+            decode_unit_multi(a, lds, cls, scratch, u, lane);
+        } else {
+            uint64_t next_in = ~0ull;
+            if (j_next < shard_units) next_in = a.units[uint64_t(shard) + uint64_t(a.n_shards) * j_next].in_off;
+            decode_unit_single(a, lds, cls, scratch, u, lane, ch, next_in);
+        }
         j = j_next;
     }
 }
