@@ -156,6 +156,8 @@ struct dint_dict {
     // behind the event of the launch that used the slot last
     static constexpr uint32_t kQueueSlots = 32;
     uint32_t* d_queues = nullptr;
+    uint8_t* d_sched[kQueueSlots] = {};   // per slot: the bundle schedule of the launch (grow-only)
+    size_t sched_cap[kQueueSlots] = {};
     hipEvent_t slot_done[kQueueSlots] = {};
     bool slot_used[kQueueSlots] = {};
     std::atomic<uint32_t> next_slot{0};
@@ -438,6 +440,8 @@ void dint_dict_destroy(dint_dict* dd) {
     if (dd->ev_start) (void)hipEventDestroy(dd->ev_start);
     if (dd->ev_stop) (void)hipEventDestroy(dd->ev_stop);
     if (dd->d_queues) (void)hipFree(dd->d_queues);
+    for (auto p : dd->d_sched)
+        if (p) (void)hipFree(p);
     for (auto e : dd->slot_done)
         if (e) (void)hipEventDestroy(e);
     delete dd;
@@ -579,6 +583,21 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
     a.queue = mut->d_queues + size_t(slot) * kQueueShards * kQueueStride;
     a.n_shards = std::min<uint32_t>(kQueueShards, grid);
     HIP_TRY(hipMemsetAsync(a.queue, 0, size_t(kQueueShards) * kQueueStride * 4, s));
+    // tiny consecutive units are decoded several to a tile: schedule them (single-dictionary streams)
+    a.sched = nullptr;
+    if (dd->kind != DINT_DICT_MULTI_PACKED && !only_full && n_units >= 2 && !std::getenv("DINT_NO_BUNDLES")) {
+        if (mut->sched_cap[slot] < n_units) {
+            if (mut->d_sched[slot]) HIP_TRY(hipFree(mut->d_sched[slot]));
+            mut->d_sched[slot] = nullptr;
+            mut->sched_cap[slot] = 0;
+            const size_t want = n_units + n_units / 4 + 1024;
+            HIP_TRY(hipMalloc(&mut->d_sched[slot], want));
+            mut->sched_cap[slot] = want;
+        }
+        hipLaunchKernelGGL(bundle_schedule_kernel, dim3(uint32_t((n_units + 255) / 256)), dim3(256), 0, s, d_units,
+                           uint64_t(n_units), uint64_t(enc_bytes), uint64_t(out_capacity), mut->d_sched[slot]);
+        a.sched = mut->d_sched[slot];
+    }
     HIP_TRY(hipEventRecord(mut->ev_start, s));
     if (dd->kind == DINT_DICT_MULTI_PACKED)
         hipLaunchKernelGGL(decode_multi_kernel, dim3(grid), dim3(kBlockThreads), lds_bytes, s, a);

@@ -124,6 +124,8 @@ struct decode_args {
     uint32_t* queue;    // kQueueShards counters, kQueueStride words apart, zero at launch
     uint32_t n_shards;  // counters in use
     uint32_t only_full; // in-index path: decode units of exactly 256 integers only (tails are interpolative)
+    const uint8_t* sched;  // nullable; per unit: 0 = member of a bundle led by an earlier unit, 1 = on its own,
+                           // c > 1 = leads a bundle of c consecutive tiny units (bundle_schedule_kernel)
 };
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -154,6 +156,18 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
     x += __builtin_amdgcn_update_dpp(0u, x, 0x118, 0xf, 0xf, false);  // row_shr:8
     x += __builtin_amdgcn_update_dpp(0u, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
     x += __builtin_amdgcn_update_dpp(0u, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
+    return x;
+}
+
+// Inclusive prefix maximum over the 64 lanes (same DPP pattern; zero fill is neutral for unsigned max).
+__device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t x) {
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    x = mx(x, uint32_t(__builtin_amdgcn_update_dpp(0u, x, 0x111, 0xf, 0xf, false)));
+    x = mx(x, uint32_t(__builtin_amdgcn_update_dpp(0u, x, 0x112, 0xf, 0xf, false)));
+    x = mx(x, uint32_t(__builtin_amdgcn_update_dpp(0u, x, 0x114, 0xf, 0xf, false)));
+    x = mx(x, uint32_t(__builtin_amdgcn_update_dpp(0u, x, 0x118, 0xf, 0xf, false)));
+    x = mx(x, uint32_t(__builtin_amdgcn_update_dpp(x, x, 0x142, 0xa, 0xf, false)));
+    x = mx(x, uint32_t(__builtin_amdgcn_update_dpp(x, x, 0x143, 0xc, 0xf, false)));
     return x;
 }
 
@@ -303,22 +317,238 @@ __device__ __forceinline__ uint64_t chain_tile(const u32x4& d, uint32_t t, uint3
     return c == 0 ? x : c == 1 ? y : c == 2 ? z : w;
 }
 
-// ROUNDS x GROUPS x 256 = outputs per expansion batch: 2 x 4 for the long single-dictionary
-// segments; a multi-dictionary segment is one block of at most 256 integers, 1 x 1.
-template <int W, uint32_t ROUNDS, uint32_t GROUPS, bool CHAINED>
-__device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const uint32_t* lds, const uint16_t* cls,
-                                                   uint32_t* scratch, const dict_desc& dd, uint64_t in_off,
-                                                   uint32_t n, uint32_t* const out, uint32_t lane, chain_io& ch) {
+// What a tile's front end hands to its expansion, per lane (slot k = 0..3 of the lane) and per wave.
+struct tile_slots {
+    uint32_t live[kSPL];    // all ones: a codeword header inside the segment
+    uint32_t off4[kSPL];    // byte offset of its first output behind the lane's first
+    uint32_t lord[kSPL];    // its ordinal behind the lane's first codeword
+    uint32_t src4[kSPL];    // source byte address (LDS; cold: table offset + kColdBase4)
+    uint32_t pk[kSPL];      // staging cells it needs | 1 << 16 if they are fetched from the table
+    uint32_t cpre[kSPL];    // prefix of pk inside the lane
+    uint32_t lit[kSPL];     // all ones: exception header (its value is in excval)
+    uint32_t excval[kSPL];
+    uint32_t lsum, obase;   // outputs of the lane's live codewords, position of the first
+    uint32_t rbase, nlive;  // ordinal of its first live codeword, how many it has
+    uint32_t cl, qb, wb;    // pk sum of the lane; first cell / first fetch of the lane
+    uint32_t total;         // outputs of the tile (wave-uniform)
+    bool tile_exc, tile_staged;  // some lane holds an exception / needs staging (wave-uniform)
+};
+
+// Steps 3 and 4 of a tile: batches of at most ROUNDS x GROUPS x 256 outputs and kStageQuads staging
+// cells (normally one: the whole tile) — cold fetch, flag/delta tables, staging, expansion, stores.
+// `before_stores` runs once before the first store is issued: the caller parks there the waits for
+// everything it has prefetched (see decode_segment).
+template <uint32_t ROUNDS, uint32_t GROUPS, class BeforeStores>
+__device__ __forceinline__ void expand_tile(const tile_slots& t, uint32_t out_int0, const uint32_t* lds, uint32_t* scratch,
+                                            const __amdgpu_buffer_rsrc_t rs_table, const __amdgpu_buffer_rsrc_t rs_out,
+                                            uint32_t* const out, uint32_t lane, BeforeStores&& before_stores) {
     constexpr uint32_t kCap = ROUNDS * GROUPS * 256;
     static_assert(kCap <= kMaxCap, "the flag bitmap holds 2048 positions");
-    constexpr uint32_t kSlotBytes = W / 8;
-    constexpr uint32_t kTileBytes = kTileSlots * kSlotBytes;
     // per-wave scratch (byte offsets): {flag word, rank base} pairs | delta table | staging cells
     uint8_t* const fw = reinterpret_cast<uint8_t*>(scratch);                  // 64 pairs of 8 bytes (+1 spare)
     uint8_t* const delta = reinterpret_cast<uint8_t*>(scratch + kFwWords);    // 256 entries + 4 dummies
     uint8_t* const stage = reinterpret_cast<uint8_t*>(scratch + kFwWords + kDeltaWords);  // 128 cells of 16 bytes
     const uint8_t* const lds_bytes = reinterpret_cast<const uint8_t*>(lds);
     const uint32_t stage_off = uint32_t(stage - lds_bytes);                   // the cells as gather sources
+    // lane constants of the expansion: this lane owns outputs 4*lane .. 4*lane+3 of every group
+    const uint32_t sh = (4 * lane) & 31u;                 // bit position of its nibble in its flag word
+    const uint32_t pair_byte = (lane >> 3) * 8;           // its {flag, base} pair inside a group's 8 pairs
+    (void)out;
+    MARK("4_batch_select");
+    // ---- 3./4. batches of <= kCap outputs and <= kStageQuads cells (normally one: the whole tile)
+    // (a do-while: the compiler must see that the wait inside precedes the register rotation
+    // below on every path, or it waits again there — after the stores, for their acknowledgements)
+    uint32_t done = 0, rdone = 0, qdone = 0, wdone = 0;
+    do {
+        const bool inb = t.lsum != 0 && t.obase >= done && (t.obase + t.lsum - done) <= kCap &&
+                         (t.qb + (t.cl & 0xFFFFu) - qdone) <= kStageQuads &&
+                         (kStageQuads <= 2 * kWave || (t.wb + (t.cl >> 16) - wdone) <= 2 * kWave);  // two fetches per lane
+        const uint64_t bm = __ballot(inb);
+        const uint32_t last = 63u - uint32_t(__builtin_clzll(bm | 1ull));
+        const uint32_t bend = readlane(t.obase + t.lsum, last);
+        const uint32_t rend = readlane(t.rbase + t.nlive, last);
+        const uint32_t qend = readlane(t.qb + (t.cl & 0xFFFFu), last);
+        const uint32_t wend = readlane(t.wb + (t.cl >> 16), last);
+        if (bend <= done) break;                // (malformed input: nothing decodable left in this tile)
+        const uint32_t bt = bend - done;        // outputs in this batch, 1..kCap
+        const uint32_t nfetch = wend - wdone;   // cold codewords to fetch, <= kStageQuads
+        const uint32_t inbM = inb ? ~0u : 0u;
+
+        MARK("5_worklist");
+        // (a) worklist of the cold codewords {table byte offset, cell | quads << 16}, then each
+        // lane takes up to two of them and fetches their first two quads (sizes 1..8); the
+        // fetches fly while the batch tables are built
+        uint32_t srcb[kSPL];
+#pragma unroll
+        for (uint32_t k = 0; k != kSPL; ++k) srcb[k] = t.src4[k];
+        // (deliberately uninitialised: each is written and read under the same lane predicate)
+        u32x2 e0, e1;
+        u32x4 q00, q01, q10, q11;
+        if (t.tile_staged) {
+#pragma unroll
+            for (uint32_t k = 0; k != kSPL; ++k) {
+                const uint32_t lv = t.live[k] & inbM;
+                const uint32_t cell = t.qb - qdone + (t.cpre[k] & 0xFFFFu);
+                if (lv != 0 && (t.pk[k] & 0xFFFFu) != 0) srcb[k] = stage_off + 16u * cell;
+                // every slot writes an entry: the ones with nothing to fetch park it past the list
+                const bool fetch = lv != 0 && (t.pk[k] >> 16) != 0;
+                const u32x2 e = {t.src4[k] - kColdBase4, cell | (t.pk[k] << 16)};
+                *reinterpret_cast<u32x2*>(stage + 8u * (fetch ? t.wb - wdone + (t.cpre[k] >> 16) : kStageQuads + k)) = e;
+            }
+            wave_lds_fence();
+            if (lane < nfetch) e0 = *reinterpret_cast<const u32x2*>(stage + 8u * lane);
+            if (nfetch > 64u && lane + 64u < nfetch) e1 = *reinterpret_cast<const u32x2*>(stage + 8u * (lane + 64u));
+            wave_lds_fence();
+#ifndef DINT_EXP_NOFETCH  // timing experiment: no cold payload reads (results are wrong)
+            if (lane < nfetch) {
+                q00 = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e0.x, 0, 0);
+                if (((e0.y >> 16) & 7u) > 1u) q01 = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e0.x + 16u, 0, 0);
+            }
+            if (nfetch > 64u && lane + 64u < nfetch) {
+                q10 = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e1.x, 0, 0);
+                if (((e1.y >> 16) & 7u) > 1u) q11 = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e1.x + 16u, 0, 0);
+            }
+#endif
+        }
+
+        MARK("6_flags");
+        // (b) flags and deltas. Every slot runs the same instructions: a codeword that is not
+        // live in this batch ORs a zero into an in-range flag word and parks its delta in a dummy.
+        *reinterpret_cast<uint32_t*>(fw + 8 * lane) = 0;  // clear all 64 flag words
+        wave_lds_fence();
+        const uint32_t rel0 = t.obase - done, ord0 = t.rbase - rdone;
+#pragma unroll
+        for (uint32_t k = 0; k != kSPL; ++k) {
+            const uint32_t lv = t.live[k] & inbM;
+            const uint32_t rel = rel0 + (t.off4[k] >> 2);
+            uint32_t* const fword = reinterpret_cast<uint32_t*>(fw + ((rel >> 2) & 0x1F8u));
+            __hip_atomic_fetch_or(fword, lv & (1u << (rel & 31u)), __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_WAVEFRONT);
+            const uint32_t ord = (lv & (ord0 + t.lord[k])) | (~lv & (kTileSlots + k));
+            *reinterpret_cast<uint32_t*>(delta + 4 * ord) = srcb[k] - 4 * rel;
+        }
+        wave_lds_fence();
+        {
+            uint32_t* const pair = reinterpret_cast<uint32_t*>(fw + 8 * lane);
+            const uint32_t pc = uint32_t(__builtin_popcount(pair[0]));
+            const uint32_t pi = wave_inclusive_sum(pc);
+            pair[1] = pi - pc - 1u;  // flags before this word, minus one
+        }
+        MARK("7_stage_write");
+
+        // (c) the fetched quads and the exception literals go into their cells
+        if (t.tile_staged) {
+            if (lane < nfetch) {
+                uint8_t* const c = stage + 16u * (e0.y & 0xFFFFu);
+                *reinterpret_cast<u32x4*>(c) = q00;
+                if (((e0.y >> 16) & 7u) > 1u) *reinterpret_cast<u32x4*>(c + 16) = q01;
+            }
+            if (nfetch > 64u && lane + 64u < nfetch) {
+                uint8_t* const c = stage + 16u * (e1.y & 0xFFFFu);
+                *reinterpret_cast<u32x4*>(c) = q10;
+                if (((e1.y >> 16) & 7u) > 1u) *reinterpret_cast<u32x4*>(c + 16) = q11;
+            }
+            // size-16 cold codewords (rare): quads 2 and 3, fetched and waited for on the spot
+            const bool big0 = lane < nfetch && ((e0.y >> 16) & 7u) > 2u;
+            const bool big1 = nfetch > 64u && lane + 64u < nfetch && ((e1.y >> 16) & 7u) > 2u;
+#ifdef DINT_EXP_NOFETCH
+            if (false) {
+#else
+            if (__ballot(big0 || big1) != 0) {
+#endif
+                if (big0) {
+                    uint8_t* const c = stage + 16u * (e0.y & 0xFFFFu);
+                    *reinterpret_cast<u32x4*>(c + 32) = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e0.x + 32u, 0, 0);
+                    if (((e0.y >> 16) & 7u) > 3u)
+                        *reinterpret_cast<u32x4*>(c + 48) = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e0.x + 48u, 0, 0);
+                }
+                if (big1) {
+                    uint8_t* const c = stage + 16u * (e1.y & 0xFFFFu);
+                    *reinterpret_cast<u32x4*>(c + 32) = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e1.x + 32u, 0, 0);
+                    if (((e1.y >> 16) & 7u) > 3u)
+                        *reinterpret_cast<u32x4*>(c + 48) = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e1.x + 48u, 0, 0);
+                }
+            }
+            if (t.tile_exc) {
+#pragma unroll
+                for (uint32_t k = 0; k != kSPL; ++k)
+                    if ((t.live[k] & inbM & t.lit[k]) != 0)
+                        *reinterpret_cast<uint32_t*>(stage + 16u * (t.qb - qdone + (t.cpre[k] & 0xFFFFu))) = t.excval[k];
+            }
+        }
+        wave_lds_fence();
+
+        MARK("8_expand");
+        // (d) expansion, GROUPS * 256 outputs per round: each lane takes 4 consecutive outputs of
+        // every 256-output group; every source is an LDS byte address by now. Stores are whole
+        // 16-byte quads: the descriptor clips what lies past the segment's n integers (range
+        // checking is per dword), and what a quad writes past this batch's end inside the segment
+        // is rewritten by the batches and tiles that follow (same wave, program order).
+#pragma unroll
+        for (uint32_t rd = 0; rd != ROUNDS; ++rd) {
+            if (rd * GROUPS * 4 * kWave < bt) {  // wave-uniform
+#ifdef DINT_EXP_STORE_LOCAL  // timing experiment: same store instructions, all into the segment's first 4 KB
+                const uint32_t obyte = 0;
+#else
+                const uint32_t obyte = 4 * (out_int0 + done) + rd * GROUPS * 16 * kWave;  // output byte offset of the round
+#endif
+                uint32_t x[GROUPS][4];
+#pragma unroll
+                for (uint32_t g = 0; g != GROUPS; ++g) {
+                    if ((rd * GROUPS + g) * 4 * kWave < bt) {  // wave-uniform
+                        const u32x2 pr = *reinterpret_cast<const u32x2*>(fw + (rd * GROUPS + g) * 64 + pair_byte);
+                        const uint32_t w = pr.x;
+                        const uint32_t base = pr.y + uint32_t(__builtin_popcount(__builtin_amdgcn_ubfe(w, 0u, sh)));  // flags below its nibble
+                        const uint32_t nib = w >> sh;
+                        uint32_t r[4];
+                        r[0] = base + (nib & 1u);
+                        r[1] = base + uint32_t(__builtin_popcount(nib & 3u));
+                        r[2] = base + uint32_t(__builtin_popcount(nib & 7u));
+                        r[3] = base + uint32_t(__builtin_popcount(nib & 15u));
+                        const uint32_t pos4 = (rd * GROUPS + g) * 16 * kWave + 16 * lane;  // byte position in the batch
+#pragma unroll
+                        for (int k = 0; k != 4; ++k) {
+                            const uint32_t ad = *reinterpret_cast<const uint32_t*>(delta + 4 * r[k]) + pos4 + 4 * k;
+                            x[g][k] = *reinterpret_cast<const uint32_t*>(lds_bytes + ad);
+                        }
+                    }
+                }
+                MARK("9_stores");
+                // the prefetched registers must have landed before the first store is issued
+                if (rd == 0) before_stores();
+#pragma unroll
+                for (uint32_t g = 0; g != GROUPS; ++g) {
+                    const uint32_t p0 = (rd * GROUPS + g) * 4 * kWave + 4 * lane;
+                    if ((rd * GROUPS + g) * 4 * kWave < bt) {  // wave-uniform
+#ifdef DINT_EXP_NOSTORE
+                        if (x[g][0] == 0xDEADBEEFu && x[g][1] == 0x12345u) out[g] = x[g][2] + x[g][3];
+#else
+                        if (p0 < bt) {
+                            const u32x4 xv = {x[g][0], x[g][1], x[g][2], x[g][3]};
+                            __builtin_amdgcn_raw_buffer_store_b128(xv, rs_out, 16 * g * kWave + 16 * lane, obyte, DINT_STORE_AUX);
+                        }
+#endif
+                    }
+                }
+            }
+        }
+        wave_lds_fence();
+        done = bend;
+        rdone = rend;
+        qdone = qend;
+        wdone = wend;
+    } while (done < t.total);
+
+}
+
+// ROUNDS x GROUPS x 256 = outputs per expansion batch: 2 x 4 for the long single-dictionary
+// segments; a multi-dictionary segment is one block of at most 256 integers, 1 x 1.
+template <int W, uint32_t ROUNDS, uint32_t GROUPS, bool CHAINED>
+__device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const uint32_t* lds, const uint16_t* cls,
+                                                   uint32_t* scratch, const dict_desc& dd, uint64_t in_off,
+                                                   uint32_t n, uint32_t* const out, uint32_t lane, chain_io& ch) {
+    constexpr uint32_t kSlotBytes = W / 8;
+    constexpr uint32_t kTileBytes = kTileSlots * kSlotBytes;
     const uint16_t* const rows = cls + (W == 16 ? 0 : kRows16);
 
     const uint32_t hot_k = dd.hot_k;
@@ -371,10 +601,6 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
     // Everything loaded so far has landed before the loop is entered: inside it, a wait may only
     // ever sit right before a tile's stores (see the prefetch note below), never after them.
     asm volatile("" ::"v"(raw1), "v"(raw2), "v"(cur.m[0]), "v"(cur.m[1]), "v"(cur.m[2]), "v"(cur.m[3]));
-
-    // lane constants of the expansion: this lane owns outputs 4*lane .. 4*lane+3 of every group
-    const uint32_t sh = (4 * lane) & 31u;                 // bit position of its nibble in its flag word
-    const uint32_t pair_byte = (lane >> 3) * 8;           // its {flag, base} pair inside a group's 8 pairs
 
     uint32_t produced = 0;
     uint32_t carry = 0;            // payload slots an exception of the previous tile still owns
@@ -595,192 +821,25 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
                 if (ch.more && nb + 1 + kChainBytes <= a.enc_bytes) chain_request(a.enc, nb, lane, ch);
             }
         }
-        MARK("4_batch_select");
-        // ---- 3./4. batches of <= kCap outputs and <= kStageQuads cells (normally one: the whole tile)
-        // (a do-while: the compiler must see that the wait inside precedes the register rotation
-        // below on every path, or it waits again there — after the stores, for their acknowledgements)
-        uint32_t done = 0, rdone = 0, qdone = 0, wdone = 0;
-        do {
-            const bool inb = lsum != 0 && obase >= done && (obase + lsum - done) <= kCap &&
-                             (qb + (cl & 0xFFFFu) - qdone) <= kStageQuads &&
-                             (kStageQuads <= 2 * kWave || (wb + (cl >> 16) - wdone) <= 2 * kWave);  // two fetches per lane
-            const uint64_t bm = __ballot(inb);
-            const uint32_t last = 63u - uint32_t(__builtin_clzll(bm | 1ull));
-            const uint32_t bend = readlane(obase + lsum, last);
-            const uint32_t rend = readlane(rbase + nlive, last);
-            const uint32_t qend = readlane(qb + (cl & 0xFFFFu), last);
-            const uint32_t wend = readlane(wb + (cl >> 16), last);
-            const uint32_t bt = bend - done;        // outputs in this batch, 1..kCap
-            const uint32_t nfetch = wend - wdone;   // cold codewords to fetch, <= kStageQuads
-            const uint32_t inbM = inb ? ~0u : 0u;
-
-            MARK("5_worklist");
-            // (a) worklist of the cold codewords {table byte offset, cell | quads << 16}, then each
-            // lane takes up to two of them and fetches their first two quads (sizes 1..8); the
-            // fetches fly while the batch tables are built
-            uint32_t srcb[kSPL];
+        tile_slots t;
 #pragma unroll
-            for (uint32_t k = 0; k != kSPL; ++k) srcb[k] = src4[k];
-            // (deliberately uninitialised: each is written and read under the same lane predicate)
-            u32x2 e0, e1;
-            u32x4 q00, q01, q10, q11;
-            if (tile_staged) {
-#pragma unroll
-                for (uint32_t k = 0; k != kSPL; ++k) {
-                    const uint32_t lv = live[k] & inbM;
-                    const uint32_t cell = qb - qdone + (cpre[k] & 0xFFFFu);
-                    if (lv != 0 && (pk[k] & 0xFFFFu) != 0) srcb[k] = stage_off + 16u * cell;
-                    // every slot writes an entry: the ones with nothing to fetch park it past the list
-                    const bool fetch = lv != 0 && (pk[k] >> 16) != 0;
-                    const u32x2 e = {src4[k] - kColdBase4, cell | (pk[k] << 16)};
-                    *reinterpret_cast<u32x2*>(stage + 8u * (fetch ? wb - wdone + (cpre[k] >> 16) : kStageQuads + k)) = e;
-                }
-                wave_lds_fence();
-                if (lane < nfetch) e0 = *reinterpret_cast<const u32x2*>(stage + 8u * lane);
-                if (nfetch > 64u && lane + 64u < nfetch) e1 = *reinterpret_cast<const u32x2*>(stage + 8u * (lane + 64u));
-                wave_lds_fence();
-#ifndef DINT_EXP_NOFETCH  // timing experiment: no cold payload reads (results are wrong)
-                if (lane < nfetch) {
-                    q00 = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e0.x, 0, 0);
-                    if (((e0.y >> 16) & 7u) > 1u) q01 = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e0.x + 16u, 0, 0);
-                }
-                if (nfetch > 64u && lane + 64u < nfetch) {
-                    q10 = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e1.x, 0, 0);
-                    if (((e1.y >> 16) & 7u) > 1u) q11 = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e1.x + 16u, 0, 0);
-                }
-#endif
-            }
-
-            MARK("6_flags");
-            // (b) flags and deltas. Every slot runs the same instructions: a codeword that is not
-            // live in this batch ORs a zero into an in-range flag word and parks its delta in a dummy.
-            *reinterpret_cast<uint32_t*>(fw + 8 * lane) = 0;  // clear all 64 flag words
-            wave_lds_fence();
-            const uint32_t rel0 = obase - done, ord0 = rbase - rdone;
-#pragma unroll
-            for (uint32_t k = 0; k != kSPL; ++k) {
-                const uint32_t lv = live[k] & inbM;
-                const uint32_t rel = rel0 + (off4[k] >> 2);
-                uint32_t* const fword = reinterpret_cast<uint32_t*>(fw + ((rel >> 2) & 0x1F8u));
-                __hip_atomic_fetch_or(fword, lv & (1u << (rel & 31u)), __ATOMIC_RELAXED,
-                                      __HIP_MEMORY_SCOPE_WAVEFRONT);
-                const uint32_t ord = (lv & (ord0 + lord[k])) | (~lv & (kTileSlots + k));
-                *reinterpret_cast<uint32_t*>(delta + 4 * ord) = srcb[k] - 4 * rel;
-            }
-            wave_lds_fence();
-            {
-                uint32_t* const pair = reinterpret_cast<uint32_t*>(fw + 8 * lane);
-                const uint32_t pc = uint32_t(__builtin_popcount(pair[0]));
-                const uint32_t pi = wave_inclusive_sum(pc);
-                pair[1] = pi - pc - 1u;  // flags before this word, minus one
-            }
-            MARK("7_stage_write");
-
-            // (c) the fetched quads and the exception literals go into their cells
-            if (tile_staged) {
-                if (lane < nfetch) {
-                    uint8_t* const c = stage + 16u * (e0.y & 0xFFFFu);
-                    *reinterpret_cast<u32x4*>(c) = q00;
-                    if (((e0.y >> 16) & 7u) > 1u) *reinterpret_cast<u32x4*>(c + 16) = q01;
-                }
-                if (nfetch > 64u && lane + 64u < nfetch) {
-                    uint8_t* const c = stage + 16u * (e1.y & 0xFFFFu);
-                    *reinterpret_cast<u32x4*>(c) = q10;
-                    if (((e1.y >> 16) & 7u) > 1u) *reinterpret_cast<u32x4*>(c + 16) = q11;
-                }
-                // size-16 cold codewords (rare): quads 2 and 3, fetched and waited for on the spot
-                const bool big0 = lane < nfetch && ((e0.y >> 16) & 7u) > 2u;
-                const bool big1 = nfetch > 64u && lane + 64u < nfetch && ((e1.y >> 16) & 7u) > 2u;
-#ifdef DINT_EXP_NOFETCH
-                if (false) {
-#else
-                if (__ballot(big0 || big1) != 0) {
-#endif
-                    if (big0) {
-                        uint8_t* const c = stage + 16u * (e0.y & 0xFFFFu);
-                        *reinterpret_cast<u32x4*>(c + 32) = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e0.x + 32u, 0, 0);
-                        if (((e0.y >> 16) & 7u) > 3u)
-                            *reinterpret_cast<u32x4*>(c + 48) = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e0.x + 48u, 0, 0);
-                    }
-                    if (big1) {
-                        uint8_t* const c = stage + 16u * (e1.y & 0xFFFFu);
-                        *reinterpret_cast<u32x4*>(c + 32) = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e1.x + 32u, 0, 0);
-                        if (((e1.y >> 16) & 7u) > 3u)
-                            *reinterpret_cast<u32x4*>(c + 48) = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e1.x + 48u, 0, 0);
-                    }
-                }
-                if (tile_exc) {
-#pragma unroll
-                    for (uint32_t k = 0; k != kSPL; ++k)
-                        if ((live[k] & inbM & lit[k]) != 0)
-                            *reinterpret_cast<uint32_t*>(stage + 16u * (qb - qdone + (cpre[k] & 0xFFFFu))) = excval[k];
-                }
-            }
-            wave_lds_fence();
-
-            MARK("8_expand");
-            // (d) expansion, GROUPS * 256 outputs per round: each lane takes 4 consecutive outputs of
-            // every 256-output group; every source is an LDS byte address by now. Stores are whole
-            // 16-byte quads: the descriptor clips what lies past the segment's n integers (range
-            // checking is per dword), and what a quad writes past this batch's end inside the segment
-            // is rewritten by the batches and tiles that follow (same wave, program order).
-#pragma unroll
-            for (uint32_t rd = 0; rd != ROUNDS; ++rd) {
-                if (rd * GROUPS * 4 * kWave < bt) {  // wave-uniform
-#ifdef DINT_EXP_STORE_LOCAL  // timing experiment: same store instructions, all into the segment's first 4 KB
-                    const uint32_t obyte = 0;
-#else
-                    const uint32_t obyte = 4 * (produced + done) + rd * GROUPS * 16 * kWave;  // output byte offset of the round
-#endif
-                    uint32_t x[GROUPS][4];
-#pragma unroll
-                    for (uint32_t g = 0; g != GROUPS; ++g) {
-                        if ((rd * GROUPS + g) * 4 * kWave < bt) {  // wave-uniform
-                            const u32x2 pr = *reinterpret_cast<const u32x2*>(fw + (rd * GROUPS + g) * 64 + pair_byte);
-                            const uint32_t w = pr.x;
-                            const uint32_t base = pr.y + uint32_t(__builtin_popcount(__builtin_amdgcn_ubfe(w, 0u, sh)));  // flags below its nibble
-                            const uint32_t nib = w >> sh;
-                            uint32_t r[4];
-                            r[0] = base + (nib & 1u);
-                            r[1] = base + uint32_t(__builtin_popcount(nib & 3u));
-                            r[2] = base + uint32_t(__builtin_popcount(nib & 7u));
-                            r[3] = base + uint32_t(__builtin_popcount(nib & 15u));
-                            const uint32_t pos4 = (rd * GROUPS + g) * 16 * kWave + 16 * lane;  // byte position in the batch
-#pragma unroll
-                            for (int k = 0; k != 4; ++k) {
-                                const uint32_t ad = *reinterpret_cast<const uint32_t*>(delta + 4 * r[k]) + pos4 + 4 * k;
-                                x[g][k] = *reinterpret_cast<const uint32_t*>(lds_bytes + ad);
-                            }
-                        }
-                    }
-                    MARK("9_stores");
-                    // the prefetched registers must have landed before the first store is issued
-                    if (rd == 0) {
-                        asm volatile("" ::"v"(raw3), "v"(nxt.m[0]), "v"(nxt.m[1]), "v"(nxt.m[2]), "v"(nxt.m[3]));
-                        if (CHAINED) asm volatile("" ::"v"(ch.sel), "v"(ch.data.x), "v"(ch.data.y), "v"(ch.data.z), "v"(ch.data.w));
-                    }
-#pragma unroll
-                    for (uint32_t g = 0; g != GROUPS; ++g) {
-                        const uint32_t p0 = (rd * GROUPS + g) * 4 * kWave + 4 * lane;
-                        if ((rd * GROUPS + g) * 4 * kWave < bt) {  // wave-uniform
-#ifdef DINT_EXP_NOSTORE
-                            if (x[g][0] == 0xDEADBEEFu && x[g][1] == 0x12345u) out[g] = x[g][2] + x[g][3];
-#else
-                            if (p0 < bt) {
-                                const u32x4 xv = {x[g][0], x[g][1], x[g][2], x[g][3]};
-                                __builtin_amdgcn_raw_buffer_store_b128(xv, rs_out, 16 * g * kWave + 16 * lane, obyte, DINT_STORE_AUX);
-                            }
-#endif
-                        }
-                    }
-                }
-            }
-            wave_lds_fence();
-            done = bend;
-            rdone = rend;
-            qdone = qend;
-            wdone = wend;
-        } while (done < total);
+        for (uint32_t k = 0; k != kSPL; ++k) {
+            t.live[k] = live[k];
+            t.off4[k] = off4[k];
+            t.lord[k] = lord[k];
+            t.src4[k] = src4[k];
+            t.pk[k] = pk[k];
+            t.cpre[k] = cpre[k];
+            t.lit[k] = lit[k];
+            t.excval[k] = excval[k];
+        }
+        t.lsum = lsum, t.obase = obase, t.rbase = rbase, t.nlive = nlive, t.cl = cl, t.qb = qb, t.wb = wb;
+        t.total = total, t.tile_exc = tile_exc, t.tile_staged = tile_staged;
+        // the prefetched registers must have landed before the first store is issued
+        expand_tile<ROUNDS, GROUPS>(t, produced, lds, scratch, rs_table, rs_out, out, lane, [&]() {
+            asm volatile("" ::"v"(raw3), "v"(nxt.m[0]), "v"(nxt.m[1]), "v"(nxt.m[2]), "v"(nxt.m[3]));
+            if (CHAINED) asm volatile("" ::"v"(ch.sel), "v"(ch.data.x), "v"(ch.data.y), "v"(ch.data.z), "v"(ch.data.w));
+        });
 
         MARK("10_rotate");
         produced += total;
@@ -822,6 +881,247 @@ __device__ __forceinline__ void decode_unit_single(const decode_args& a, const u
         end = decode_segment<16, kRounds, kGroups, false>(a, lds, cls, scratch, a.dict.first, in_off, n, a.out + out_off, lane, ch);
     }
     if (a.end_off && lane == 0) a.end_off[unit_index] = end;
+}
+
+// ---- bundles of tiny units -----------------------------------------------------------------------
+// Nine in ten posting lists of a Gov2-shaped collection hold at most 64 postings; as units of
+// their own they are 0.2 % of the integers and a fifth of the tiles (each wave tile-step costs the
+// same whether 5 or 250 of its slot positions are used). A bundle packs up to 64 consecutive tiny
+// units into ONE tile: unit i takes ceil(bytes_i / 8) whole lanes, the front end runs segmented
+// (per-lane slot address, carries cut at unit starts, sizes clamped at each unit's n), and because
+// the units' outputs are consecutive the expansion is the ordinary one over the bundle's outputs.
+constexpr uint32_t kBundleMaxInts = 64;    // a unit is bundled only if it decodes to at most this many integers
+constexpr uint32_t kBundleMaxBytes = 128;  // ... and spans at most this many stream bytes (16 lanes)
+constexpr uint32_t kBundleWindow = 48;     // lanes per bundle before the last unit's (<= 16) are added
+
+// Host-launched before the decode kernel: sched[i] for every unit (see decode_args::sched). One
+// workgroup per 256 units; bundles do not cross these blocks.
+__global__ __launch_bounds__(256) void bundle_schedule_kernel(const dint_unit* units, uint64_t n_units, uint64_t enc_bytes,
+                                                              uint64_t out_capacity, uint8_t* sched) {
+    __shared__ uint32_t lanes[256], pre[256];
+    __shared__ uint8_t start[256];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t i = uint64_t(blockIdx.x) * 256 + tid;
+    uint32_t L = 0;
+    uint64_t in = 0, out = 0;
+    uint32_t n = 0;
+    if (i < n_units) {
+        in = units[i].in_off;
+        out = units[i].out_off;
+        n = units[i].n;
+        const uint64_t nxt = i + 1 < n_units ? units[i + 1].in_off : enc_bytes;
+        if (n >= 1 && n <= kBundleMaxInts && nxt > in && nxt - in <= kBundleMaxBytes && out + n <= out_capacity) {
+            const uint32_t l = uint32_t((nxt - in + 7) >> 3);
+            if (in + 8ull * l <= enc_bytes) L = l;  // every lane's 8-byte load stays inside the buffer
+        }
+    }
+    lanes[tid] = L;
+    pre[tid] = L;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {  // inclusive scan
+        const uint32_t v = tid >= d ? pre[tid - d] : 0;
+        __syncthreads();
+        pre[tid] += v;
+        __syncthreads();
+    }
+    const uint32_t p = pre[tid] - L;  // lanes of the eligible units before this one in the block
+    bool st = true;
+    if (L != 0 && tid != 0 && lanes[tid - 1] != 0) {
+        const uint32_t pp = pre[tid - 1] - lanes[tid - 1];
+        st = p / kBundleWindow != pp / kBundleWindow || out != units[i - 1].out_off + units[i - 1].n;
+    }
+    start[tid] = st ? 1 : 0;
+    __syncthreads();
+    if (i >= n_units) return;
+    uint32_t c = 0;
+    if (st) {
+        c = 1;
+        if (L != 0)
+            while (tid + c < 256 && i + c < n_units && !start[tid + c]) ++c;
+    }
+    sched[i] = uint8_t(c);
+}
+
+// One tile over `cnt` (2..64) consecutive tiny single-dictionary units starting at unit u0.
+__device__ __forceinline__ void decode_bundle(const decode_args& a, const uint32_t* lds, const uint16_t* cls, uint32_t* scratch,
+                                              uint64_t u0, uint32_t cnt, uint32_t lane) {
+    const dict_desc dd = a.dict.first;
+    const uint32_t hot_k = dd.hot_k;
+    const __amdgpu_buffer_rsrc_t rs_meta =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.dict.gmeta), 0, int(a.dict.gmeta_words * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_table =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.dict.gtable), 0, int(a.dict.gtable_words * 4), 0x00020000);
+
+    // ---- the units' descriptors, one per lane; lanes and outputs of each by one packed scan ----
+    const bool has = lane < cnt;
+    const dint_unit* up = a.units + u0 + (has ? lane : 0u);
+    const uint64_t my_in = up->in_off;
+    const uint32_t my_n = has ? up->n : 0u;
+    uint32_t nxt_lo = __shfl_down(uint32_t(my_in), 1), nxt_hi = __shfl_down(uint32_t(my_in >> 32), 1);
+    if (lane + 1 == cnt) {
+        const uint64_t e = u0 + cnt < a.n_units ? a.units[u0 + cnt].in_off : a.enc_bytes;
+        nxt_lo = uint32_t(e);
+        nxt_hi = uint32_t(e >> 32);
+    }
+    const uint64_t nxt_in = (uint64_t(nxt_hi) << 32) | nxt_lo;
+    const uint32_t my_lanes = has ? uint32_t((nxt_in - my_in + 7) >> 3) : 0u;  // 1..16 by the schedule's test
+    const uint32_t pk0 = my_n | (my_lanes << 16);
+    const uint32_t inc0 = wave_inclusive_sum(pk0);
+    const uint32_t my_lane0 = (inc0 - pk0) >> 16;      // first lane of this lane's unit
+    const uint32_t my_out0 = (inc0 - pk0) & 0xFFFFu;   // its first output, relative to the bundle
+    const uint32_t used = readlane(inc0, 63) >> 16;    // lanes in use, < 64
+    const uint32_t total = readlane(inc0, 63) & 0xFFFFu;
+    const uint64_t out0 = a.units[u0].out_off;
+    if (total == 0 || out0 + total > a.out_capacity) return;
+
+    // ---- lane -> unit: heads scattered into LDS, prefix maximum; then the unit's parameters ----
+    uint32_t* const map = scratch;  // the flag pairs' space, free until expand_tile
+    map[lane] = 0;
+    wave_lds_fence();
+    if (has) map[my_lane0] = lane + 1;
+    wave_lds_fence();
+    const uint32_t seg = wave_inclusive_max(map[lane]) - 1u;  // lane 0 is always a head
+    wave_lds_fence();
+    const bool lane_used = lane < used;
+    const int sl = int(seg);
+    const uint64_t seg_in = (uint64_t(uint32_t(__shfl(uint32_t(my_in >> 32), sl))) << 32) | uint32_t(__shfl(uint32_t(my_in), sl));
+    const uint32_t seg_n = __shfl(my_n, sl);
+    const uint32_t seg_lane0 = __shfl(my_lane0, sl);
+    const uint32_t seg_out0 = __shfl(my_out0, sl);
+    const bool seg_head = lane == seg_lane0;
+
+    // ---- slots and metadata ---------------------------------------------------------------------
+    tile_regs cur;
+    {
+        uint64_t raw = 0;
+        if (lane_used) {
+            const u32x2 r = reinterpret_cast<const u32x2_a1*>(a.enc + seg_in + 8u * (lane - seg_lane0))->v;
+            raw = (uint64_t(r.y) << 32) | r.x;
+        }
+        unpack_slots<16>(raw, cur);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k != kSPL; ++k) cur.m[k] = lds[cur.s[k] < hot_k ? dd.hot_base + cur.s[k] : 0u];
+    asm volatile("" : "+v"(cur.m[0]), "+v"(cur.m[1]), "+v"(cur.m[2]), "+v"(cur.m[3]));
+#pragma unroll
+    for (uint32_t k = 0; k != kSPL; ++k)
+        if (cur.s[k] >= hot_k) cur.m[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_meta, 4 * (dd.meta_base + cur.s[k]), 0, 0);
+
+    // ---- classification: as in decode_segment, the carries cut at every unit's first lane ----------
+    tile_slots t;
+    uint32_t row;
+    {
+        uint32_t lo = 0;
+#pragma unroll
+        for (uint32_t k = kSPL; k-- != 0;) lo = 3 * lo + (2u - (cur.s[k] < 2 ? cur.s[k] : 2u));
+        uint32_t st_in = 0;
+        for (;;) {
+            row = cls[st_in * 81 + lo];
+            uint32_t prev = __shfl_up((row >> 8) & 7u, 1);
+            if (seg_head) prev = 0;
+            if (__ballot(prev != st_in) == 0) break;
+            st_in = prev;
+        }
+    }
+    const uint32_t excbits = (row >> 4) & 15u;
+    t.tile_exc = __ballot(lane_used && excbits != 0) != 0;
+    if (t.tile_exc) {
+        const uint32_t nlo = __shfl_down((cur.s[1] << 16) | cur.s[0], 1);  // an exception's payload never leaves its unit's lanes
+        uint32_t e[kSPL + 2];
+#pragma unroll
+        for (uint32_t k = 0; k != kSPL; ++k) e[k] = cur.s[k];
+        e[kSPL] = nlo & 0xFFFFu;
+        e[kSPL + 1] = nlo >> 16;
+#pragma unroll
+        for (uint32_t k = 0; k != kSPL; ++k) t.excval[k] = e[k] == 0 ? e[k + 1] : (e[k + 1] | (e[k + 2] << 16));
+    }
+
+    // ---- sizes; positions inside each unit (one scan + the value at the unit's first lane); clamp ----
+    uint32_t sz4[kSPL];
+    const uint32_t usedM = lane_used ? ~0u : 0u;
+#pragma unroll
+    for (uint32_t k = 0; k != kSPL; ++k) {
+        const uint32_t m = cur.m[k];
+        const uint32_t payM = uint32_t(int32_t(row << (31 - k)) >> 31);
+        const uint32_t excM = uint32_t(int32_t(row << (27 - k)) >> 31);
+        sz4[k] = ((((m >> 22) & 0x3FCu) + 4u) & ~excM) | (4u & excM);
+        sz4[k] &= ~payM & usedM;
+        t.src4[k] = (m << 2) & 0x3FFFFFCu;
+        t.lit[k] = excM;
+        t.live[k] = ~payM & usedM;
+    }
+    t.lord[0] = 0;
+    t.lord[1] = (row >> 11) & 1u;
+    t.lord[2] = (row >> 12) & 3u;
+    t.lord[3] = (row >> 14) & 3u;
+    t.off4[0] = 0;
+#pragma unroll
+    for (uint32_t k = 1; k != kSPL; ++k) t.off4[k] = t.off4[k - 1] + sz4[k - 1];
+    const uint32_t raw_sum = (t.off4[kSPL - 1] + sz4[kSPL - 1]) >> 2;
+    const uint32_t inc1 = wave_inclusive_sum(raw_sum);
+    // (the read is unconditional: ds_bpermute returns nothing from lanes that do not take part)
+    const uint32_t inc1_before = uint32_t(__shfl(inc1, int(seg_lane0 + 63u) & 63));
+    const uint32_t before_seg = seg_lane0 == 0 ? 0u : inc1_before;
+    const uint32_t p0 = inc1 - raw_sum - before_seg;  // position of the lane's first codeword inside its unit
+    uint32_t nlive = 0, lsum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k != kSPL; ++k) {
+        const uint32_t pos = p0 + (t.off4[k] >> 2);
+        const bool act = t.live[k] != 0 && pos < seg_n;
+        const uint32_t room4 = 4 * (seg_n - pos);
+        sz4[k] = act ? (sz4[k] < room4 ? sz4[k] : room4) : 0u;
+        t.live[k] = act ? ~0u : 0u;
+        nlive += act ? 1u : 0u;
+        lsum += sz4[k] >> 2;
+    }
+    t.lsum = lsum;
+    t.nlive = nlive;
+    t.obase = seg_out0 + p0;
+    t.rbase = wave_inclusive_sum(nlive) - nlive;
+    t.total = total;
+
+    // ---- staging demand, as in decode_segment ---------------------------------------------------------
+#pragma unroll
+    for (uint32_t k = 0; k != kSPL; ++k) {
+        const uint32_t coldM = t.live[k] & ~t.lit[k] & (0u - ((t.src4[k] >> 25) & 1u));
+        t.pk[k] = (coldM & ((1u << 16) | ((sz4[k] + 12u) >> 4))) | (t.live[k] & t.lit[k] & 1u);
+    }
+    t.cpre[0] = 0;
+#pragma unroll
+    for (uint32_t k = 1; k != kSPL; ++k) t.cpre[k] = t.cpre[k - 1] + t.pk[k - 1];
+    t.cl = t.cpre[kSPL - 1] + t.pk[kSPL - 1];
+    t.tile_staged = __ballot(t.cl != 0) != 0;
+    uint32_t cexcl = 0;
+    if (t.tile_staged) cexcl = wave_inclusive_sum(t.cl) - t.cl;
+    t.qb = cexcl & 0xFFFFu;
+    t.wb = cexcl >> 16;
+
+#ifdef DINT_DEBUG_BUNDLE
+    if (u0 <= 3 && lane < 6)
+        printf("u0 %llu cnt %u lane %u seg %u in %llu n %u lane0 %u out0 %u | s %u %u %u %u row %x live %x %x %x %x sz %u %u %u %u p0 %u obase %u lsum %u nlive %u rbase %u exc %u %u %u %u pk %x %x %x %x total %u used %u\n",
+               (unsigned long long)u0, cnt, lane, seg, (unsigned long long)seg_in, seg_n, seg_lane0, seg_out0, cur.s[0], cur.s[1], cur.s[2], cur.s[3], row,
+               t.live[0] & 1, t.live[1] & 1, t.live[2] & 1, t.live[3] & 1, sz4[0], sz4[1], sz4[2], sz4[3], p0, t.obase, t.lsum, t.nlive, t.rbase,
+               t.excval[0], t.excval[1], t.excval[2], t.excval[3], t.pk[0], t.pk[1], t.pk[2], t.pk[3], total, used);
+#endif
+    // where each unit's stream ends: after its last live codeword (and that one's payload)
+    if (a.end_off) {
+        uint32_t last_end = 0;  // slots from the lane's first to the end of its last live codeword
+#pragma unroll
+        for (uint32_t k = 0; k != kSPL; ++k)
+            if (t.live[k] != 0) last_end = k + 1 + (((excbits >> k) & 1u) ? cur.s[k] + 1u : 0u);
+        if (has) a.end_off[u0 + lane] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (last_end != 0)
+            atomicMax(reinterpret_cast<unsigned long long*>(a.end_off + u0 + seg),
+                      (unsigned long long)(seg_in + 8ull * (lane - seg_lane0) + 2ull * last_end));
+    }
+
+    uint32_t* const out = a.out + out0;
+    const uint64_t out_bits = reinterpret_cast<uint64_t>(out);
+    uint32_t* const out_u = reinterpret_cast<uint32_t*>((uint64_t(uniform(uint32_t(out_bits >> 32))) << 32) |
+                                                        uniform(uint32_t(out_bits)));
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out_u, 0, int(total * 4), 0x00020000);
+    expand_tile<kRounds, kGroups>(t, 0u, lds, scratch, rs_table, rs_out, out, lane, []() {});
 }
 
 // A multi-dictionary unit: blocks of 256 integers (the last one shorter), each opened
@@ -903,6 +1203,9 @@ __device__ __forceinline__ void decode_kernel_body(const decode_args& a) {
         const uint64_t u = uint64_t(shard) + uint64_t(a.n_shards) * j;
         if (MULTI) {
             decode_unit_multi(a, lds, cls, scratch, u, lane);
+        } else if (a.sched && uniform(a.sched[u]) != 1u) {
+            const uint32_t cnt = uniform(a.sched[u]);
+            if (cnt != 0) decode_bundle(a, lds, cls, scratch, u, cnt, lane);  // 0: a member, its leader decodes it
         } else {
             uint64_t next_in = ~0ull;
             if (j_next < shard_units) next_in = a.units[uint64_t(shard) + uint64_t(a.n_shards) * j_next].in_off;

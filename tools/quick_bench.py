@@ -8,7 +8,8 @@ from dint_amd import host, device
 postings = int(float(sys.argv[1])) if len(sys.argv) > 1 else 200_000_000
 unit_ints = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 t = time.time()
-coll = host.synth_collection(postings, universe=25_000_000, seed=12345)
+min_len = int(os.environ.get("MIN_LEN", "1"))
+coll = host.synth_collection(postings, universe=25_000_000, seed=12345, min_len=min_len)
 print("generated", coll.num_postings, "postings in", len(coll.lens), "lists", round(time.time() - t, 1), "s", flush=True)
 t = time.time()
 dict_file = host.build_dictionary(host.SINGLE_PACKED, coll, max_sample_ints=20_000_000)
