@@ -172,3 +172,31 @@ def test_multi_blocks_use_both_codeword_widths(small_corpus):
     enc, units = small_corpus.encoded(host.MULTI_PACKED)
     sels = enc[units["in_off"].astype(np.int64)]
     assert (sels < 6).any() and (sels >= 6).any() and (sels < 12).all()
+
+
+@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.RECTANGULAR])
+@pytest.mark.parametrize("unit_ints", [1024, 16])
+def test_bundles_of_tiny_lists(device, kind, unit_ints):
+    """Collections made of tiny lists (the long tail of an inverted index): consecutive tiny units are
+    decoded several to a tile (decode_bundle). Same integers and end offsets as one unit at a time."""
+    import os
+
+    for seed, params in ((5, dict(max_len=70)), (6, dict(max_len=9)), (8, dict(max_len=300, universe=3_000_000))):
+        coll = host.synth_collection(60_000, seed=seed, **{"universe": 200_000, **params})
+        dict_file = host.build_dictionary(kind, coll)
+        enc, _ = host.encode_vroom(kind, dict_file, coll, unit_ints=unit_ints)
+        d = device.Dictionary(kind, dict_file)
+        units, total, _ = d.index_stream(enc, unit_ints)
+        out, ends, _ = device.decode_stream(d, enc, units, total)
+        assert np.array_equal(out, coll.gaps)
+        os.environ["DINT_NO_BUNDLES"] = "1"
+        try:
+            out1, ends1, _ = device.decode_stream(d, enc, units, total)
+        finally:
+            del os.environ["DINT_NO_BUNDLES"]
+        assert np.array_equal(out1, coll.gaps)
+        assert np.array_equal(ends, ends1)
+        # a unit ends where the next one starts, minus that list's header when it opens a new list
+        same_list = units["list"][1:] == units["list"][:-1]
+        assert np.array_equal(ends[:-1][same_list], units["in_off"][1:][same_list])
+        assert int(ends[-1]) == enc.size
