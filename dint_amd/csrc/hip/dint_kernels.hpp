@@ -1103,17 +1103,19 @@ __device__ __forceinline__ void decode_bundle(const decode_args& a, const uint32
                t.live[0] & 1, t.live[1] & 1, t.live[2] & 1, t.live[3] & 1, sz4[0], sz4[1], sz4[2], sz4[3], p0, t.obase, t.lsum, t.nlive, t.rbase,
                t.excval[0], t.excval[1], t.excval[2], t.excval[3], t.pk[0], t.pk[1], t.pk[2], t.pk[3], total, used);
 #endif
-    // where each unit's stream ends: after its last live codeword (and that one's payload)
+    // where each unit's stream ends: after its last live codeword (and that one's payload). That codeword
+    // sits in the unit's highest lane that has a live one: the next such lane belongs to another unit.
     if (a.end_off) {
         uint32_t last_end = 0;  // slots from the lane's first to the end of its last live codeword
 #pragma unroll
         for (uint32_t k = 0; k != kSPL; ++k)
             if (t.live[k] != 0) last_end = k + 1 + (((excbits >> k) & 1u) ? cur.s[k] + 1u : 0u);
-        if (has) a.end_off[u0 + lane] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        if (last_end != 0)
-            atomicMax(reinterpret_cast<unsigned long long*>(a.end_off + u0 + seg),
-                      (unsigned long long)(seg_in + 8ull * (lane - seg_lane0) + 2ull * last_end));
+        const uint64_t havers = __ballot(last_end != 0);
+        const uint64_t above = lane == 63 ? 0ull : havers & ~((2ull << lane) - 1ull);
+        const uint32_t next_lane = above ? uint32_t(__builtin_ctzll(above)) : lane;
+        const uint32_t next_seg = uint32_t(__shfl(seg, int(next_lane)));  // (unconditional: every lane takes part)
+        if (last_end != 0 && (above == 0 || next_seg != seg))
+            a.end_off[u0 + seg] = seg_in + 8ull * (lane - seg_lane0) + 2ull * last_end;
     }
 
     uint32_t* const out = a.out + out0;
