@@ -585,18 +585,33 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
     HIP_TRY(hipMemsetAsync(a.queue, 0, size_t(kQueueShards) * kQueueStride * 4, s));
     // tiny consecutive units are decoded several to a tile: schedule them (single-dictionary streams)
     a.sched = nullptr;
-    if (dd->kind != DINT_DICT_MULTI_PACKED && !only_full && n_units >= 2 && !std::getenv("DINT_NO_BUNDLES")) {
-        if (mut->sched_cap[slot] < n_units) {
+    a.items = nullptr;
+    a.n_items = nullptr;
+    if (dd->kind != DINT_DICT_MULTI_PACKED && !only_full && n_units >= 2 && n_units < 0xFFFFFFFFull &&
+        !std::getenv("DINT_NO_BUNDLES")) {
+        // workspace of the slot: [items u32 x n][block counts/offsets u32 x blocks][n_items u32][sched u8 x n]
+        const size_t n_blocks = (n_units + 255) / 256;
+        const size_t need = 4 * n_units + 4 * n_blocks + 4 + n_units;
+        if (mut->sched_cap[slot] < need) {
             if (mut->d_sched[slot]) HIP_TRY(hipFree(mut->d_sched[slot]));
             mut->d_sched[slot] = nullptr;
             mut->sched_cap[slot] = 0;
-            const size_t want = n_units + n_units / 4 + 1024;
+            const size_t want = need + need / 4 + 4096;
             HIP_TRY(hipMalloc(&mut->d_sched[slot], want));
             mut->sched_cap[slot] = want;
         }
-        hipLaunchKernelGGL(bundle_schedule_kernel, dim3(uint32_t((n_units + 255) / 256)), dim3(256), 0, s, d_units,
-                           uint64_t(n_units), uint64_t(enc_bytes), uint64_t(out_capacity), mut->d_sched[slot]);
-        a.sched = mut->d_sched[slot];
+        uint32_t* const d_items = reinterpret_cast<uint32_t*>(mut->d_sched[slot]);
+        uint32_t* const d_block = d_items + n_units;
+        uint32_t* const d_n_items = d_block + n_blocks;
+        uint8_t* const d_sch = reinterpret_cast<uint8_t*>(d_n_items + 1);
+        hipLaunchKernelGGL(bundle_schedule_kernel, dim3(uint32_t(n_blocks)), dim3(256), 0, s, d_units, uint64_t(n_units),
+                           uint64_t(enc_bytes), uint64_t(out_capacity), d_sch, d_block);
+        hipLaunchKernelGGL(bundle_offsets_kernel, dim3(1), dim3(1024), 0, s, d_block, uint32_t(n_blocks), d_n_items);
+        hipLaunchKernelGGL(bundle_items_kernel, dim3(uint32_t(n_blocks)), dim3(256), 0, s, d_sch, uint64_t(n_units), d_block,
+                           d_items);
+        a.sched = d_sch;
+        a.items = d_items;
+        a.n_items = d_n_items;
     }
     HIP_TRY(hipEventRecord(mut->ev_start, s));
     if (dd->kind == DINT_DICT_MULTI_PACKED)

@@ -126,6 +126,8 @@ struct decode_args {
     uint32_t only_full; // in-index path: decode units of exactly 256 integers only (tails are interpolative)
     const uint8_t* sched;  // nullable; per unit: 0 = member of a bundle led by an earlier unit, 1 = on its own,
                            // c > 1 = leads a bundle of c consecutive tiny units (bundle_schedule_kernel)
+    const uint32_t* items; // with sched: the units with sched != 0, in order — what the queue hands out
+    const uint32_t* n_items;
 };
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -897,7 +899,7 @@ constexpr uint32_t kBundleWindow = 48;     // lanes per bundle before the last u
 // Host-launched before the decode kernel: sched[i] for every unit (see decode_args::sched). One
 // workgroup per 256 units; bundles do not cross these blocks.
 __global__ __launch_bounds__(256) void bundle_schedule_kernel(const dint_unit* units, uint64_t n_units, uint64_t enc_bytes,
-                                                              uint64_t out_capacity, uint8_t* sched) {
+                                                              uint64_t out_capacity, uint8_t* sched, uint32_t* block_items) {
     __shared__ uint32_t lanes[256], pre[256];
     __shared__ uint8_t start[256];
     const uint32_t tid = threadIdx.x;
@@ -931,7 +933,8 @@ __global__ __launch_bounds__(256) void bundle_schedule_kernel(const dint_unit* u
         st = p / kBundleWindow != pp / kBundleWindow || out != units[i - 1].out_off + units[i - 1].n;
     }
     start[tid] = st ? 1 : 0;
-    __syncthreads();
+    const int starts = __syncthreads_count(st && i < n_units);
+    if (tid == 0) block_items[blockIdx.x] = uint32_t(starts);
     if (i >= n_units) return;
     uint32_t c = 0;
     if (st) {
@@ -940,6 +943,46 @@ __global__ __launch_bounds__(256) void bundle_schedule_kernel(const dint_unit* u
             while (tid + c < 256 && i + c < n_units && !start[tid + c]) ++c;
     }
     sched[i] = uint8_t(c);
+}
+
+// Work items = the units with sched != 0. block_items -> exclusive offsets (one workgroup), then every
+// block of 256 units writes its items.
+__global__ __launch_bounds__(1024) void bundle_offsets_kernel(uint32_t* block_items, uint32_t n_blocks, uint32_t* n_items) {
+    __shared__ uint32_t part[1024];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n_blocks; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n_blocks ? block_items[i] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024; d <<= 1) {
+            const uint32_t x = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+            __syncthreads();
+            part[threadIdx.x] += x;
+            __syncthreads();
+        }
+        if (i < n_blocks) block_items[i] = carry + part[threadIdx.x] - v;
+        carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_items = carry;
+}
+
+__global__ __launch_bounds__(256) void bundle_items_kernel(const uint8_t* sched, uint64_t n_units, const uint32_t* block_offsets,
+                                                           uint32_t* items) {
+    __shared__ uint32_t pre[256];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t i = uint64_t(blockIdx.x) * 256 + tid;
+    const uint32_t f = i < n_units && sched[i] != 0 ? 1u : 0u;
+    pre[tid] = f;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        const uint32_t v = tid >= d ? pre[tid - d] : 0;
+        __syncthreads();
+        pre[tid] += v;
+        __syncthreads();
+    }
+    if (f) items[block_offsets[blockIdx.x] + pre[tid] - 1] = uint32_t(i);
 }
 
 // One tile over `cnt` (2..64) consecutive tiny single-dictionary units starting at unit u0.
@@ -1192,7 +1235,15 @@ __device__ __forceinline__ void decode_kernel_body(const decode_args& a) {
     uint32_t* scratch = lds + a.dict.hot_words + kClassTableWords + wave * kScratchWords;
     const uint32_t shard = blockIdx.x % a.n_shards;  // n_shards = min(kQueueShards, gridDim.x)
     uint32_t* counter = a.queue + shard * kQueueStride;
-    const uint64_t shard_units = (a.n_units + a.n_shards - 1 - shard) / a.n_shards;
+    // with a schedule the queue hands out work items (bundle leaders and units on their own)
+    const uint64_t n_work = a.sched ? uint64_t(uniform(*a.n_items)) : a.n_units;
+#ifdef DINT_EXP_CONTIG_SHARDS  // experiment: every shard (XCD) walks its own contiguous eighth of the work
+    const uint64_t per_shard = (n_work + a.n_shards - 1) / a.n_shards;
+    const uint64_t shard_first = per_shard * shard;
+    const uint64_t shard_units = shard_first >= n_work ? 0 : (n_work - shard_first < per_shard ? n_work - shard_first : per_shard);
+#else
+    const uint64_t shard_units = (n_work + a.n_shards - 1 - shard) / a.n_shards;
+#endif
     auto draw = [&]() -> uint32_t {
         uint32_t j = 0;
         if (lane == 0) j = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1202,15 +1253,21 @@ __device__ __forceinline__ void decode_kernel_body(const decode_args& a) {
     uint32_t j = draw();
     while (j < shard_units) {
         const uint32_t j_next = draw();
-        const uint64_t u = uint64_t(shard) + uint64_t(a.n_shards) * j;
+#ifdef DINT_EXP_CONTIG_SHARDS
+        const uint64_t w = shard_first + j;
+#else
+        const uint64_t w = uint64_t(shard) + uint64_t(a.n_shards) * j;
+#endif
+        const uint64_t u = a.sched ? uint64_t(uniform(a.items[w])) : w;
+        const uint32_t cnt = a.sched ? uint32_t(uniform(a.sched[u])) : 1u;
         if (MULTI) {
             decode_unit_multi(a, lds, cls, scratch, u, lane);
-        } else if (a.sched && uniform(a.sched[u]) != 1u) {
-            const uint32_t cnt = uniform(a.sched[u]);
-            if (cnt != 0) decode_bundle(a, lds, cls, scratch, u, cnt, lane);  // 0: a member, its leader decodes it
+        } else if (cnt > 1) {
+            decode_bundle(a, lds, cls, scratch, u, cnt, lane);
         } else {
             uint64_t next_in = ~0ull;
-            if (j_next < shard_units) next_in = a.units[uint64_t(shard) + uint64_t(a.n_shards) * j_next].in_off;
+            if (DINT_UNIT_CHAIN && !a.sched && j_next < shard_units)
+                next_in = a.units[uint64_t(shard) + uint64_t(a.n_shards) * j_next].in_off;
             decode_unit_single(a, lds, cls, scratch, u, lane, ch, next_in);
         }
         j = j_next;
