@@ -371,7 +371,10 @@ __device__ __forceinline__ void expand_tile(const tile_slots& t, uint32_t out_in
         const uint32_t rend = readlane(t.rbase + t.nlive, last);
         const uint32_t qend = readlane(t.qb + (t.cl & 0xFFFFu), last);
         const uint32_t wend = readlane(t.wb + (t.cl >> 16), last);
-        if (bend <= done) break;                // (malformed input: nothing decodable left in this tile)
+        if (bend <= done) {  // (malformed input: nothing decodable left in this tile)
+            before_stores();  // every way out of the loop passes the caller's wait point
+            break;
+        }
         const uint32_t bt = bend - done;        // outputs in this batch, 1..kCap
         const uint32_t nfetch = wend - wdone;   // cold codewords to fetch, <= kStageQuads
         const uint32_t inbM = inb ? ~0u : 0u;
@@ -480,6 +483,12 @@ __device__ __forceinline__ void expand_tile(const tile_slots& t, uint32_t out_in
         }
         wave_lds_fence();
 
+        // the wait point of the tile: the staged data is in, nothing has been stored yet. The caller
+        // parks the waits for its own prefetches here and issues the next ones right behind them.
+        // (the fetch registers too, on every path: a load the compiler cannot prove consumed would make it
+        // wait wherever that register is next written — after the stores)
+        asm volatile("" : "+v"(q00), "+v"(q01), "+v"(q10), "+v"(q11));
+        before_stores();
         MARK("8_expand");
         // (d) expansion, GROUPS * 256 outputs per round: each lane takes 4 consecutive outputs of
         // every 256-output group; every source is an LDS byte address by now. Stores are whole
@@ -517,7 +526,6 @@ __device__ __forceinline__ void expand_tile(const tile_slots& t, uint32_t out_in
                 }
                 MARK("9_stores");
                 // the prefetched registers must have landed before the first store is issued
-                if (rd == 0) before_stores();
 #pragma unroll
                 for (uint32_t g = 0; g != GROUPS; ++g) {
                     const uint32_t p0 = (rd * GROUPS + g) * 4 * kWave + 4 * lane;
@@ -612,6 +620,14 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
 
     while (produced < n) {
         const uint32_t next_lo = uint32_t(raw1);  // first slots of the next tile (exception spill)
+        // The far prefetch — the slots of the tile after next, straight from HBM — goes out first: it has to
+        // be back before this tile's stores (every wait is a wait for everything), so it gets the whole tile.
+        // (Issued a third of a tile before the wait, it cost a fifth of the kernel time whenever the stream
+        // was not cached: any collection whose stream outgrows the 256 MB memory-side cache. Issuing it
+        // right after the previous wait instead would keep its register in flight across the loop's
+        // back edge, where the compiler copies it — and waits, after the stores.)
+        slot_byte += kTileBytes;
+        const uint64_t raw3 = load_lane_slots<W>(a.enc, slot_byte, lane, a.enc_bytes);
 
         // Perturbation experiments (timing only): which resource does the kernel sit on? Pad every tile
         // with N independent instructions of one class and watch the time.
@@ -809,12 +825,9 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
         // before the stores (vmcnt is one in-order counter for loads AND stores on gfx950: a wait
         // placed after the stores would also wait for their acknowledgements).
         // The last tile of a segment has no successor to prefetch; a chained one asks for the next block.
-        uint64_t raw3 = 0;
         if (!last_tile) {
             unpack_slots<W>(raw1, nxt);
             load_metas(nxt);
-            slot_byte += kTileBytes;
-            raw3 = load_lane_slots<W>(a.enc, slot_byte, lane, a.enc_bytes);
         } else {
 #pragma unroll
             for (uint32_t k = 0; k != kSPL; ++k) nxt.s[k] = nxt.m[k] = 0;
@@ -838,9 +851,11 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
         t.lsum = lsum, t.obase = obase, t.rbase = rbase, t.nlive = nlive, t.cl = cl, t.qb = qb, t.wb = wb;
         t.total = total, t.tile_exc = tile_exc, t.tile_staged = tile_staged;
         // the prefetched registers must have landed before the first store is issued
+        // ("+v": from here on the values are the asm's, not a load's — nothing for the compiler to wait for later)
+        uint64_t raw3w = raw3;
         expand_tile<ROUNDS, GROUPS>(t, produced, lds, scratch, rs_table, rs_out, out, lane, [&]() {
-            asm volatile("" ::"v"(raw3), "v"(nxt.m[0]), "v"(nxt.m[1]), "v"(nxt.m[2]), "v"(nxt.m[3]));
-            if (CHAINED) asm volatile("" ::"v"(ch.sel), "v"(ch.data.x), "v"(ch.data.y), "v"(ch.data.z), "v"(ch.data.w));
+            asm volatile("" : "+v"(raw3w), "+v"(nxt.m[0]), "+v"(nxt.m[1]), "+v"(nxt.m[2]), "+v"(nxt.m[3]));
+            if (CHAINED) asm volatile("" : "+v"(ch.sel), "+v"(ch.data.x), "+v"(ch.data.y), "+v"(ch.data.z), "+v"(ch.data.w));
         });
 
         MARK("10_rotate");
@@ -850,8 +865,8 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
 
         // ---- rotate the pipeline ---------------------------------------------------
         cur = nxt;
-        raw1 = CHAINED ? raw3 : raw2;
-        raw2 = raw3;
+        raw1 = CHAINED ? raw3w : raw2;
+        raw2 = raw3w;
     }
     MARK("epilogue");
     return tile_base + uint64_t(kSlotBytes) * end_slot;
@@ -1219,10 +1234,8 @@ __device__ __forceinline__ void decode_unit_multi(const decode_args& a, const ui
 // Units are handed out dynamically: their cost varies a lot (a sparse list full
 // of exceptions takes several times longer than a dense one of the same length),
 // so a static unit -> wave map leaves most of the chip idle behind the slowest
-// waves. kQueueShards counters (one per group of workgroups, blockIdx % 8 — the
-// workgroups that share an XCD under round-robin placement; a speed choice only)
-// each serve the units u = shard + n_shards * j; a wave draws its next index
-// while it is still decoding the current unit.
+// waves. kQueueShards counters, one per group of workgroups; a wave draws its next
+// work item while it is still decoding the current one.
 template <bool MULTI>
 __device__ __forceinline__ void decode_kernel_body(const decode_args& a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -1233,31 +1246,34 @@ __device__ __forceinline__ void decode_kernel_body(const decode_args& a) {
     const uint32_t lane = lane_id();
     const uint32_t wave = uniform(threadIdx.x / kWave);
     uint32_t* scratch = lds + a.dict.hot_words + kClassTableWords + wave * kScratchWords;
+    // Work queue. Every shard — the workgroups with the same blockIdx % n_shards: one XCD under
+    // round-robin placement — walks its own CONTIGUOUS part of the work items and, when that is done,
+    // helps with the next shards' parts. Contiguous, because an XCD that strides over the whole
+    // stream and output touches every 2 MB page of them, and past ~2 GB the translations no longer stay
+    // in its TLB (the time per integer rose by a fifth); stealing, because equal counts of work items
+    // are not equal work.
     const uint32_t shard = blockIdx.x % a.n_shards;  // n_shards = min(kQueueShards, gridDim.x)
-    uint32_t* counter = a.queue + shard * kQueueStride;
     // with a schedule the queue hands out work items (bundle leaders and units on their own)
     const uint64_t n_work = a.sched ? uint64_t(uniform(*a.n_items)) : a.n_units;
-#ifdef DINT_EXP_CONTIG_SHARDS  // experiment: every shard (XCD) walks its own contiguous eighth of the work
     const uint64_t per_shard = (n_work + a.n_shards - 1) / a.n_shards;
-    const uint64_t shard_first = per_shard * shard;
-    const uint64_t shard_units = shard_first >= n_work ? 0 : (n_work - shard_first < per_shard ? n_work - shard_first : per_shard);
-#else
-    const uint64_t shard_units = (n_work + a.n_shards - 1 - shard) / a.n_shards;
-#endif
-    auto draw = [&]() -> uint32_t {
-        uint32_t j = 0;
-        if (lane == 0) j = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return uniform(j);
+    uint32_t cur = shard, tried = 0;
+    auto draw = [&]() -> uint64_t {  // next work item, or ~0: nothing left anywhere
+        while (tried < a.n_shards) {
+            const uint64_t first = per_shard * cur;
+            const uint64_t size = first >= n_work ? 0 : (n_work - first < per_shard ? n_work - first : per_shard);
+            uint32_t j = 0;
+            if (lane == 0) j = __hip_atomic_fetch_add(a.queue + cur * kQueueStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            j = uniform(j);
+            if (j < size) return first + j;
+            cur = cur + 1 == a.n_shards ? 0 : cur + 1;
+            ++tried;
+        }
+        return ~0ull;
     };
     chain_io ch{};
-    uint32_t j = draw();
-    while (j < shard_units) {
-        const uint32_t j_next = draw();
-#ifdef DINT_EXP_CONTIG_SHARDS
-        const uint64_t w = shard_first + j;
-#else
-        const uint64_t w = uint64_t(shard) + uint64_t(a.n_shards) * j;
-#endif
+    uint64_t w = draw();
+    while (w != ~0ull) {
+        const uint64_t w_next = draw();
         const uint64_t u = a.sched ? uint64_t(uniform(a.items[w])) : w;
         const uint32_t cnt = a.sched ? uint32_t(uniform(a.sched[u])) : 1u;
         if (MULTI) {
@@ -1266,11 +1282,10 @@ __device__ __forceinline__ void decode_kernel_body(const decode_args& a) {
             decode_bundle(a, lds, cls, scratch, u, cnt, lane);
         } else {
             uint64_t next_in = ~0ull;
-            if (DINT_UNIT_CHAIN && !a.sched && j_next < shard_units)
-                next_in = a.units[uint64_t(shard) + uint64_t(a.n_shards) * j_next].in_off;
+            if (DINT_UNIT_CHAIN && !a.sched && w_next != ~0ull) next_in = a.units[w_next].in_off;
             decode_unit_single(a, lds, cls, scratch, u, lane, ch, next_in);
         }
-        j = j_next;
+        w = w_next;
     }
 }
 
