@@ -68,6 +68,9 @@ constexpr uint32_t kTileSlots = kWave * kSPL;         // 256 slots per tile
 #ifndef DINT_GROUPS
 #define DINT_GROUPS 2
 #endif
+#ifndef DINT_EARLY_METAS
+#define DINT_EARLY_METAS 0
+#endif
 #ifndef DINT_UNIT_CHAIN
 #define DINT_UNIT_CHAIN 0  // 1: single-dictionary units request their successor's first tiles (measured: no gain)
 #endif
@@ -628,6 +631,11 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
         // back edge, where the compiler copies it — and waits, after the stores.)
         slot_byte += kTileBytes;
         const uint64_t raw3 = load_lane_slots<W>(a.enc, slot_byte, lane, a.enc_bytes);
+#if DINT_EARLY_METAS
+        // the next tile's metadata too (L2 for its cold codewords): same reasoning
+        unpack_slots<W>(raw1, nxt);
+        load_metas(nxt);
+#endif
 
         // Perturbation experiments (timing only): which resource does the kernel sit on? Pad every tile
         // with N independent instructions of one class and watch the time.
@@ -826,8 +834,10 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
         // placed after the stores would also wait for their acknowledgements).
         // The last tile of a segment has no successor to prefetch; a chained one asks for the next block.
         if (!last_tile) {
+#if !DINT_EARLY_METAS
             unpack_slots<W>(raw1, nxt);
             load_metas(nxt);
+#endif
         } else {
 #pragma unroll
             for (uint32_t k = 0; k != kSPL; ++k) nxt.s[k] = nxt.m[k] = 0;
