@@ -1292,7 +1292,10 @@ __device__ __forceinline__ void decode_kernel_body(const decode_args& a) {
             decode_bundle(a, lds, cls, scratch, u, cnt, lane);
         } else {
             uint64_t next_in = ~0ull;
-            if (DINT_UNIT_CHAIN && !a.sched && w_next != ~0ull) next_in = a.units[w_next].in_off;
+            if (DINT_UNIT_CHAIN && w_next != ~0ull) {
+                const uint64_t un = a.sched ? uint64_t(uniform(a.items[w_next])) : w_next;
+                if (!a.sched || uniform(a.sched[un]) == 1u) next_in = a.units[un].in_off;
+            }
             decode_unit_single(a, lds, cls, scratch, u, lane, ch, next_in);
         }
         w = w_next;
