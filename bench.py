@@ -133,6 +133,8 @@ def main():
     out_dev = torch.empty(n_ints, dtype=torch.int32, device=dev)
     end_dev = torch.zeros(n_units, dtype=torch.int64, device=dev)
 
+    log(rank, f"device buffers: enc {enc_dev.data_ptr():#x} out {out_dev.data_ptr():#x} units {units_dev.data_ptr():#x}")
+
     def sync_all():
         if distributed:
             dist.barrier()
