@@ -200,3 +200,26 @@ def test_bundles_of_tiny_lists(device, kind, unit_ints):
         same_list = units["list"][1:] == units["list"][:-1]
         assert np.array_equal(ends[:-1][same_list], units["in_off"][1:][same_list])
         assert int(ends[-1]) == enc.size
+
+
+@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.RECTANGULAR, host.MULTI_PACKED])
+def test_seeded_sweep_of_small_collections(device, kind):
+    """Many small collections with different length / density mixes, unit sizes from one block to whole
+    lists: decoded integers and end offsets must equal the encoder's input and its byte layout."""
+    r = np.random.default_rng(1234 + kind)
+    for it in range(24):
+        postings = int(r.integers(2_000, 120_000))
+        universe = int(r.choice([5_000, 60_000, 1_000_000, 25_000_000]))
+        max_len = int(r.choice([8, 70, 300, 5_000, universe // 3 + 1]))
+        unit_ints = int(r.choice([0, 256, 300, 1024, 8192]))
+        coll = host.synth_collection(postings, seed=int(r.integers(1 << 30)), universe=universe, max_len=max(1, max_len))
+        dict_file = host.build_dictionary(kind, coll)
+        enc, _ = host.encode_vroom(kind, dict_file, coll, unit_ints=unit_ints, greedy=bool(it % 5 == 0))
+        d = device.Dictionary(kind, dict_file)
+        units, total, n_lists = d.index_stream(enc, unit_ints)
+        assert total == coll.num_postings and n_lists == np.count_nonzero(coll.lens)
+        out, ends, _ = device.decode_stream(d, enc, units, total)
+        assert np.array_equal(out, coll.gaps), (it, postings, universe, max_len, unit_ints)
+        same_list = units["list"][1:] == units["list"][:-1]
+        assert np.array_equal(ends[:-1][same_list], units["in_off"][1:][same_list])
+        assert int(ends[-1]) == enc.size
