@@ -4,34 +4,36 @@
 // (vroom_env/dint_codecs.hpp:37-107); how is unrelated to its one-codeword-at-a-
 // time loop:
 //
-//  * one 64-lane wavefront walks one unit (include/dint_hip.h) in TILES of
-//    64 * kSPL 16-bit slots; lane l owns the kSPL CONSECUTIVE slots kSPL*l ..
-//    (one unaligned load), so (lane, k) order is stream order is output order;
+//  * one 64-lane wavefront walks one work item — a unit (include/dint_hip.h), or a bundle of
+//    tiny units packed into one tile — in TILES of 64 * kSPL 16-bit slots; lane l owns the kSPL
+//    CONSECUTIVE slots kSPL*l .. (one unaligned load), so (lane, k) order is stream order is
+//    output order;
 //  * per slot one metadata word ((size-1) << 24 | payload offset): LDS for the hot
 //    codewords (a prefix of the dictionary), L2 for the cold ones, looked up one tile ahead;
-//  * header/payload classification costs nothing unless a tile holds a 0 or 1
-//    slot (or an exception straddles in); then a short per-lane state machine is
-//    iterated until the lane-to-lane carries agree (one or two rounds);
+//  * header/payload classification: a table-driven per-lane state machine, iterated until the
+//    lane-to-lane carries agree (one or two rounds); nothing to do in tiles without 0 / 1 slots;
 //  * a local prefix plus ONE DPP wave scan gives every codeword its output offset;
 //  * EXPANSION is output-centric: every codeword sets ONE bit at its first output
 //    position in a per-wave flag bitmap (ds_or) and stores `source - position` in
 //    a table indexed by its ordinal; a small scan over the bitmap's word
 //    popcounts gives per-word rank bases. Then each lane takes 4 consecutive
 //    output integers: flag word + rank base -> 4 ranks -> 4 table reads -> 4 LDS
-//    gathers -> one 16-byte store, so every global store instruction covers 1 KB of
-//    consecutive output. Every source is in LDS by then: hot payloads and the zero region
-//    of the runs live there; the COLD payloads of a batch are fetched once per codeword
-//    (a compact worklist, one 16-byte load per lane and quad, while the batch tables are
-//    being built) into per-wave staging cells, where the exception literals go too. The
-//    per-CU vector memory path (TA/TCP) is the scarce resource of this kernel: per-output
-//    4-byte gathers from L2 kept it busy 90% of the time (profiles/r01_pmc_ta_v8.txt). Exactly n integers are
-//    written per unit, nothing past them (the reference needs a pre-zeroed buffer
-//    and a 256-word overflow area, include/dint/dint_codecs.hpp:11,
-//    dict_posting_list.hpp:296).
+//    gathers -> one 16-byte non-temporal store, so every global store instruction covers
+//    1 KB of consecutive output. Every source is in LDS by then: hot payloads and the zero
+//    region of the runs live there; the COLD payloads of a batch are fetched once per
+//    codeword (a compact worklist, one 16-byte load per lane and quad, while the batch
+//    tables are being built) into per-wave staging cells, where the exception literals go
+//    too. Exactly n integers are written per unit, nothing past them (the reference needs a
+//    pre-zeroed buffer and a 256-word overflow area, include/dint/dint_codecs.hpp:11,
+//    dict_posting_list.hpp:296);
+//  * WAITS: gfx950 counts loads and stores in one in-order counter, so a tile has exactly one
+//    wait point — after its cold fetch, before its stores — where everything prefetched is
+//    consumed (read-write asm barriers, so that the compiler never adds a wait behind the
+//    stores, which would be a wait for their acknowledgements).
 //
 // LDS (160 KB/CU, one 1024-thread workgroup per CU):
 //   [ 256 zero words | hot meta | hot payloads ]  <= kHotImageWords, shared by 16 waves
-//   [ slot classification table, 4 KB ]
+//   [ slot classification table, 1.3 KB ]
 //   16 x [ {flag word, rank base} pairs | per-codeword delta table | staging cells ]
 #pragma once
 #include <hip/hip_runtime.h>
