@@ -919,14 +919,15 @@ __device__ __forceinline__ void decode_unit_single(const decode_args& a, const u
 // units into ONE tile: unit i takes ceil(bytes_i / 8) whole lanes, the front end runs segmented
 // (per-lane slot address, carries cut at unit starts, sizes clamped at each unit's n), and because
 // the units' outputs are consecutive the expansion is the ordinary one over the bundle's outputs.
-constexpr uint32_t kBundleMaxInts = 64;    // a unit is bundled only if it decodes to at most this many integers
-constexpr uint32_t kBundleMaxBytes = 128;  // ... and spans at most this many stream bytes (16 lanes)
-constexpr uint32_t kBundleWindow = 48;     // lanes per bundle before the last unit's (<= 16) are added
+constexpr uint32_t kBundleMaxInts = 256;   // a unit is bundled only if it decodes to at most this many integers
+constexpr uint32_t kBundleMaxBytes = 256;  // ... and spans at most this many stream bytes (32 lanes)
+constexpr uint32_t kBundleWindow = 32;     // lanes per bundle before the last unit's (<= 32) are added
 
 // Host-launched before the decode kernel: sched[i] for every unit (see decode_args::sched). One
 // workgroup per 256 units; bundles do not cross these blocks.
 __global__ __launch_bounds__(256) void bundle_schedule_kernel(const dint_unit* units, uint64_t n_units, uint64_t enc_bytes,
-                                                              uint64_t out_capacity, uint8_t* sched, uint32_t* block_items) {
+                                                              uint64_t out_capacity, uint32_t only_full, uint8_t* sched,
+                                                              uint32_t* block_items) {
     __shared__ uint32_t lanes[256], pre[256];
     __shared__ uint8_t start[256];
     const uint32_t tid = threadIdx.x;
@@ -939,7 +940,9 @@ __global__ __launch_bounds__(256) void bundle_schedule_kernel(const dint_unit* u
         out = units[i].out_off;
         n = units[i].n;
         const uint64_t nxt = i + 1 < n_units ? units[i + 1].in_off : enc_bytes;
-        if (n >= 1 && n <= kBundleMaxInts && nxt > in && nxt - in <= kBundleMaxBytes && out + n <= out_capacity) {
+        // (in-index launches decode only the full blocks; the other units stay on their own and are skipped)
+        if (n >= 1 && n <= kBundleMaxInts && (!only_full || n == 256) && nxt > in && nxt - in <= kBundleMaxBytes &&
+            out + n <= out_capacity) {
             const uint32_t l = uint32_t((nxt - in + 7) >> 3);
             if (in + 8ull * l <= enc_bytes) L = l;  // every lane's 8-byte load stays inside the buffer
         }
@@ -1034,7 +1037,7 @@ __device__ __forceinline__ void decode_bundle(const decode_args& a, const uint32
         nxt_hi = uint32_t(e >> 32);
     }
     const uint64_t nxt_in = (uint64_t(nxt_hi) << 32) | nxt_lo;
-    const uint32_t my_lanes = has ? uint32_t((nxt_in - my_in + 7) >> 3) : 0u;  // 1..16 by the schedule's test
+    const uint32_t my_lanes = has ? uint32_t((nxt_in - my_in + 7) >> 3) : 0u;  // 1..32 by the schedule's test
     const uint32_t pk0 = my_n | (my_lanes << 16);
     const uint32_t inc0 = wave_inclusive_sum(pk0);
     const uint32_t my_lane0 = (inc0 - pk0) >> 16;      // first lane of this lane's unit
