@@ -557,7 +557,7 @@ int dint_index_stream(const dint_dict* dd, const uint8_t* enc, size_t enc_bytes,
 
 static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_bytes, const dint_unit* d_units,
                          size_t n_units, uint32_t* d_out, size_t out_capacity, uint64_t* d_end_off, void* stream,
-                         uint32_t only_full) {
+                         uint32_t only_full, const uint32_t* d_spans = nullptr) {
     if (!dd) return DINT_ERR_ARG;
     if (n_units == 0) return DINT_OK;
     if (!d_enc || !d_units || !d_out || enc_bytes < 8) return DINT_ERR_ARG;  // slots are fetched 8 bytes at a time
@@ -587,6 +587,7 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
     a.sched = nullptr;
     a.items = nullptr;
     a.n_items = nullptr;
+    a.spans = d_spans;
     if (dd->kind != DINT_DICT_MULTI_PACKED && n_units >= 2 && n_units < 0xFFFFFFFFull &&
         !std::getenv("DINT_NO_BUNDLES")) {
         // workspace of the slot: [items u32 x n][block counts/offsets u32 x blocks][n_items u32][sched u8 x n]
@@ -604,7 +605,7 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
         uint32_t* const d_block = d_items + n_units;
         uint32_t* const d_n_items = d_block + n_blocks;
         uint8_t* const d_sch = reinterpret_cast<uint8_t*>(d_n_items + 1);
-        hipLaunchKernelGGL(bundle_schedule_kernel, dim3(uint32_t(n_blocks)), dim3(256), 0, s, d_units, uint64_t(n_units),
+        hipLaunchKernelGGL(bundle_schedule_kernel, dim3(uint32_t(n_blocks)), dim3(256), 0, s, d_units, d_spans, uint64_t(n_units),
                            uint64_t(enc_bytes), uint64_t(out_capacity), only_full, d_sch, d_block);
         hipLaunchKernelGGL(bundle_offsets_kernel, dim3(1), dim3(1024), 0, s, d_block, uint32_t(n_blocks), d_n_items);
         hipLaunchKernelGGL(bundle_items_kernel, dim3(uint32_t(n_blocks)), dim3(256), 0, s, d_sch, uint64_t(n_units), d_block,
@@ -688,11 +689,13 @@ int dint_decode_posting_blocks(const dint_dict* docs_dict, const dint_dict* freq
     hipStream_t s = static_cast<hipStream_t>(stream);
     dint_unit* d_units = nullptr;
     uint64_t* d_ends = nullptr;
+    uint32_t* d_spans = nullptr;
     int st = DINT_OK;
     auto cleanup = [&] {
         (void)hipStreamSynchronize(s);
         if (d_units) (void)hipFree(d_units);
         if (d_ends) (void)hipFree(d_ends);
+        if (d_spans) (void)hipFree(d_spans);
     };
 #define TRY_OR_CLEAN(call)            \
     do {                              \
@@ -703,18 +706,20 @@ int dint_decode_posting_blocks(const dint_dict* docs_dict, const dint_dict* freq
     } while (0)
     TRY_OR_CLEAN(hipMalloc(&d_units, n_blocks * sizeof(dint_unit)));
     TRY_OR_CLEAN(hipMalloc(&d_ends, n_blocks * sizeof(uint64_t)));
+    TRY_OR_CLEAN(hipMalloc(&d_spans, n_blocks * sizeof(uint32_t)));
     const uint32_t tb = 256;
     const uint32_t grid = uint32_t((n_blocks + tb - 1) / tb);
     // docs parts: full blocks through the DINT kernel, short ones through the interpolative decoder
-    hipLaunchKernelGGL(blocks_to_units_kernel, dim3(grid), dim3(tb), 0, s, d_blocks, nullptr, uint64_t(n_blocks), d_units);
-    st = launch_decode(docs_dict, d_index, index_bytes, d_units, n_blocks, d_docids, out_capacity, d_ends, s, 1);
+    hipLaunchKernelGGL(blocks_to_units_kernel, dim3(grid), dim3(tb), 0, s, d_blocks, nullptr, uint64_t(n_blocks),
+                       uint64_t(index_bytes), d_units, d_spans);
+    st = launch_decode(docs_dict, d_index, index_bytes, d_units, n_blocks, d_docids, out_capacity, d_ends, s, 1, d_spans);
     if (st == DINT_OK) {
         hipLaunchKernelGGL(interpolative_tails_kernel, dim3(grid), dim3(tb), 0, s, d_index, uint64_t(index_bytes),
                            d_blocks, nullptr, uint64_t(n_blocks), d_docids, uint64_t(out_capacity), d_ends);
         if (d_freqs) {  // freqs parts start where the docs parts ended
             hipLaunchKernelGGL(blocks_to_units_kernel, dim3(grid), dim3(tb), 0, s, d_blocks, d_ends,
-                               uint64_t(n_blocks), d_units);
-            st = launch_decode(freqs_dict, d_index, index_bytes, d_units, n_blocks, d_freqs, out_capacity, nullptr, s, 1);
+                               uint64_t(n_blocks), uint64_t(index_bytes), d_units, d_spans);
+            st = launch_decode(freqs_dict, d_index, index_bytes, d_units, n_blocks, d_freqs, out_capacity, nullptr, s, 1, d_spans);
             if (st == DINT_OK)
                 hipLaunchKernelGGL(interpolative_tails_kernel, dim3(grid), dim3(tb), 0, s, d_index,
                                    uint64_t(index_bytes), d_blocks, d_ends, uint64_t(n_blocks), d_freqs,
@@ -808,7 +813,8 @@ static int decode_doc_pages(dint_query_index* qi, size_t n_pages, uint32_t* d_ou
     const uint32_t tb = 256;
     const uint32_t grid = uint32_t((n_pages + tb - 1) / tb);
     const uint64_t cap = uint64_t(n_pages) * kPageSlots;
-    hipLaunchKernelGGL(blocks_to_units_kernel, dim3(grid), dim3(tb), 0, s, qi->sub.p, nullptr, uint64_t(n_pages), qi->units.p);
+    hipLaunchKernelGGL(blocks_to_units_kernel, dim3(grid), dim3(tb), 0, s, qi->sub.p, nullptr, uint64_t(n_pages),
+                       uint64_t(qi->index_bytes), qi->units.p, static_cast<uint32_t*>(nullptr));
     const int st = launch_decode(qi->docs, qi->d_index, qi->index_bytes, qi->units.p, n_pages, d_out, cap, nullptr, s, 1);
     if (st != DINT_OK) return st;
     hipLaunchKernelGGL(interpolative_tails_kernel, dim3(grid), dim3(tb), 0, s, qi->d_index, uint64_t(qi->index_bytes),

@@ -133,6 +133,7 @@ struct decode_args {
                            // c > 1 = leads a bundle of c consecutive tiny units (bundle_schedule_kernel)
     const uint32_t* items; // with sched: the units with sched != 0, in order — what the queue hands out
     const uint32_t* n_items;
+    const uint32_t* spans; // nullable; per unit an upper bound of its stream bytes (else: up to the next unit's start)
 };
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -925,9 +926,9 @@ constexpr uint32_t kBundleWindow = 32;     // lanes per bundle before the last u
 
 // Host-launched before the decode kernel: sched[i] for every unit (see decode_args::sched). One
 // workgroup per 256 units; bundles do not cross these blocks.
-__global__ __launch_bounds__(256) void bundle_schedule_kernel(const dint_unit* units, uint64_t n_units, uint64_t enc_bytes,
-                                                              uint64_t out_capacity, uint32_t only_full, uint8_t* sched,
-                                                              uint32_t* block_items) {
+__global__ __launch_bounds__(256) void bundle_schedule_kernel(const dint_unit* units, const uint32_t* spans, uint64_t n_units,
+                                                              uint64_t enc_bytes, uint64_t out_capacity, uint32_t only_full,
+                                                              uint8_t* sched, uint32_t* block_items) {
     __shared__ uint32_t lanes[256], pre[256];
     __shared__ uint8_t start[256];
     const uint32_t tid = threadIdx.x;
@@ -939,7 +940,7 @@ __global__ __launch_bounds__(256) void bundle_schedule_kernel(const dint_unit* u
         in = units[i].in_off;
         out = units[i].out_off;
         n = units[i].n;
-        const uint64_t nxt = i + 1 < n_units ? units[i + 1].in_off : enc_bytes;
+        const uint64_t nxt = spans ? in + spans[i] : (i + 1 < n_units ? units[i + 1].in_off : enc_bytes);
         // (in-index launches decode only the full blocks; the other units stay on their own and are skipped)
         if (n >= 1 && n <= kBundleMaxInts && (!only_full || n == 256) && nxt > in && nxt - in <= kBundleMaxBytes &&
             out + n <= out_capacity) {
@@ -1036,7 +1037,8 @@ __device__ __forceinline__ void decode_bundle(const decode_args& a, const uint32
         nxt_lo = uint32_t(e);
         nxt_hi = uint32_t(e >> 32);
     }
-    const uint64_t nxt_in = (uint64_t(nxt_hi) << 32) | nxt_lo;
+    uint64_t nxt_in = (uint64_t(nxt_hi) << 32) | nxt_lo;
+    if (a.spans && has) nxt_in = my_in + a.spans[u0 + lane];
     const uint32_t my_lanes = has ? uint32_t((nxt_in - my_in + 7) >> 3) : 0u;  // 1..32 by the schedule's test
     const uint32_t pk0 = my_n | (my_lanes << 16);
     const uint32_t inc0 = wave_inclusive_sum(pk0);
@@ -1322,11 +1324,16 @@ __global__ __launch_bounds__(kBlockThreads, DINT_MIN_WAVES) void decode_multi_ke
 // unit table for the docs parts (in_off from the block table) or for the freqs parts (in_off =
 // where the docs part ended)
 __global__ void blocks_to_units_kernel(const dint_block_ref* blocks, const uint64_t* docs_end, uint64_t n_blocks,
-                                       dint_unit* units) {
+                                       uint64_t index_bytes, dint_unit* units, uint32_t* spans) {
     const uint64_t b = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (b >= n_blocks) return;
     dint_unit u;
     u.in_off = docs_end ? docs_end[b] : blocks[b].in_off;
+    if (spans) {  // a part ends no later than where the next block of the table begins (exact for freqs parts)
+        const uint64_t nxt = b + 1 < n_blocks && blocks[b + 1].in_off > u.in_off ? blocks[b + 1].in_off : index_bytes;
+        const uint64_t sp = nxt > u.in_off ? nxt - u.in_off : 0;
+        spans[b] = sp > 0xFFFFFFFFull ? 0xFFFFFFFFu : uint32_t(sp);
+    }
     u.out_off = blocks[b].out_off;
     u.n = blocks[b].n;
     u.list = blocks[b].list;
