@@ -346,7 +346,7 @@ struct dint_query_index {
     uint32_t* d_rank = nullptr;     // n_blocks
     uint32_t* d_touched = nullptr;  // n_blocks
     uint32_t* d_n_touched = nullptr;
-    device_buffer<uint32_t> page_block, page_query, term_first, term_blocks, cand, target, probe;
+    device_buffer<uint32_t> page_block, page_query, term_first, term_blocks, cand, target, probe, tails;
     device_buffer<dint_block_ref> sub;
     device_buffer<dint_unit> units;
     device_buffer<unsigned long long> counts;
@@ -690,12 +690,14 @@ int dint_decode_posting_blocks(const dint_dict* docs_dict, const dint_dict* freq
     dint_unit* d_units = nullptr;
     uint64_t* d_ends = nullptr;
     uint32_t* d_spans = nullptr;
+    uint32_t* d_tails = nullptr;  // [n_blocks] indices of the short blocks, [n_blocks]: their number
     int st = DINT_OK;
     auto cleanup = [&] {
         (void)hipStreamSynchronize(s);
         if (d_units) (void)hipFree(d_units);
         if (d_ends) (void)hipFree(d_ends);
         if (d_spans) (void)hipFree(d_spans);
+        if (d_tails) (void)hipFree(d_tails);
     };
 #define TRY_OR_CLEAN(call)            \
     do {                              \
@@ -707,22 +709,25 @@ int dint_decode_posting_blocks(const dint_dict* docs_dict, const dint_dict* freq
     TRY_OR_CLEAN(hipMalloc(&d_units, n_blocks * sizeof(dint_unit)));
     TRY_OR_CLEAN(hipMalloc(&d_ends, n_blocks * sizeof(uint64_t)));
     TRY_OR_CLEAN(hipMalloc(&d_spans, n_blocks * sizeof(uint32_t)));
+    TRY_OR_CLEAN(hipMalloc(&d_tails, (n_blocks + 1) * sizeof(uint32_t)));
+    TRY_OR_CLEAN(hipMemsetAsync(d_tails + n_blocks, 0, 4, s));
     const uint32_t tb = 256;
     const uint32_t grid = uint32_t((n_blocks + tb - 1) / tb);
+    hipLaunchKernelGGL(collect_tails_kernel, dim3(grid), dim3(tb), 0, s, d_blocks, uint64_t(n_blocks), d_tails, d_tails + n_blocks);
     // docs parts: full blocks through the DINT kernel, short ones through the interpolative decoder
     hipLaunchKernelGGL(blocks_to_units_kernel, dim3(grid), dim3(tb), 0, s, d_blocks, nullptr, uint64_t(n_blocks),
                        uint64_t(index_bytes), d_units, d_spans);
     st = launch_decode(docs_dict, d_index, index_bytes, d_units, n_blocks, d_docids, out_capacity, d_ends, s, 1, d_spans);
     if (st == DINT_OK) {
         hipLaunchKernelGGL(interpolative_tails_kernel, dim3(grid), dim3(tb), 0, s, d_index, uint64_t(index_bytes),
-                           d_blocks, nullptr, uint64_t(n_blocks), d_docids, uint64_t(out_capacity), d_ends);
+                           d_blocks, nullptr, d_tails, d_tails + n_blocks, d_docids, uint64_t(out_capacity), d_ends);
         if (d_freqs) {  // freqs parts start where the docs parts ended
             hipLaunchKernelGGL(blocks_to_units_kernel, dim3(grid), dim3(tb), 0, s, d_blocks, d_ends,
                                uint64_t(n_blocks), uint64_t(index_bytes), d_units, d_spans);
             st = launch_decode(freqs_dict, d_index, index_bytes, d_units, n_blocks, d_freqs, out_capacity, nullptr, s, 1, d_spans);
             if (st == DINT_OK)
                 hipLaunchKernelGGL(interpolative_tails_kernel, dim3(grid), dim3(tb), 0, s, d_index,
-                                   uint64_t(index_bytes), d_blocks, d_ends, uint64_t(n_blocks), d_freqs,
+                                   uint64_t(index_bytes), d_blocks, d_ends, d_tails, d_tails + n_blocks, d_freqs,
                                    uint64_t(out_capacity), nullptr);
         }
     }
@@ -753,6 +758,7 @@ void dint_query_index_destroy(dint_query_index* qi) {
     qi->cand.release();
     qi->target.release();
     qi->probe.release();
+    qi->tails.release();
     qi->sub.release();
     qi->units.release();
     qi->counts.release();
@@ -817,8 +823,12 @@ static int decode_doc_pages(dint_query_index* qi, size_t n_pages, uint32_t* d_ou
                        uint64_t(qi->index_bytes), qi->units.p, static_cast<uint32_t*>(nullptr));
     const int st = launch_decode(qi->docs, qi->d_index, qi->index_bytes, qi->units.p, n_pages, d_out, cap, nullptr, s, 1);
     if (st != DINT_OK) return st;
+    if (!qi->tails.ensure(n_pages + 1)) return DINT_ERR_HIP;
+    HIP_TRY(hipMemsetAsync(qi->tails.p + n_pages, 0, 4, s));
+    hipLaunchKernelGGL(collect_tails_kernel, dim3(grid), dim3(tb), 0, s, qi->sub.p, uint64_t(n_pages), qi->tails.p,
+                       qi->tails.p + n_pages);
     hipLaunchKernelGGL(interpolative_tails_kernel, dim3(grid), dim3(tb), 0, s, qi->d_index, uint64_t(qi->index_bytes),
-                       qi->sub.p, nullptr, uint64_t(n_pages), d_out, cap, nullptr);
+                       qi->sub.p, nullptr, qi->tails.p, qi->tails.p + n_pages, d_out, cap, nullptr);
     const uint32_t wgrid = uint32_t((n_pages * kWave + tb - 1) / tb);
     hipLaunchKernelGGL(finalize_postings_kernel, dim3(wgrid), dim3(tb), 0, s, qi->sub.p, uint64_t(n_pages), d_out,
                        nullptr, cap);

@@ -1377,11 +1377,22 @@ struct tail_bits {
     }
 };
 
-__global__ void interpolative_tails_kernel(const uint8_t* index, uint64_t index_bytes, const dint_block_ref* blocks,
-                                           const uint64_t* docs_end, uint64_t n_blocks, uint32_t* out,
-                                           uint64_t out_capacity, uint64_t* end_off) {
+// The short blocks are one in fifteen of a block table; collected first, so that the bit-serial decoder
+// below runs with full wavefronts (scattered over the table, four active lanes per wave made every
+// wave last as long as its slowest decode).
+__global__ void collect_tails_kernel(const dint_block_ref* blocks, uint64_t n_blocks, uint32_t* tails, uint32_t* n_tails) {
     const uint64_t b = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (b >= n_blocks) return;
+    const uint32_t n = blocks[b].n;
+    if (n != 0 && n < 256) tails[atomicAdd(n_tails, 1u)] = uint32_t(b);
+}
+
+__global__ void interpolative_tails_kernel(const uint8_t* index, uint64_t index_bytes, const dint_block_ref* blocks,
+                                           const uint64_t* docs_end, const uint32_t* tails, const uint32_t* n_tails,
+                                           uint32_t* out, uint64_t out_capacity, uint64_t* end_off) {
+    const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= *n_tails) return;
+    const uint64_t b = tails[t];
     const uint32_t n = blocks[b].n;
     if (n == 0 || n >= 256 || blocks[b].out_off + n > out_capacity) return;
     uint64_t pos = docs_end ? docs_end[b] : blocks[b].in_off;
