@@ -1356,8 +1356,12 @@ struct tail_bits {
         if (!len) return 0;
         if (avail < len) {
             uint32_t w = 0;
-            for (uint32_t i = 0; i != 4; ++i)
-                if (byte + i < limit) w |= uint32_t(p[byte + i]) << (8 * i);
+            if (byte + 4 <= limit) {
+                w = reinterpret_cast<const u32_a1*>(p + byte)->v;  // one unaligned load
+            } else {
+                for (uint32_t i = 0; i != 4; ++i)
+                    if (byte + i < limit) w |= uint32_t(p[byte + i]) << (8 * i);
+            }
             byte += 4;
             buf |= uint64_t(w) << avail;
             avail += 32;
