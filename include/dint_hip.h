@@ -102,6 +102,10 @@ void dint_free(void* p);
  * overflow area — unlike the reference, dint_codecs.hpp:11). If d_end_off is
  * not NULL, d_end_off[u] receives the byte offset one past unit u's last
  * consumed byte (the reference's returned `in` pointer).
+ * Units may come in any order; runs of table-consecutive tiny units (<= 256
+ * integers, <= 256 stream bytes up to the next unit's start, consecutive
+ * outputs — the long tail of short posting lists) are decoded several to a
+ * wavefront tile, which changes the speed, never the result.
  * Replaces: single_dint::decode / multi_opt_dint::decode
  *           (vroom_env/dint_codecs.hpp:37-107, :521-619). */
 int dint_decode_units(const dint_dict* dict, const uint8_t* d_enc, size_t enc_bytes,
