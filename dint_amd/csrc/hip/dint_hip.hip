@@ -588,7 +588,7 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
     a.items = nullptr;
     a.n_items = nullptr;
     a.spans = d_spans;
-    if (dd->kind != DINT_DICT_MULTI_PACKED && n_units >= 2 && n_units < 0xFFFFFFFFull &&
+    if (n_units >= 2 && n_units < 0xFFFFFFFFull &&
         !std::getenv("DINT_NO_BUNDLES")) {
         // workspace of the slot: [items u32 x n][block counts/offsets u32 x blocks][n_items u32][sched u8 x n]
         const size_t n_blocks = (n_units + 255) / 256;
@@ -606,7 +606,8 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
         uint32_t* const d_n_items = d_block + n_blocks;
         uint8_t* const d_sch = reinterpret_cast<uint8_t*>(d_n_items + 1);
         hipLaunchKernelGGL(bundle_schedule_kernel, dim3(uint32_t(n_blocks)), dim3(256), 0, s, d_units, d_spans, uint64_t(n_units),
-                           uint64_t(enc_bytes), uint64_t(out_capacity), only_full, d_sch, d_block);
+                           d_enc, uint64_t(enc_bytes), uint64_t(out_capacity), only_full,
+                           uint32_t(dd->kind == DINT_DICT_MULTI_PACKED), d_sch, d_block);
         hipLaunchKernelGGL(bundle_offsets_kernel, dim3(1), dim3(1024), 0, s, d_block, uint32_t(n_blocks), d_n_items);
         hipLaunchKernelGGL(bundle_items_kernel, dim3(uint32_t(n_blocks)), dim3(256), 0, s, d_sch, uint64_t(n_units), d_block,
                            d_items);

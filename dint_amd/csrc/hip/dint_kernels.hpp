@@ -922,13 +922,13 @@ __device__ __forceinline__ void decode_unit_single(const decode_args& a, const u
 // the units' outputs are consecutive the expansion is the ordinary one over the bundle's outputs.
 constexpr uint32_t kBundleMaxInts = 256;   // a unit is bundled only if it decodes to at most this many integers
 constexpr uint32_t kBundleMaxBytes = 256;  // ... and spans at most this many stream bytes (32 lanes)
-constexpr uint32_t kBundleWindow = 32;     // lanes per bundle before the last unit's (<= 32) are added
 
 // Host-launched before the decode kernel: sched[i] for every unit (see decode_args::sched). One
 // workgroup per 256 units; bundles do not cross these blocks.
 __global__ __launch_bounds__(256) void bundle_schedule_kernel(const dint_unit* units, const uint32_t* spans, uint64_t n_units,
-                                                              uint64_t enc_bytes, uint64_t out_capacity, uint32_t only_full,
-                                                              uint8_t* sched, uint32_t* block_items) {
+                                                              const uint8_t* enc, uint64_t enc_bytes, uint64_t out_capacity,
+                                                              uint32_t only_full, uint32_t multi, uint8_t* sched,
+                                                              uint32_t* block_items) {
     __shared__ uint32_t lanes[256], pre[256];
     __shared__ uint8_t start[256];
     const uint32_t tid = threadIdx.x;
@@ -944,26 +944,36 @@ __global__ __launch_bounds__(256) void bundle_schedule_kernel(const dint_unit* u
         // (in-index launches decode only the full blocks; the other units stay on their own and are skipped)
         if (n >= 1 && n <= kBundleMaxInts && (!only_full || n == 256) && nxt > in && nxt - in <= kBundleMaxBytes &&
             out + n <= out_capacity) {
-            const uint32_t l = uint32_t((nxt - in + 7) >> 3);
-            if (in + 8ull * l <= enc_bytes) L = l;  // every lane's 8-byte load stays inside the buffer
+            if (!multi) {
+                const uint32_t l = uint32_t((nxt - in + 7) >> 3);
+                if (in + 8ull * l <= enc_bytes) L = l;  // every lane's 8-byte load stays inside the buffer
+            } else {
+                // a multi unit of <= 256 integers is one block: selector byte, then 16- or 8-bit slots
+                // (4 to a lane: 8 or 4 bytes); every lane still loads 8 bytes
+                const uint32_t sel = enc[in];
+                const uint32_t stride = sel >= 6 ? 4u : 8u;
+                const uint32_t l = uint32_t((nxt - in - 1 + stride - 1) / stride);
+                if (sel < 12 && l >= 1 && l <= 32 && in + 1 + uint64_t(stride) * l + 8 <= enc_bytes) L = l;
+            }
         }
     }
     lanes[tid] = L;
-    pre[tid] = L;
+    // does this unit continue the previous one (both eligible, outputs consecutive)?
+    pre[tid] = (L != 0 && tid != 0 && i < n_units && out == units[i - 1].out_off + units[i - 1].n) ? 1u : 0u;
     __syncthreads();
-    for (uint32_t d = 1; d < 256; d <<= 1) {  // inclusive scan
-        const uint32_t v = tid >= d ? pre[tid - d] : 0;
-        __syncthreads();
-        pre[tid] += v;
-        __syncthreads();
+    // greedy packing, one thread per block of 256 units: a bundle takes units while their lanes fit a wave
+    if (tid == 0) {
+        uint32_t in_use = 0, members = 0;
+        for (uint32_t j = 0; j != 256; ++j) {
+            const uint32_t l = lanes[j];
+            const bool cont = l != 0 && j != 0 && lanes[j - 1] != 0 && pre[j] != 0 && in_use + l <= kWave - 1 && members < kWave;
+            start[j] = cont ? 0 : 1;
+            in_use = cont ? in_use + l : l;
+            members = cont ? members + 1 : 1;
+        }
     }
-    const uint32_t p = pre[tid] - L;  // lanes of the eligible units before this one in the block
-    bool st = true;
-    if (L != 0 && tid != 0 && lanes[tid - 1] != 0) {
-        const uint32_t pp = pre[tid - 1] - lanes[tid - 1];
-        st = p / kBundleWindow != pp / kBundleWindow || out != units[i - 1].out_off + units[i - 1].n;
-    }
-    start[tid] = st ? 1 : 0;
+    __syncthreads();
+    const bool st = start[tid] != 0;
     const int starts = __syncthreads_count(st && i < n_units);
     if (tid == 0) block_items[blockIdx.x] = uint32_t(starts);
     if (i >= n_units) return;
@@ -1016,11 +1026,12 @@ __global__ __launch_bounds__(256) void bundle_items_kernel(const uint8_t* sched,
     if (f) items[block_offsets[blockIdx.x] + pre[tid] - 1] = uint32_t(i);
 }
 
-// One tile over `cnt` (2..64) consecutive tiny single-dictionary units starting at unit u0.
+// One tile over `cnt` (2..64) consecutive tiny units starting at unit u0. MULTI: every unit is one block
+// of a multi-dictionary stream — its selector byte picks the dictionary and the slot width, per unit,
+// hence per lane.
+template <bool MULTI>
 __device__ __forceinline__ void decode_bundle(const decode_args& a, const uint32_t* lds, const uint16_t* cls, uint32_t* scratch,
                                               uint64_t u0, uint32_t cnt, uint32_t lane) {
-    const dict_desc dd = a.dict.first;
-    const uint32_t hot_k = dd.hot_k;
     const __amdgpu_buffer_rsrc_t rs_meta =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.dict.gmeta), 0, int(a.dict.gmeta_words * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_table =
@@ -1039,7 +1050,19 @@ __device__ __forceinline__ void decode_bundle(const decode_args& a, const uint32
     }
     uint64_t nxt_in = (uint64_t(nxt_hi) << 32) | nxt_lo;
     if (a.spans && has) nxt_in = my_in + a.spans[u0 + lane];
-    const uint32_t my_lanes = has ? uint32_t((nxt_in - my_in + 7) >> 3) : 0u;  // 1..32 by the schedule's test
+    // the unit's dictionary and slot width (MULTI: from its selector byte)
+    uint32_t my_narrow = 0, my_hot_base = a.dict.first.hot_base, my_hot_k = a.dict.first.hot_k, my_meta_base = a.dict.first.meta_base;
+    uint32_t my_lanes = has ? uint32_t((nxt_in - my_in + 7) >> 3) : 0u;  // 1..32 by the schedule's test
+    if (MULTI) {
+        const uint32_t sel = has ? uint32_t(a.enc[my_in]) : 0u;
+        my_narrow = sel >= 6 ? 1u : 0u;
+        const dict_desc* dp = a.dict.descs + (my_narrow ? sel - 6 : sel) % 6;
+        my_hot_base = dp->hot_base;
+        my_hot_k = dp->hot_k;
+        my_meta_base = dp->meta_base;
+        const uint32_t stride = my_narrow ? 4u : 8u;
+        my_lanes = has ? uint32_t((nxt_in - my_in - 1 + stride - 1) / stride) : 0u;
+    }
     const uint32_t pk0 = my_n | (my_lanes << 16);
     const uint32_t inc0 = wave_inclusive_sum(pk0);
     const uint32_t my_lane0 = (inc0 - pk0) >> 16;      // first lane of this lane's unit
@@ -1064,23 +1087,35 @@ __device__ __forceinline__ void decode_bundle(const decode_args& a, const uint32
     const uint32_t seg_lane0 = __shfl(my_lane0, sl);
     const uint32_t seg_out0 = __shfl(my_out0, sl);
     const bool seg_head = lane == seg_lane0;
+    const bool narrow = MULTI && __shfl(my_narrow, sl) != 0;
+    const uint32_t hot_base = MULTI ? uint32_t(__shfl(my_hot_base, sl)) : my_hot_base;
+    const uint32_t hot_k = MULTI ? uint32_t(__shfl(my_hot_k, sl)) : my_hot_k;
+    const uint32_t meta_base = MULTI ? uint32_t(__shfl(my_meta_base, sl)) : my_meta_base;
+    const uint64_t slot0 = seg_in + (MULTI ? 1u : 0u);          // the unit's first slot
+    const uint32_t stride = narrow ? 4u : 8u;                    // stream bytes per lane
 
     // ---- slots and metadata ---------------------------------------------------------------------
     tile_regs cur;
+    uint32_t raw_lo = 0;  // the lane's first four bytes (the next lane's: what an exception at its end spills into)
     {
         uint64_t raw = 0;
         if (lane_used) {
-            const u32x2 r = reinterpret_cast<const u32x2_a1*>(a.enc + seg_in + 8u * (lane - seg_lane0))->v;
+            const u32x2 r = reinterpret_cast<const u32x2_a1*>(a.enc + slot0 + stride * (lane - seg_lane0))->v;
             raw = (uint64_t(r.y) << 32) | r.x;
         }
+        raw_lo = uint32_t(raw);
         unpack_slots<16>(raw, cur);
+        if (MULTI && narrow) {
+#pragma unroll
+            for (uint32_t k = 0; k != kSPL; ++k) cur.s[k] = (raw_lo >> (8 * k)) & 0xFFu;
+        }
     }
 #pragma unroll
-    for (uint32_t k = 0; k != kSPL; ++k) cur.m[k] = lds[cur.s[k] < hot_k ? dd.hot_base + cur.s[k] : 0u];
+    for (uint32_t k = 0; k != kSPL; ++k) cur.m[k] = lds[cur.s[k] < hot_k ? hot_base + cur.s[k] : 0u];
     asm volatile("" : "+v"(cur.m[0]), "+v"(cur.m[1]), "+v"(cur.m[2]), "+v"(cur.m[3]));
 #pragma unroll
     for (uint32_t k = 0; k != kSPL; ++k)
-        if (cur.s[k] >= hot_k) cur.m[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_meta, 4 * (dd.meta_base + cur.s[k]), 0, 0);
+        if (cur.s[k] >= hot_k) cur.m[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_meta, 4 * (meta_base + cur.s[k]), 0, 0);
 
     // ---- classification: as in decode_segment, the carries cut at every unit's first lane ----------
     tile_slots t;
@@ -1090,8 +1125,9 @@ __device__ __forceinline__ void decode_bundle(const decode_args& a, const uint32
 #pragma unroll
         for (uint32_t k = kSPL; k-- != 0;) lo = 3 * lo + (2u - (cur.s[k] < 2 ? cur.s[k] : 2u));
         uint32_t st_in = 0;
+        const uint32_t rows_at = narrow ? kRows16 : 0u;  // the 8-bit rows follow the 16-bit ones
         for (;;) {
-            row = cls[st_in * 81 + lo];
+            row = cls[rows_at + st_in * 81 + lo];
             uint32_t prev = __shfl_up((row >> 8) & 7u, 1);
             if (seg_head) prev = 0;
             if (__ballot(prev != st_in) == 0) break;
@@ -1101,7 +1137,7 @@ __device__ __forceinline__ void decode_bundle(const decode_args& a, const uint32
     const uint32_t excbits = (row >> 4) & 15u;
     t.tile_exc = __ballot(lane_used && excbits != 0) != 0;
     if (t.tile_exc) {
-        const uint32_t nlo = __shfl_down((cur.s[1] << 16) | cur.s[0], 1);  // an exception's payload never leaves its unit's lanes
+        const uint32_t nlo = __shfl_down(raw_lo, 1);  // an exception's payload never leaves its unit's lanes
         uint32_t e[kSPL + 2];
 #pragma unroll
         for (uint32_t k = 0; k != kSPL; ++k) e[k] = cur.s[k];
@@ -1109,6 +1145,18 @@ __device__ __forceinline__ void decode_bundle(const decode_args& a, const uint32
         e[kSPL + 1] = nlo >> 16;
 #pragma unroll
         for (uint32_t k = 0; k != kSPL; ++k) t.excval[k] = e[k] == 0 ? e[k + 1] : (e[k + 1] | (e[k + 2] << 16));
+        if (MULTI && narrow) {  // 8-bit slots: the value is the next 2 or 4 of them
+            uint32_t b[kSPL + 4];
+#pragma unroll
+            for (uint32_t k = 0; k != kSPL; ++k) b[k] = cur.s[k];
+#pragma unroll
+            for (uint32_t k = 0; k != 4; ++k) b[kSPL + k] = (nlo >> (8 * k)) & 0xFFu;
+#pragma unroll
+            for (uint32_t k = 0; k != kSPL; ++k) {
+                const uint32_t lo16 = b[k + 1] | (b[k + 2] << 8);
+                t.excval[k] = b[k] == 0 ? lo16 : (lo16 | (b[k + 3] << 16) | (b[k + 4] << 24));
+            }
+        }
     }
 
     // ---- sizes; positions inside each unit (one scan + the value at the unit's first lane); clamp ----
@@ -1184,13 +1232,14 @@ __device__ __forceinline__ void decode_bundle(const decode_args& a, const uint32
         uint32_t last_end = 0;  // slots from the lane's first to the end of its last live codeword
 #pragma unroll
         for (uint32_t k = 0; k != kSPL; ++k)
-            if (t.live[k] != 0) last_end = k + 1 + (((excbits >> k) & 1u) ? cur.s[k] + 1u : 0u);
+            if (t.live[k] != 0)
+                last_end = k + 1 + (((excbits >> k) & 1u) ? (narrow ? 2 * cur.s[k] + 2u : cur.s[k] + 1u) : 0u);
         const uint64_t havers = __ballot(last_end != 0);
         const uint64_t above = lane == 63 ? 0ull : havers & ~((2ull << lane) - 1ull);
         const uint32_t next_lane = above ? uint32_t(__builtin_ctzll(above)) : lane;
         const uint32_t next_seg = uint32_t(__shfl(seg, int(next_lane)));  // (unconditional: every lane takes part)
         if (last_end != 0 && (above == 0 || next_seg != seg))
-            a.end_off[u0 + seg] = seg_in + 8ull * (lane - seg_lane0) + 2ull * last_end;
+            a.end_off[u0 + seg] = slot0 + uint64_t(stride) * (lane - seg_lane0) + (narrow ? 1ull : 2ull) * last_end;
     }
 
     uint32_t* const out = a.out + out0;
@@ -1294,9 +1343,10 @@ __device__ __forceinline__ void decode_kernel_body(const decode_args& a) {
         const uint64_t u = a.sched ? uint64_t(uniform(a.items[w])) : w;
         const uint32_t cnt = a.sched ? uint32_t(uniform(a.sched[u])) : 1u;
         if (MULTI) {
-            decode_unit_multi(a, lds, cls, scratch, u, lane);
+            if (cnt > 1) decode_bundle<true>(a, lds, cls, scratch, u, cnt, lane);
+            else decode_unit_multi(a, lds, cls, scratch, u, lane);
         } else if (cnt > 1) {
-            decode_bundle(a, lds, cls, scratch, u, cnt, lane);
+            decode_bundle<false>(a, lds, cls, scratch, u, cnt, lane);
         } else {
             uint64_t next_in = ~0ull;
             if (DINT_UNIT_CHAIN && w_next != ~0ull) {

@@ -13,7 +13,8 @@ for typ in ("single_rect_dint", "single_packed_dint", "multi_packed_dint"):
     kind = host.KIND_BY_TYPE[typ]
     t = time.time()
     d_file = host.build_dictionary(kind, coll, max_sample_ints=20_000_000)
-    enc, units = host.encode_vroom(kind, d_file, coll, unit_ints=8192)
+    # multi: one block per unit, so that consecutive blocks are bundled several to a tile
+    enc, units = host.encode_vroom(kind, d_file, coll, unit_ints=256 if kind == host.MULTI_PACKED else 8192)
     d = device.Dictionary(kind, d_file)
     enc_dev = torch.from_numpy(enc).to(dev); units_dev = device.units_to_device(units, dev)
     out_dev = torch.empty(coll.num_postings, dtype=torch.int32, device=dev)
