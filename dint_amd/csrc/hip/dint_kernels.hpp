@@ -962,14 +962,18 @@ __global__ __launch_bounds__(256) void bundle_schedule_kernel(const dint_unit* u
     pre[tid] = (L != 0 && tid != 0 && i < n_units && out == units[i - 1].out_off + units[i - 1].n) ? 1u : 0u;
     __syncthreads();
     // greedy packing, one thread per block of 256 units: a bundle takes units while their lanes fit a wave
-    if (tid == 0) {
-        uint32_t in_use = 0, members = 0;
-        for (uint32_t j = 0; j != 256; ++j) {
+    // (four threads, 64 units each — a bundle does not cross these quarters; the chain through in_use is
+    // the only serial part, the LDS reads are unrolled ahead of it)
+    if ((tid & 63u) == 0) {
+        uint32_t in_use = 0, members = 0, prev_l = 0;
+#pragma unroll 16
+        for (uint32_t j = tid; j != tid + 64; ++j) {
             const uint32_t l = lanes[j];
-            const bool cont = l != 0 && j != 0 && lanes[j - 1] != 0 && pre[j] != 0 && in_use + l <= kWave - 1 && members < kWave;
+            const bool cont = l != 0 && prev_l != 0 && pre[j] != 0 && in_use + l <= kWave - 1 && members < kWave;
             start[j] = cont ? 0 : 1;
             in_use = cont ? in_use + l : l;
             members = cont ? members + 1 : 1;
+            prev_l = l;
         }
     }
     __syncthreads();
