@@ -557,7 +557,7 @@ int dint_index_stream(const dint_dict* dd, const uint8_t* enc, size_t enc_bytes,
 
 static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_bytes, const dint_unit* d_units,
                          size_t n_units, uint32_t* d_out, size_t out_capacity, uint64_t* d_end_off, void* stream,
-                         uint32_t only_full, const uint32_t* d_spans = nullptr) {
+                         uint32_t only_full, const uint32_t* d_spans = nullptr, uint32_t plus_one = 0) {
     if (!dd) return DINT_ERR_ARG;
     if (n_units == 0) return DINT_OK;
     if (!d_enc || !d_units || !d_out || enc_bytes < 8) return DINT_ERR_ARG;  // slots are fetched 8 bytes at a time
@@ -572,6 +572,7 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
     a.out_capacity = out_capacity;
     a.end_off = d_end_off;
     a.only_full = only_full;
+    a.plus_one = plus_one;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint64_t blocks_needed = (uint64_t(n_units) + kWavesPerBlock - 1) / kWavesPerBlock;
     const uint32_t grid = uint32_t(std::min<uint64_t>(blocks_needed, std::max<uint32_t>(1, dd->compute_units) * kBlocksPerCU));
@@ -721,21 +722,22 @@ int dint_decode_posting_blocks(const dint_dict* docs_dict, const dint_dict* freq
     st = launch_decode(docs_dict, d_index, index_bytes, d_units, n_blocks, d_docids, out_capacity, d_ends, s, 1, d_spans);
     if (st == DINT_OK) {
         hipLaunchKernelGGL(interpolative_tails_kernel, dim3(grid), dim3(tb), 0, s, d_index, uint64_t(index_bytes),
-                           d_blocks, nullptr, d_tails, d_tails + n_blocks, d_docids, uint64_t(out_capacity), d_ends);
+                           d_blocks, nullptr, d_tails, d_tails + n_blocks, d_docids, uint64_t(out_capacity), d_ends, 0u);
         if (d_freqs) {  // freqs parts start where the docs parts ended
             hipLaunchKernelGGL(blocks_to_units_kernel, dim3(grid), dim3(tb), 0, s, d_blocks, d_ends,
                                uint64_t(n_blocks), uint64_t(index_bytes), d_units, d_spans);
-            st = launch_decode(freqs_dict, d_index, index_bytes, d_units, n_blocks, d_freqs, out_capacity, nullptr, s, 1, d_spans);
+            // (freq = decoded value + 1, dict_posting_list.hpp:164-169: added where the values are stored)
+            st = launch_decode(freqs_dict, d_index, index_bytes, d_units, n_blocks, d_freqs, out_capacity, nullptr, s, 1, d_spans, 1);
             if (st == DINT_OK)
                 hipLaunchKernelGGL(interpolative_tails_kernel, dim3(grid), dim3(tb), 0, s, d_index,
                                    uint64_t(index_bytes), d_blocks, d_ends, d_tails, d_tails + n_blocks, d_freqs,
-                                   uint64_t(out_capacity), nullptr);
+                                   uint64_t(out_capacity), nullptr, 1u);
         }
     }
     if (st == DINT_OK) {
         const uint32_t wgrid = uint32_t((n_blocks * kWave + tb - 1) / tb);
         hipLaunchKernelGGL(finalize_postings_kernel, dim3(wgrid), dim3(tb), 0, s, d_blocks, uint64_t(n_blocks),
-                           d_docids, d_freqs, uint64_t(out_capacity));
+                           d_docids, static_cast<uint32_t*>(nullptr), uint64_t(out_capacity));
         if (!hip_ok(hipGetLastError(), "in-index kernels")) st = DINT_ERR_HIP;
     }
 #undef TRY_OR_CLEAN
@@ -829,7 +831,7 @@ static int decode_doc_pages(dint_query_index* qi, size_t n_pages, uint32_t* d_ou
     hipLaunchKernelGGL(collect_tails_kernel, dim3(grid), dim3(tb), 0, s, qi->sub.p, uint64_t(n_pages), qi->tails.p,
                        qi->tails.p + n_pages);
     hipLaunchKernelGGL(interpolative_tails_kernel, dim3(grid), dim3(tb), 0, s, qi->d_index, uint64_t(qi->index_bytes),
-                       qi->sub.p, nullptr, qi->tails.p, qi->tails.p + n_pages, d_out, cap, nullptr);
+                       qi->sub.p, nullptr, qi->tails.p, qi->tails.p + n_pages, d_out, cap, nullptr, 0u);
     const uint32_t wgrid = uint32_t((n_pages * kWave + tb - 1) / tb);
     hipLaunchKernelGGL(finalize_postings_kernel, dim3(wgrid), dim3(tb), 0, s, qi->sub.p, uint64_t(n_pages), d_out,
                        nullptr, cap);

@@ -134,6 +134,7 @@ struct decode_args {
     const uint32_t* items; // with sched: the units with sched != 0, in order — what the queue hands out
     const uint32_t* n_items;
     const uint32_t* spans; // nullable; per unit an upper bound of its stream bytes (else: up to the next unit's start)
+    uint32_t plus_one;     // in-index freqs parts: every decoded integer + 1 (dict_posting_list.hpp:164-169)
 };
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -339,6 +340,7 @@ struct tile_slots {
     uint32_t rbase, nlive;  // ordinal of its first live codeword, how many it has
     uint32_t cl, qb, wb;    // pk sum of the lane; first cell / first fetch of the lane
     uint32_t total;         // outputs of the tile (wave-uniform)
+    uint32_t plus_one;      // add one to every output (wave-uniform; the in-index freqs parts)
     bool tile_exc, tile_staged;  // some lane holds an exception / needs staging (wave-uniform)
 };
 
@@ -540,7 +542,8 @@ __device__ __forceinline__ void expand_tile(const tile_slots& t, uint32_t out_in
                         if (x[g][0] == 0xDEADBEEFu && x[g][1] == 0x12345u) out[g] = x[g][2] + x[g][3];
 #else
                         if (p0 < bt) {
-                            const u32x4 xv = {x[g][0], x[g][1], x[g][2], x[g][3]};
+                            u32x4 xv = {x[g][0], x[g][1], x[g][2], x[g][3]};
+                            if (t.plus_one) xv += 1u;  // wave-uniform branch: nothing on the plain decode path
                             __builtin_amdgcn_raw_buffer_store_b128(xv, rs_out, 16 * g * kWave + 16 * lane, obyte, DINT_STORE_AUX);
                         }
 #endif
@@ -863,6 +866,7 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
         }
         t.lsum = lsum, t.obase = obase, t.rbase = rbase, t.nlive = nlive, t.cl = cl, t.qb = qb, t.wb = wb;
         t.total = total, t.tile_exc = tile_exc, t.tile_staged = tile_staged;
+        t.plus_one = a.plus_one;
         // the prefetched registers must have landed before the first store is issued
         // ("+v": from here on the values are the asm's, not a load's — nothing for the compiler to wait for later)
         uint64_t raw3w = raw3;
@@ -1206,6 +1210,7 @@ __device__ __forceinline__ void decode_bundle(const decode_args& a, const uint32
     t.obase = seg_out0 + p0;
     t.rbase = wave_inclusive_sum(nlive) - nlive;
     t.total = total;
+    t.plus_one = a.plus_one;
 
     // ---- staging demand, as in decode_segment ---------------------------------------------------------
 #pragma unroll
@@ -1447,7 +1452,7 @@ __global__ void collect_tails_kernel(const dint_block_ref* blocks, uint64_t n_bl
 
 __global__ void interpolative_tails_kernel(const uint8_t* index, uint64_t index_bytes, const dint_block_ref* blocks,
                                            const uint64_t* docs_end, const uint32_t* tails, const uint32_t* n_tails,
-                                           uint32_t* out, uint64_t out_capacity, uint64_t* end_off) {
+                                           uint32_t* out, uint64_t out_capacity, uint64_t* end_off, uint32_t plus_one) {
     const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (t >= *n_tails) return;
     const uint64_t b = tails[t];
@@ -1486,6 +1491,8 @@ __global__ void interpolative_tails_kernel(const uint8_t* index, uint64_t index_
         for (uint32_t i = n - 1; i > 0; --i) o[i] -= o[i - 1];
         used = (br.pos + 7) / 8;
     }
+    if (plus_one)
+        for (uint32_t i = 0; i != n; ++i) o[i] += 1;
     if (end_off) end_off[b] = pos + used;
 }
 
