@@ -162,6 +162,10 @@ struct dint_dict {
     bool slot_used[kQueueSlots] = {};
     std::atomic<uint32_t> next_slot{0};
     std::mutex launch_mutex;
+    // workspace of dint_decode_posting_blocks (grow-only; one call at a time per dictionary)
+    void* pl_ws = nullptr;
+    size_t pl_ws_bytes = 0;
+    std::mutex pl_mutex;
 };
 
 namespace {
@@ -422,6 +426,9 @@ int dint_dict_create(int kind, const void* file_bytes, size_t len, int device, d
                 "hipFuncSetAttribute") ||
         !hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_multi_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsWords * 4)),
+                "hipFuncSetAttribute") ||
+        !hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(&interpolative_tails_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(kTailLdsBytes)),
                 "hipFuncSetAttribute")) {
         dint_dict_destroy(dd);
         return DINT_ERR_HIP;
@@ -442,6 +449,7 @@ void dint_dict_destroy(dint_dict* dd) {
     if (dd->d_queues) (void)hipFree(dd->d_queues);
     for (auto p : dd->d_sched)
         if (p) (void)hipFree(p);
+    if (dd->pl_ws) (void)hipFree(dd->pl_ws);
     for (auto e : dd->slot_done)
         if (e) (void)hipEventDestroy(e);
     delete dd;
@@ -689,18 +697,24 @@ int dint_decode_posting_blocks(const dint_dict* docs_dict, const dint_dict* freq
         return DINT_ERR_ARG;
     HIP_TRY(hipSetDevice(docs_dict->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    dint_unit* d_units = nullptr;
-    uint64_t* d_ends = nullptr;
-    uint32_t* d_spans = nullptr;
-    uint32_t* d_tails = nullptr;  // [n_blocks] indices of the short blocks, [n_blocks]: their number
+    // workspace: [units][docs ends][spans][short blocks + their number], kept with the docs dictionary
+    dint_dict* owner = const_cast<dint_dict*>(docs_dict);
+    std::lock_guard<std::mutex> ws_lock(owner->pl_mutex);
+    const size_t need = n_blocks * (sizeof(dint_unit) + sizeof(uint64_t) + 2 * sizeof(uint32_t)) + 64;
+    if (owner->pl_ws_bytes < need) {
+        if (owner->pl_ws) HIP_TRY(hipFree(owner->pl_ws));
+        owner->pl_ws = nullptr;
+        owner->pl_ws_bytes = 0;
+        const size_t want = need + need / 4;
+        HIP_TRY(hipMalloc(&owner->pl_ws, want));
+        owner->pl_ws_bytes = want;
+    }
+    dint_unit* const d_units = static_cast<dint_unit*>(owner->pl_ws);
+    uint64_t* const d_ends = reinterpret_cast<uint64_t*>(d_units + n_blocks);
+    uint32_t* const d_spans = reinterpret_cast<uint32_t*>(d_ends + n_blocks);
+    uint32_t* const d_tails = d_spans + n_blocks;  // [n_blocks] indices of the short blocks, [n_blocks]: their number
     int st = DINT_OK;
-    auto cleanup = [&] {
-        (void)hipStreamSynchronize(s);
-        if (d_units) (void)hipFree(d_units);
-        if (d_ends) (void)hipFree(d_ends);
-        if (d_spans) (void)hipFree(d_spans);
-        if (d_tails) (void)hipFree(d_tails);
-    };
+    auto cleanup = [&] { (void)hipStreamSynchronize(s); };
 #define TRY_OR_CLEAN(call)            \
     do {                              \
         if (!hip_ok((call), #call)) { \
@@ -708,20 +722,17 @@ int dint_decode_posting_blocks(const dint_dict* docs_dict, const dint_dict* freq
             return DINT_ERR_HIP;      \
         }                             \
     } while (0)
-    TRY_OR_CLEAN(hipMalloc(&d_units, n_blocks * sizeof(dint_unit)));
-    TRY_OR_CLEAN(hipMalloc(&d_ends, n_blocks * sizeof(uint64_t)));
-    TRY_OR_CLEAN(hipMalloc(&d_spans, n_blocks * sizeof(uint32_t)));
-    TRY_OR_CLEAN(hipMalloc(&d_tails, (n_blocks + 1) * sizeof(uint32_t)));
     TRY_OR_CLEAN(hipMemsetAsync(d_tails + n_blocks, 0, 4, s));
     const uint32_t tb = 256;
     const uint32_t grid = uint32_t((n_blocks + tb - 1) / tb);
+    const uint32_t tgrid = uint32_t((n_blocks + 63) / 64);  // one wave per 64 short blocks (most exit at once)
     hipLaunchKernelGGL(collect_tails_kernel, dim3(grid), dim3(tb), 0, s, d_blocks, uint64_t(n_blocks), d_tails, d_tails + n_blocks);
     // docs parts: full blocks through the DINT kernel, short ones through the interpolative decoder
     hipLaunchKernelGGL(blocks_to_units_kernel, dim3(grid), dim3(tb), 0, s, d_blocks, nullptr, uint64_t(n_blocks),
                        uint64_t(index_bytes), d_units, d_spans);
     st = launch_decode(docs_dict, d_index, index_bytes, d_units, n_blocks, d_docids, out_capacity, d_ends, s, 1, d_spans);
     if (st == DINT_OK) {
-        hipLaunchKernelGGL(interpolative_tails_kernel, dim3(grid), dim3(tb), 0, s, d_index, uint64_t(index_bytes),
+        hipLaunchKernelGGL(interpolative_tails_kernel, dim3(tgrid), dim3(64), kTailLdsBytes, s, d_index, uint64_t(index_bytes),
                            d_blocks, nullptr, d_tails, d_tails + n_blocks, d_docids, uint64_t(out_capacity), d_ends, 0u);
         if (d_freqs) {  // freqs parts start where the docs parts ended
             hipLaunchKernelGGL(blocks_to_units_kernel, dim3(grid), dim3(tb), 0, s, d_blocks, d_ends,
@@ -729,7 +740,7 @@ int dint_decode_posting_blocks(const dint_dict* docs_dict, const dint_dict* freq
             // (freq = decoded value + 1, dict_posting_list.hpp:164-169: added where the values are stored)
             st = launch_decode(freqs_dict, d_index, index_bytes, d_units, n_blocks, d_freqs, out_capacity, nullptr, s, 1, d_spans, 1);
             if (st == DINT_OK)
-                hipLaunchKernelGGL(interpolative_tails_kernel, dim3(grid), dim3(tb), 0, s, d_index,
+                hipLaunchKernelGGL(interpolative_tails_kernel, dim3(tgrid), dim3(64), kTailLdsBytes, s, d_index,
                                    uint64_t(index_bytes), d_blocks, d_ends, d_tails, d_tails + n_blocks, d_freqs,
                                    uint64_t(out_capacity), nullptr, 1u);
         }
@@ -830,8 +841,8 @@ static int decode_doc_pages(dint_query_index* qi, size_t n_pages, uint32_t* d_ou
     HIP_TRY(hipMemsetAsync(qi->tails.p + n_pages, 0, 4, s));
     hipLaunchKernelGGL(collect_tails_kernel, dim3(grid), dim3(tb), 0, s, qi->sub.p, uint64_t(n_pages), qi->tails.p,
                        qi->tails.p + n_pages);
-    hipLaunchKernelGGL(interpolative_tails_kernel, dim3(grid), dim3(tb), 0, s, qi->d_index, uint64_t(qi->index_bytes),
-                       qi->sub.p, nullptr, qi->tails.p, qi->tails.p + n_pages, d_out, cap, nullptr, 0u);
+    hipLaunchKernelGGL(interpolative_tails_kernel, dim3(uint32_t((n_pages + 63) / 64)), dim3(64), kTailLdsBytes, s, qi->d_index,
+                       uint64_t(qi->index_bytes), qi->sub.p, nullptr, qi->tails.p, qi->tails.p + n_pages, d_out, cap, nullptr, 0u);
     const uint32_t wgrid = uint32_t((n_pages * kWave + tb - 1) / tb);
     hipLaunchKernelGGL(finalize_postings_kernel, dim3(wgrid), dim3(tb), 0, s, qi->sub.p, uint64_t(n_pages), d_out,
                        nullptr, cap);

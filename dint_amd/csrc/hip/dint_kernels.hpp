@@ -1450,50 +1450,77 @@ __global__ void collect_tails_kernel(const dint_block_ref* blocks, uint64_t n_bl
     if (n != 0 && n < 256) tails[atomicAdd(n_tails, 1u)] = uint32_t(b);
 }
 
-__global__ void interpolative_tails_kernel(const uint8_t* index, uint64_t index_bytes, const dint_block_ref* blocks,
-                                           const uint64_t* docs_end, const uint32_t* tails, const uint32_t* n_tails,
-                                           uint32_t* out, uint64_t out_capacity, uint64_t* end_off, uint32_t plus_one) {
-    const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (t >= *n_tails) return;
-    const uint64_t b = tails[t];
-    const uint32_t n = blocks[b].n;
-    if (n == 0 || n >= 256 || blocks[b].out_off + n > out_capacity) return;
-    uint64_t pos = docs_end ? docs_end[b] : blocks[b].in_off;
-    uint32_t sum;
-    if (docs_end) {  // freqs: sum_of_values = -1 -> TightVariableByte sum first
-        sum = 0;
-        for (uint32_t shift = 0; pos < index_bytes; shift += 7) {
-            const uint8_t c = index[pos++];
-            sum += uint32_t(c & 127) << (shift & 31);
-            if (c & 128) break;
-        }
-    } else {
-        sum = blocks[b].max - blocks[b].base - (n - 1);
+// One wavefront per 64 short blocks, one block per lane. The decoder's values and its explicit stack
+// live in LDS (rows of odd stride: lane-private and conflict-free); the block is differenced there and
+// the wave then copies the rows out together, coalesced — no pass over global memory but that one.
+constexpr uint32_t kTailRow = 257;     // words per lane: up to 255 values
+constexpr uint32_t kTailStack = 41;    // words per lane: 10 frames of 4 (depth <= log2(256) + 1)
+constexpr uint32_t kTailLdsBytes = 64 * (kTailRow + kTailStack) * 4;
+
+__global__ __launch_bounds__(64) void interpolative_tails_kernel(const uint8_t* index, uint64_t index_bytes,
+                                                                 const dint_block_ref* blocks, const uint64_t* docs_end,
+                                                                 const uint32_t* tails, const uint32_t* n_tails, uint32_t* out,
+                                                                 uint64_t out_capacity, uint64_t* end_off, uint32_t plus_one) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t tail_lds[];
+    __shared__ uint32_t row_n[64];
+    __shared__ uint64_t row_out[64];
+    const uint32_t lane = threadIdx.x;
+    if (uint64_t(blockIdx.x) * 64 >= *n_tails) return;  // (the grid is sized for the worst case)
+    const uint64_t t = uint64_t(blockIdx.x) * 64 + lane;
+    uint32_t* const o = tail_lds + lane * kTailRow;
+    uint32_t* const stack = tail_lds + 64 * kTailRow + lane * kTailStack;
+    uint32_t n = 0;
+    uint64_t b = 0;
+    if (t < *n_tails) {
+        b = tails[t];
+        n = blocks[b].n;
+        if (n >= 256 || blocks[b].out_off + n > out_capacity) n = 0;
     }
-    uint32_t* o = out + blocks[b].out_off;
-    o[n - 1] = sum;
-    uint64_t used = 0;
-    if (n > 1) {
-        tail_bits br{index + pos, index_bytes - pos, 0, 0, 0, 0};
-        struct frame {
-            uint32_t off, n, low, high;
-        } stack[20];
-        int top = 0;
-        stack[top++] = {0, n - 1, 0, sum};
-        while (top) {
-            const frame f = stack[--top];
-            const uint32_t h = f.n / 2;
-            const uint32_t val = f.low + br.read_int(f.high - f.low + 1);
-            o[f.off + h] = val;
-            if (f.n - h - 1) stack[top++] = {f.off + h + 1, f.n - h - 1, val, f.high};
-            if (h) stack[top++] = {f.off, h, f.low, val};
+    row_n[lane] = n;
+    row_out[lane] = n ? blocks[b].out_off : 0;
+    if (n != 0) {
+        uint64_t pos = docs_end ? docs_end[b] : blocks[b].in_off;
+        uint32_t sum;
+        if (docs_end) {  // freqs: sum_of_values = -1 -> TightVariableByte sum first
+            sum = 0;
+            for (uint32_t shift = 0; pos < index_bytes; shift += 7) {
+                const uint8_t c = index[pos++];
+                sum += uint32_t(c & 127) << (shift & 31);
+                if (c & 128) break;
+            }
+        } else {
+            sum = blocks[b].max - blocks[b].base - (n - 1);
         }
-        for (uint32_t i = n - 1; i > 0; --i) o[i] -= o[i - 1];
-        used = (br.pos + 7) / 8;
+        o[n - 1] = sum;
+        uint64_t used = 0;
+        if (n > 1) {
+            tail_bits br{index + pos, index_bytes - pos, 0, 0, 0, 0};
+            uint32_t top = 0;
+            auto push = [&](uint32_t off, uint32_t cnt, uint32_t low, uint32_t high) {
+                uint32_t* f = stack + 4 * top++;
+                f[0] = off, f[1] = cnt, f[2] = low, f[3] = high;
+            };
+            push(0, n - 1, 0, sum);
+            while (top) {
+                const uint32_t* f = stack + 4 * --top;
+                const uint32_t f_off = f[0], f_n = f[1], f_low = f[2], f_high = f[3];
+                const uint32_t h = f_n / 2;
+                const uint32_t val = f_low + br.read_int(f_high - f_low + 1);
+                o[f_off + h] = val;
+                if (f_n - h - 1) push(f_off + h + 1, f_n - h - 1, val, f_high);
+                if (h) push(f_off, h, f_low, val);
+            }
+            for (uint32_t i = n - 1; i > 0; --i) o[i] -= o[i - 1];
+            used = (br.pos + 7) / 8;
+        }
+        if (end_off) end_off[b] = pos + used;
     }
-    if (plus_one)
-        for (uint32_t i = 0; i != n; ++i) o[i] += 1;
-    if (end_off) end_off[b] = pos + used;
+    __syncthreads();
+    for (uint32_t j = 0; j != 64; ++j) {  // rows out, the whole wave on one row at a time
+        const uint32_t nj = row_n[j];
+        uint32_t* const dst = out + row_out[j];
+        for (uint32_t i = lane; i < nj; i += 64) dst[i] = tail_lds[j * kTailRow + i] + plus_one;
+    }
 }
 
 // gaps -> docIDs (docid_i = base + sum_{j<=i} gap_j + i, dict_posting_list.hpp:111-124) and

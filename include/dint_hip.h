@@ -148,7 +148,7 @@ int dint_index_posting_lists(const uint8_t* index, size_t index_bytes, const uin
  * binary-interpolative decoder, then gap -> docID prefix sums. d_index / d_blocks / outputs are
  * device pointers on the dictionaries' device; both dictionaries must be of the same kind and
  * live on the same device. The call enqueues on `stream` and returns after synchronising it
- * (it owns a temporary workspace).
+ * (its workspace is kept with docs_dict: one call at a time per docs dictionary).
  * Replaces: document_enumerator::decode_docs_block / decode_freqs_block + the docid
  * accumulation of next() (dict_posting_list.hpp:111-124, 284-318), i.e. dint_block::decode /
  * opt_dint_multi_dict_block::decode (include/dint/dint_codecs.hpp:13-49, 460-510) and
