@@ -3,7 +3,10 @@
 (src/queries.cpp:15-61 — every query run on its own, first pass untimed, avg/q50/q90/q95 in µs)
 plus the batch rate the device path is built for, with the oracle's and_query timed beside it.
 
-    python tools/bench_queries.py [--postings 1e8] [--type single_packed_dint] [--runs 3]
+    python tests/query_timing.py [--postings 1e8] [--type single_packed_dint] [--runs 3]
+
+Lives under tests/ because it times the CPU oracle next to the device path (the oracle is test
+infrastructure: nothing outside tests/, smoke() and bench.py's cpu_baseline may touch it).
 """
 import argparse
 import json

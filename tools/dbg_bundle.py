@@ -1,5 +1,5 @@
 import sys, os
-sys.path[:0]=['/root/repo','/root/repo/tests','/root/repo/oracle']
+sys.path[:0]=[os.path.dirname(os.path.dirname(os.path.abspath(__file__)))]
 import numpy as np
 import torch; torch.cuda.init()
 from dint_amd import host, device

@@ -1,7 +1,7 @@
 """Scratch: decode rate of the current kernel on a synthetic collection (development aid)."""
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+sys.path[:0] = [ROOT]
 import numpy as np, torch
 from dint_amd import host, device
 
