@@ -144,6 +144,7 @@ struct dint_dict {
     std::vector<uint32_t> h_start;  // per dictionary first meta slot (+ end)
     std::vector<uint32_t> h_size;   // per meta slot
     // device buffers
+    void* d_block = nullptr;  // one allocation: gmeta | gtable | LDS image | descriptors
     uint32_t* d_gmeta = nullptr;
     uint32_t* d_gtable = nullptr;
     uint32_t* d_image = nullptr;
@@ -273,10 +274,20 @@ int stage_dictionary(dint_dict& dd, parsed_dict const& pd) {
     if (st != DINT_OK) return st;
 
     HIP_TRY(hipSetDevice(dd.device));
-    HIP_TRY(hipMalloc(&dd.d_gmeta, gmeta.size() * 4));
-    HIP_TRY(hipMalloc(&dd.d_gtable, gtable.size() * 4));
-    HIP_TRY(hipMalloc(&dd.d_image, size_t(kHotImageWords) * 4));
-    HIP_TRY(hipMalloc(&dd.d_descs, pd.num_dicts * sizeof(dict_desc)));
+    // One allocation, a multiple of 2 MB, for everything the kernel reads at random (metadata, payload
+    // table) and at start (LDS image, descriptors): the randomly gathered tables then sit in as few and as
+    // large page-table fragments as the driver can give, whatever the state of the memory pool.
+    auto up256 = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t b_meta = up256(gmeta.size() * 4), b_table = up256(gtable.size() * 4);
+    const size_t b_image = up256(size_t(kHotImageWords) * 4), b_descs = up256(pd.num_dicts * sizeof(dict_desc));
+    const size_t two_mb = size_t(2) << 20;
+    const size_t total = (b_meta + b_table + b_image + b_descs + two_mb - 1) / two_mb * two_mb;
+    HIP_TRY(hipMalloc(&dd.d_block, total));
+    uint8_t* base = static_cast<uint8_t*>(dd.d_block);
+    dd.d_gmeta = reinterpret_cast<uint32_t*>(base);
+    dd.d_gtable = reinterpret_cast<uint32_t*>(base + b_meta);
+    dd.d_image = reinterpret_cast<uint32_t*>(base + b_meta + b_table);
+    dd.d_descs = reinterpret_cast<dint_dev::dict_desc*>(base + b_meta + b_table + b_image);
     HIP_TRY(hipMemcpy(dd.d_gmeta, gmeta.data(), gmeta.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dd.d_gtable, gtable.data(), gtable.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipEventCreate(&dd.ev_start));
@@ -440,10 +451,7 @@ int dint_dict_create(int kind, const void* file_bytes, size_t len, int device, d
 void dint_dict_destroy(dint_dict* dd) {
     if (!dd) return;
     (void)hipSetDevice(dd->device);
-    if (dd->d_gmeta) (void)hipFree(dd->d_gmeta);
-    if (dd->d_gtable) (void)hipFree(dd->d_gtable);
-    if (dd->d_image) (void)hipFree(dd->d_image);
-    if (dd->d_descs) (void)hipFree(dd->d_descs);
+    if (dd->d_block) (void)hipFree(dd->d_block);
     if (dd->ev_start) (void)hipEventDestroy(dd->ev_start);
     if (dd->ev_stop) (void)hipEventDestroy(dd->ev_stop);
     if (dd->d_queues) (void)hipFree(dd->d_queues);
