@@ -1013,6 +1013,14 @@ int dint_decode_list_host(const dint_dict* dd, const uint8_t* in, size_t in_byte
     return st;
 }
 
+#ifdef DINT_EXP_FINISH
+// Diagnostic build only: per-wave finish timestamps (100 MHz ticks) of the last decode launch.
+int dint_debug_read_finish(unsigned long long* out8192) {
+    HIP_TRY(hipMemcpyFromSymbol(out8192, HIP_SYMBOL(dint_dev::g_finish), 8192 * sizeof(unsigned long long)));
+    return DINT_OK;
+}
+#endif
+
 // Test hook (not part of the decode ABI): inclusive wave prefix sum of 64 host words.
 int dint_debug_wave_scan(const uint32_t* in64, uint32_t* out64) {
     if (!in64 || !out64) return DINT_ERR_ARG;

@@ -1311,6 +1311,9 @@ __device__ __forceinline__ void decode_unit_multi(const decode_args& a, const ui
 // so a static unit -> wave map leaves most of the chip idle behind the slowest
 // waves. kQueueShards counters, one per group of workgroups; a wave draws its next
 // work item while it is still decoding the current one.
+#ifdef DINT_EXP_FINISH
+__device__ unsigned long long g_finish[8192];
+#endif
 template <bool MULTI>
 __device__ __forceinline__ void decode_kernel_body(const decode_args& a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -1366,6 +1369,9 @@ __device__ __forceinline__ void decode_kernel_body(const decode_args& a) {
         }
         w = w_next;
     }
+#ifdef DINT_EXP_FINISH  // diagnostic: when did this wave run out of work? (tail of the kernel)
+    if (lane == 0) g_finish[blockIdx.x * kWavesPerBlock + wave] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 #ifndef DINT_MIN_WAVES
