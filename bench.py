@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)  # (the shader clock is still ramping for the first few launches)
     ap.add_argument("--type", default="single_packed_dint",
                     choices=["single_rect_dint", "single_packed_dint", "multi_packed_dint"])
     ap.add_argument("--postings", type=float, default=1.0e9,
