@@ -144,15 +144,16 @@ struct dint_dict {
     std::vector<uint32_t> h_start;  // per dictionary first meta slot (+ end)
     std::vector<uint32_t> h_size;   // per meta slot
     // device buffers
-    void* d_block = nullptr;  // one allocation: gmeta | gtable | LDS image | descriptors
-    uint32_t* d_gmeta = nullptr;
-    uint32_t* d_gtable = nullptr;
+    void* d_block = nullptr;  // one allocation: gmeta | rows | gtable | LDS image | descriptors
     uint32_t* d_image = nullptr;
     dint_dev::dict_desc* d_descs = nullptr;
     uint32_t hot_entries = 0;
+    uint32_t table_words = 0;
     dint_dev::dict_view view{};
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    bool timed = false;
+    // timing events of the decode kernel: one pair per queue slot (launches on different streams may
+    // interleave); dint_last_kernel_ms reads the pair of the most recent launch
+    int last_slot = -1;
+    bool no_bundles = false;  // DINT_NO_BUNDLES in the environment when the dictionary was created (diagnostic)
     // work-queue counters: one slot per in-flight launch, recycled round-robin
     // behind the event of the launch that used the slot last
     static constexpr uint32_t kQueueSlots = 32;
@@ -160,6 +161,7 @@ struct dint_dict {
     uint8_t* d_sched[kQueueSlots] = {};   // per slot: the bundle schedule of the launch (grow-only)
     size_t sched_cap[kQueueSlots] = {};
     hipEvent_t slot_done[kQueueSlots] = {};
+    hipEvent_t slot_start[kQueueSlots] = {}, slot_stop[kQueueSlots] = {};
     bool slot_used[kQueueSlots] = {};
     std::atomic<uint32_t> next_slot{0};
     std::mutex launch_mutex;
@@ -171,18 +173,27 @@ struct dint_dict {
 
 namespace {
 
-// Device layout of a dictionary file.
-//   gtable   = [256 zeros][the file's payload words][16 words of padding];
-//   gmeta[i] = (size-1) << 24 | kColdBase | word offset into gtable (runs: just the size), one
-//              word per offsets slot of the file (multi: the 6 dictionaries back to back);
-//   LDS image = [256 zeros]{[hot meta of dictionary d: hot_k[d] words]}[hot payloads];
-//   hot meta = (size-1) << 24 | word offset inside the image (runs -> the zeros);
-//   payloads = the union of the hot entries' table intervals, each word once (the packed
-//              formats nest short entries inside long ones: single_dictionary.hpp:109-160).
+// Device layout of a dictionary file. One allocation [gmeta | rows | goff | gtable | LDS image | descriptors]:
+//   gmeta[i] = one word per offsets slot of the file (multi: the 6 dictionaries back to back):
+//              (size-1) << 24 | kMetaCold | kMetaSlow, or | staging cells (1: up to 8 integers, 2) << 20;
+//              runs carry only their size (their source is the zero region of the LDS image);
+//   goff[i]  = the entry's word offset into gtable (slow path only);
+//   rows     = 32 bytes per slot: the entry's integers as sixteen u16 (zero padded) — what a cold codeword
+//              fetches into its LDS cell(s), ONE 16-byte lane request for up to 8 integers, addressed by the
+//              slot number alone (no offset lookup between the slot and its payload);
+//   gtable   = [the file's payload words][16 words of padding], 32-bit: the slow path's source;
+//   LDS image = [256 u16 zeros]{[hot meta of dictionary d: hot_k[d] words]}[hot payloads as u16];
+//   hot meta = (size-1) << 24 | byte offset of the payload inside the image (runs -> the zeros), one dummy
+//              word behind the last;
+//   payloads = the union of the hot entries' table intervals, each word once (the packed formats nest
+//              short entries inside long ones: single_dictionary.hpp:109-160), as u16.
+// 16 bits per integer on chip: every value of a DSF dictionary built from d-gaps is far below 65536. An
+// entry that does hold a larger value is SLOW: kMetaSlow in its metadata, never in the hot payloads or the
+// rows; the kernel writes its integers straight from gtable (dint_kernels.hpp, slow_stores).
 // Hot = codewords below hot_k[d]: the DSF builder appends entries in decreasing corpus n-gram
 // frequency (dictionary_builders.hpp:61-72), so "index < K" is the hotness test, one compare
 // in the kernel. (Picking the hot set by measured USE counts behind a bitmap + rank remap was
-// tried: 67% instead of 60% of the lookups on chip, paid for by the longer lookup — no gain.)
+// tried in round 1: 67% instead of 60% of the lookups on chip, paid for by the longer lookup — no gain.)
 // The image budget is split evenly between the dictionaries of a multi file.
 struct hot_layout {
     std::vector<uint32_t> image;
@@ -195,54 +206,70 @@ uint32_t entry_payload_words(parsed_dict const& pd, uint32_t d, uint32_t i) {
     return (i >= kReserved && sz <= kMaxEntry) ? sz : 0;  // runs and the exception rows copy zeros
 }
 
+bool entry_is_wide(parsed_dict const& pd, uint32_t d, uint32_t i) {
+    const uint32_t pw = entry_payload_words(pd, d, i), o = pd.off[pd.start[d] + i];
+    for (uint32_t w = 0; w != pw; ++w)
+        if (pd.table[o + w] > 0xFFFFu) return true;
+    return false;
+}
+
 int choose_hot_set(parsed_dict const& pd, hot_layout& out) {
     const uint32_t nd = pd.num_dicts;
-    const uint64_t share = (uint64_t(kHotImageWords) - kZeroWords - 4) / nd;
+    const uint64_t share = (2 * uint64_t(kHotImageWords) - kZeroHalves - 8) / nd - 8;  // in u16 units
     std::vector<uint8_t> covered(pd.table.size(), 0);
     std::vector<uint32_t> hot_k(nd, 0);
-    // pass 1: how many codewords of each dictionary fit its share
+    // pass 1: how many codewords of each dictionary fit its share (a meta word = 2 units, a payload integer = 1)
     for (uint32_t d = 0; d != nd; ++d) {
         const uint32_t n_entries = std::min<uint32_t>(pd.start[d + 1] - pd.start[d], kEntries);
-        uint64_t words = 0;
+        uint64_t units = 0;
         uint32_t k = 0;
         for (; k != n_entries; ++k) {
-            const uint32_t pw = entry_payload_words(pd, d, k);
+            const bool wide = entry_is_wide(pd, d, k);
+            const uint32_t pw = wide ? 0 : entry_payload_words(pd, d, k);
             const uint32_t o = pd.off[pd.start[d] + k];
-            uint32_t add = 1;
+            uint32_t add = 2;  // (the dummy word behind the metas comes out of the 8 spare units per dictionary)
             for (uint32_t w = 0; w != pw; ++w) add += covered[o + w] ? 0u : 1u;
-            if (words + add > share) break;
-            words += add;
+            if (units + add > share) break;
+            units += add;
             for (uint32_t w = 0; w != pw; ++w) covered[o + w] = 1;
         }
         hot_k[d] = k;
     }
-    // pass 2: lay the image out
-    std::vector<uint32_t>& image = out.image;
-    image.assign(kZeroWords, 0);
+    // pass 2: lay the image out (u16 units; the metas sit on word boundaries)
+    std::vector<uint16_t> halves(kZeroHalves, 0);
     out.descs.assign(nd, dict_desc{});
     out.hot_entries = 0;
     for (uint32_t d = 0; d != nd; ++d) {
         out.descs[d].meta_base = pd.start[d];
-        out.descs[d].hot_k = hot_k[d];
-        out.descs[d].hot_base = uint32_t(image.size());
+        // (at least the two exception markers count as hot: the kernel takes "slot value >= hot_k" for "this
+        // slot's staging cell receives a row", and the cell of a marker holds its literal)
+        out.descs[d].hot_k = std::max<uint32_t>(2, hot_k[d]);
+        out.descs[d].hot_base = uint32_t(halves.size() / 2);  // word offset of the dictionary's hot metas
         out.descs[d].pad = 0;
-        image.resize(image.size() + std::max<uint32_t>(1, hot_k[d]), 0);
+        // (+1: a dummy word behind the metas, what the lanes of cold slots read)
+        halves.resize(halves.size() + 2 * (std::max<uint32_t>(2, hot_k[d]) + 1), 0);
         out.hot_entries += hot_k[d];
     }
     std::vector<uint32_t> where(pd.table.size(), 0);
     for (size_t w = 0; w != pd.table.size(); ++w)
         if (covered[w]) {
-            where[w] = uint32_t(image.size());
-            image.push_back(pd.table[w]);
+            where[w] = uint32_t(halves.size());
+            halves.push_back(uint16_t(pd.table[w]));
         }
     for (uint32_t d = 0; d != nd; ++d)
         for (uint32_t i = 0; i != hot_k[d]; ++i) {
             const uint32_t sz = pd.size[pd.start[d] + i];
-            const uint32_t o = entry_payload_words(pd, d, i) ? where[pd.off[pd.start[d] + i]] : 0u;  // 0: the zero region
-            image[out.descs[d].hot_base + i] = ((sz - 1) << 24) | o;
+            uint32_t m;
+            if (entry_is_wide(pd, d, i)) m = ((sz - 1) << 24) | kMetaCold | kMetaSlow;
+            else m = ((sz - 1) << 24) | (entry_payload_words(pd, d, i) ? 2 * where[pd.off[pd.start[d] + i]] : 0u);  // 0: the zero region
+            const size_t at = 2 * (size_t(out.descs[d].hot_base) + i);
+            halves[at] = uint16_t(m);
+            halves[at + 1] = uint16_t(m >> 16);
         }
-    while (image.size() % 4) image.push_back(0);
-    if (image.size() > kHotImageWords) return DINT_ERR_FORMAT;
+    while (halves.size() % 8) halves.push_back(0);
+    out.image.assign(halves.size() / 2, 0);
+    std::memcpy(out.image.data(), halves.data(), halves.size() * 2);
+    if (out.image.size() > kHotImageWords || 2 * halves.size() > kMetaOffMask) return DINT_ERR_FORMAT;
     return DINT_OK;
 }
 
@@ -259,48 +286,67 @@ int upload_hot_set(dint_dict& dd, hot_layout const& lay) {
 int stage_dictionary(dint_dict& dd, parsed_dict const& pd) {
     const size_t slots = pd.size.size();
     std::vector<uint32_t> gmeta(slots);
-    std::vector<uint32_t> gtable(kZeroWords, 0);
-    gtable.insert(gtable.end(), pd.table.begin(), pd.table.end());
+    std::vector<uint16_t> rows(slots * 16, 0);
+    std::vector<uint32_t> goff(slots, 0);
+    std::vector<uint32_t> gtable(pd.table);
     gtable.resize(gtable.size() + kMaxEntry, 0);
-    if (gtable.size() >= kColdBase) return DINT_ERR_FORMAT;
-    for (size_t i = 0; i != slots; ++i) {
-        const uint32_t sz = pd.size[i];
-        if (sz == 0 || sz > 256) return DINT_ERR_FORMAT;
-        // runs copy zeros: their source is the zero region at the start of the LDS image, never cold
-        gmeta[i] = ((sz - 1) << 24) | (sz > kMaxEntry ? 0u : (kColdBase | (pd.off[i] + kZeroWords)));
-    }
+    for (uint32_t d = 0; d != pd.num_dicts; ++d)
+        for (uint32_t i = 0; i != pd.start[d + 1] - pd.start[d]; ++i) {
+            const size_t slot = pd.start[d] + i;
+            const uint32_t sz = pd.size[slot];
+            if (sz == 0 || sz > 256) return DINT_ERR_FORMAT;
+            const uint32_t pw = (i >= kReserved && sz <= kMaxEntry) ? sz : 0;
+            if (pw == 0) {  // runs copy zeros: their source is the zero region at the start of the LDS image
+                gmeta[slot] = (sz - 1) << 24;
+                continue;
+            }
+            bool slow = false;
+            for (uint32_t w = 0; w != pw; ++w) slow = slow || pd.table[pd.off[slot] + w] > 0xFFFFu;
+            // (goff: every entry's offset into gtable — a tile with more cold codewords than staging cells sends
+            // the surplus through the slow path too)
+            gmeta[slot] = ((sz - 1) << 24) | kMetaCold | (slow ? kMetaSlow : (pw > 8 ? 2u : 1u) << 20);
+            goff[slot] = pd.off[slot];
+            if (!slow)
+                for (uint32_t w = 0; w != pw; ++w) rows[slot * 16 + w] = uint16_t(pd.table[pd.off[slot] + w]);
+        }
     hot_layout lay;
     const int st = choose_hot_set(pd, lay);
     if (st != DINT_OK) return st;
 
     HIP_TRY(hipSetDevice(dd.device));
-    // One allocation, a multiple of 2 MB, for everything the kernel reads at random (metadata, payload
+    // One allocation, a multiple of 2 MB, for everything the kernel reads at random (metadata, rows, payload
     // table) and at start (LDS image, descriptors): the randomly gathered tables then sit in as few and as
     // large page-table fragments as the driver can give, whatever the state of the memory pool.
     auto up256 = [](size_t b) { return (b + 255) / 256 * 256; };
-    const size_t b_meta = up256(gmeta.size() * 4), b_table = up256(gtable.size() * 4);
+    const size_t b_meta = up256(gmeta.size() * 4), b_rows = up256(rows.size() * 2), b_goff = up256(goff.size() * 4),
+                 b_table = up256(gtable.size() * 4);
     const size_t b_image = up256(size_t(kHotImageWords) * 4), b_descs = up256(pd.num_dicts * sizeof(dict_desc));
     const size_t two_mb = size_t(2) << 20;
-    const size_t total = (b_meta + b_table + b_image + b_descs + two_mb - 1) / two_mb * two_mb;
+    const size_t b_tables = b_meta + b_rows + b_goff + b_table;
+    const size_t total = (b_tables + b_image + b_descs + two_mb - 1) / two_mb * two_mb;
+    if (b_tables >= (size_t(1) << 31)) return DINT_ERR_FORMAT;
     HIP_TRY(hipMalloc(&dd.d_block, total));
     uint8_t* base = static_cast<uint8_t*>(dd.d_block);
-    dd.d_gmeta = reinterpret_cast<uint32_t*>(base);
-    dd.d_gtable = reinterpret_cast<uint32_t*>(base + b_meta);
-    dd.d_image = reinterpret_cast<uint32_t*>(base + b_meta + b_table);
-    dd.d_descs = reinterpret_cast<dint_dev::dict_desc*>(base + b_meta + b_table + b_image);
-    HIP_TRY(hipMemcpy(dd.d_gmeta, gmeta.data(), gmeta.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dd.d_gtable, gtable.data(), gtable.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipEventCreate(&dd.ev_start));
-    HIP_TRY(hipEventCreate(&dd.ev_stop));
+    dd.d_image = reinterpret_cast<uint32_t*>(base + b_tables);
+    dd.d_descs = reinterpret_cast<dint_dev::dict_desc*>(base + b_tables + b_image);
+    HIP_TRY(hipMemcpy(base, gmeta.data(), gmeta.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(base + b_meta, rows.data(), rows.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(base + b_meta + b_rows, goff.data(), goff.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(base + b_meta + b_rows + b_goff, gtable.data(), gtable.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&dd.d_queues, size_t(dint_dict::kQueueSlots) * kQueueShards * kQueueStride * 4));
-    for (uint32_t i = 0; i != dint_dict::kQueueSlots; ++i)
+    for (uint32_t i = 0; i != dint_dict::kQueueSlots; ++i) {
         HIP_TRY(hipEventCreateWithFlags(&dd.slot_done[i], hipEventDisableTiming));
-    dd.view.gmeta = dd.d_gmeta;
-    dd.view.gtable = dd.d_gtable;
+        HIP_TRY(hipEventCreate(&dd.slot_start[i]));
+        HIP_TRY(hipEventCreate(&dd.slot_stop[i]));
+    }
+    dd.view.tables = base;
+    dd.view.tables_bytes = uint32_t(b_tables);
+    dd.view.rows_base = uint32_t(b_meta);
+    dd.view.goff_base = uint32_t(b_meta + b_rows);
+    dd.view.gtable_base = uint32_t(b_meta + b_rows + b_goff);
     dd.view.lds_image = dd.d_image;
     dd.view.descs = dd.d_descs;
-    dd.view.gmeta_words = uint32_t(gmeta.size());
-    dd.view.gtable_words = uint32_t(gtable.size());
+    dd.table_words = uint32_t(gtable.size());
     return upload_hot_set(dd, lay);
 }
 
@@ -420,6 +466,7 @@ int dint_dict_create(int kind, const void* file_bytes, size_t len, int device, d
     dd->entries = pd.entries;
     dd->h_start = pd.start;
     dd->h_size = pd.size;
+    dd->no_bundles = std::getenv("DINT_NO_BUNDLES") != nullptr;
     hipDeviceProp_t prop;
     if (!hip_ok(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties")) {
         delete dd;
@@ -452,8 +499,10 @@ void dint_dict_destroy(dint_dict* dd) {
     if (!dd) return;
     (void)hipSetDevice(dd->device);
     if (dd->d_block) (void)hipFree(dd->d_block);
-    if (dd->ev_start) (void)hipEventDestroy(dd->ev_start);
-    if (dd->ev_stop) (void)hipEventDestroy(dd->ev_stop);
+    for (auto e : dd->slot_start)
+        if (e) (void)hipEventDestroy(e);
+    for (auto e : dd->slot_stop)
+        if (e) (void)hipEventDestroy(e);
     if (dd->d_queues) (void)hipFree(dd->d_queues);
     for (auto p : dd->d_sched)
         if (p) (void)hipFree(p);
@@ -471,7 +520,7 @@ int dint_dict_info_get(const dint_dict* dd, dint_dict_info* info) {
     info->entries = dd->entries;
     info->hot_entries = dd->hot_entries;
     info->lds_bytes = dd->view.hot_words * 4;
-    info->table_words = dd->view.gtable_words;
+    info->table_words = dd->table_words;
     info->compute_units = dd->compute_units;
     return DINT_OK;
 }
@@ -604,12 +653,13 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
     a.sched = nullptr;
     a.items = nullptr;
     a.n_items = nullptr;
+    a.item_cnt = nullptr;
     a.spans = d_spans;
     if (n_units >= 2 && n_units < 0xFFFFFFFFull &&
-        !std::getenv("DINT_NO_BUNDLES")) {
-        // workspace of the slot: [items u32 x n][block counts/offsets u32 x blocks][n_items u32][sched u8 x n]
+        !dd->no_bundles) {
+        // workspace of the slot: [items u32 x n][block counts/offsets u32 x blocks][n_items u32][sched u8 x n][item counts u8 x n]
         const size_t n_blocks = (n_units + 255) / 256;
-        const size_t need = 4 * n_units + 4 * n_blocks + 4 + n_units;
+        const size_t need = 4 * n_units + 4 * n_blocks + 4 + 2 * n_units;
         if (mut->sched_cap[slot] < need) {
             if (mut->d_sched[slot]) HIP_TRY(hipFree(mut->d_sched[slot]));
             mut->d_sched[slot] = nullptr;
@@ -622,26 +672,28 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
         uint32_t* const d_block = d_items + n_units;
         uint32_t* const d_n_items = d_block + n_blocks;
         uint8_t* const d_sch = reinterpret_cast<uint8_t*>(d_n_items + 1);
+        uint8_t* const d_item_cnt = d_sch + n_units;
         hipLaunchKernelGGL(bundle_schedule_kernel, dim3(uint32_t(n_blocks)), dim3(256), 0, s, d_units, d_spans, uint64_t(n_units),
                            d_enc, uint64_t(enc_bytes), uint64_t(out_capacity), only_full,
                            uint32_t(dd->kind == DINT_DICT_MULTI_PACKED), d_sch, d_block);
         hipLaunchKernelGGL(bundle_offsets_kernel, dim3(1), dim3(1024), 0, s, d_block, uint32_t(n_blocks), d_n_items);
         hipLaunchKernelGGL(bundle_items_kernel, dim3(uint32_t(n_blocks)), dim3(256), 0, s, d_sch, uint64_t(n_units), d_block,
-                           d_items);
+                           d_items, d_item_cnt);
         a.sched = d_sch;
         a.items = d_items;
         a.n_items = d_n_items;
+        a.item_cnt = d_item_cnt;
     }
-    HIP_TRY(hipEventRecord(mut->ev_start, s));
+    HIP_TRY(hipEventRecord(mut->slot_start[slot], s));
     if (dd->kind == DINT_DICT_MULTI_PACKED)
         hipLaunchKernelGGL(decode_multi_kernel, dim3(grid), dim3(kBlockThreads), lds_bytes, s, a);
     else
         hipLaunchKernelGGL(decode_single_kernel, dim3(grid), dim3(kBlockThreads), lds_bytes, s, a);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(mut->ev_stop, s));
+    HIP_TRY(hipEventRecord(mut->slot_stop[slot], s));
     HIP_TRY(hipEventRecord(mut->slot_done[slot], s));
     mut->slot_used[slot] = true;
-    mut->timed = true;
+    mut->last_slot = int(slot);
     return DINT_OK;
 }
 
@@ -960,9 +1012,15 @@ int dint_and_queries(dint_query_index* qi, const uint32_t* terms, const uint64_t
 }
 
 int dint_last_kernel_ms(const dint_dict* dd, float* ms) {
-    if (!dd || !ms || !dd->timed) return DINT_ERR_ARG;
-    HIP_TRY(hipEventSynchronize(dd->ev_stop));
-    HIP_TRY(hipEventElapsedTime(ms, dd->ev_start, dd->ev_stop));
+    if (!dd || !ms) return DINT_ERR_ARG;
+    int slot;
+    {
+        std::lock_guard<std::mutex> lock(const_cast<dint_dict*>(dd)->launch_mutex);
+        slot = dd->last_slot;
+    }
+    if (slot < 0) return DINT_ERR_ARG;
+    HIP_TRY(hipEventSynchronize(dd->slot_stop[slot]));
+    HIP_TRY(hipEventElapsedTime(ms, dd->slot_start[slot], dd->slot_stop[slot]));
     return DINT_OK;
 }
 
@@ -1013,12 +1071,10 @@ int dint_decode_list_host(const dint_dict* dd, const uint8_t* in, size_t in_byte
     return st;
 }
 
-#ifdef DINT_EXP_FINISH
-// Diagnostic build only: per-wave finish timestamps (100 MHz ticks) of the last decode launch.
-int dint_debug_read_finish(unsigned long long* out8192) {
-    HIP_TRY(hipMemcpyFromSymbol(out8192, HIP_SYMBOL(dint_dev::g_finish), 8192 * sizeof(unsigned long long)));
-    return DINT_OK;
-}
+#ifdef DINT_PROFILE
+}  // extern "C"
+#include "dint_profile_host.inc"
+extern "C" {
 #endif
 
 // Test hook (not part of the decode ABI): inclusive wave prefix sum of 64 host words.

@@ -8,33 +8,39 @@
 //    tiny units packed into one tile — in TILES of 64 * kSPL 16-bit slots; lane l owns the kSPL
 //    CONSECUTIVE slots kSPL*l .. (one unaligned load), so (lane, k) order is stream order is
 //    output order;
-//  * per slot one metadata word ((size-1) << 24 | payload offset): LDS for the hot
-//    codewords (a prefix of the dictionary), L2 for the cold ones, looked up one tile ahead;
+//  * per slot one metadata word ((size-1) << 24 | source): LDS for the hot codewords (a prefix
+//    of the dictionary), L2 for the cold ones, looked up one tile ahead;
+//  * the integers of a cold codeword come from a table of 16-byte rows (eight u16) addressed by
+//    the slot value alone, fetched by LDS-DMA (buffer_load ... lds) straight into the slot's own
+//    staging cell — cell (k, lane) of the wave's 256 — at the end of the previous tile: no
+//    registers, no allocation, no worklist, one lane request per cold codeword;
 //  * header/payload classification: a table-driven per-lane state machine, iterated until the
-//    lane-to-lane carries agree (one or two rounds); nothing to do in tiles without 0 / 1 slots;
-//  * a local prefix plus ONE DPP wave scan gives every codeword its output offset;
-//  * EXPANSION is output-centric: every codeword sets ONE bit at its first output
-//    position in a per-wave flag bitmap (ds_or) and stores `source - position` in
-//    a table indexed by its ordinal; a small scan over the bitmap's word
-//    popcounts gives per-word rank bases. Then each lane takes 4 consecutive
-//    output integers: flag word + rank base -> 4 ranks -> 4 table reads -> 4 LDS
-//    gathers -> one 16-byte non-temporal store, so every global store instruction covers
-//    1 KB of consecutive output. Every source is in LDS by then: hot payloads and the zero
-//    region of the runs live there; the COLD payloads of a batch are fetched once per
-//    codeword (a compact worklist, one 16-byte load per lane and quad, while the batch
-//    tables are being built) into per-wave staging cells, where the exception literals go
-//    too. Exactly n integers are written per unit, nothing past them (the reference needs a
-//    pre-zeroed buffer and a 256-word overflow area, include/dint/dint_codecs.hpp:11,
-//    dict_posting_list.hpp:296);
+//    lane-to-lane carries agree (one or two rounds);
+//  * a local prefix plus ONE DPP wave scan gives every codeword its output offset and ordinal;
+//  * EXPANSION is output-centric: every codeword sets ONE bit at its first output position in a
+//    per-wave flag bitmap (ds_or), stores `source - position` in a table indexed by its ordinal,
+//    and the lane whose outputs cross a 32-output boundary writes the rank base of that flag word
+//    (all in one LDS phase). Then each lane takes 4 consecutive output integers: flag word + rank
+//    base -> 4 ranks -> 4 table reads -> 4 LDS gathers (u16) -> one 16-byte non-temporal store, so
+//    every global store instruction covers 1 KB of consecutive output. Every source is in LDS by
+//    then, 16 bits per integer: hot payloads, the zero region of the runs, the staging cells
+//    (cold rows, exception literals). Exactly n integers are written per unit, nothing past them
+//    (the reference needs a pre-zeroed buffer and a 256-word overflow area,
+//    include/dint/dint_codecs.hpp:11, dict_posting_list.hpp:296);
+//  * an exception literal sits in its slot's staging cell as 32 bits: the gather takes the low half, and
+//    — told by bit 0 of the source address — the upper half of a literal >= 65536 (one extra
+//    predicated read in the groups that hold one); a dictionary entry holding such a value and a cold
+//    entry of 16 integers (two in a DSF-65536-16 dictionary) are SLOW: expanded as zeros, then written
+//    by the codeword's own lane straight to global memory (slow_stores), behind the tile's stores;
 //  * WAITS: gfx950 counts loads and stores in one in-order counter, so a tile has exactly one
-//    wait point — after its cold fetch, before its stores — where everything prefetched is
-//    consumed (read-write asm barriers, so that the compiler never adds a wait behind the
-//    stores, which would be a wait for their acknowledgements).
+//    wait point — before its expansion — where everything prefetched is consumed (read-write
+//    asm barriers, so that the compiler never adds a wait behind the stores, which would be a
+//    wait for their acknowledgements).
 //
 // LDS (160 KB/CU, one 1024-thread workgroup per CU):
-//   [ 256 zero words | hot meta | hot payloads ]  <= kHotImageWords, shared by 16 waves
+//   [ 256 u16 zeros | hot meta | hot payloads (u16) ]  <= kHotImageWords, shared by 16 waves
 //   [ slot classification table, 1.3 KB ]
-//   16 x [ {flag word, rank base} pairs | per-codeword delta table | staging cells ]
+//   16 x [ {flag word, rank base} pairs | per-codeword delta table | 256 staging cells of 16 bytes ]
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -46,35 +52,26 @@ namespace dint_dev {
 // Cache policy of the output stores (gfx940+ aux bits: 1 = sc0, 2 = nt, 16 = sc1). The decoded integers are
 // written once and never read by this kernel: non-temporal stores keep the 4 bytes/integer output stream
 // from evicting the dictionary's cold part and the block directories out of L2 and from queueing
-// behind write-back traffic — 0.97 -> 0.72 ms on the 4e8-posting run, the largest single gain measured.
+// behind write-back traffic — 0.97 -> 0.72 ms on the 4e8-posting run, the largest single gain of round 1.
 #ifndef DINT_STORE_AUX
 #define DINT_STORE_AUX 2
-#endif
-#ifndef DINT_STREAM_LOADS_NT
-#define DINT_STREAM_LOADS_NT 0  // 1: the codeword stream is read with non-temporal loads as well
 #endif
 #ifndef DINT_BLOCK_THREADS
 #define DINT_BLOCK_THREADS 1024
 #endif
-#ifndef DINT_BLOCKS_PER_CU
-#define DINT_BLOCKS_PER_CU 1
+#ifndef DINT_GATHER_AUX
+#define DINT_GATHER_AUX 0  // cache policy of the metadata / row gathers (L2-resident tables, no reuse in L1)
 #endif
 
 constexpr uint32_t kWave = 64;
 constexpr uint32_t kBlockThreads = DINT_BLOCK_THREADS;
 constexpr uint32_t kWavesPerBlock = kBlockThreads / kWave;
-constexpr uint32_t kBlocksPerCU = DINT_BLOCKS_PER_CU;
-constexpr uint32_t kLdsWords = 160 * 1024 / 4 / kBlocksPerCU;
+constexpr uint32_t kBlocksPerCU = 1;
+constexpr uint32_t kLdsWords = 160 * 1024 / 4;
 constexpr uint32_t kSPL = 4;                          // slots per lane per tile
 constexpr uint32_t kTileSlots = kWave * kSPL;         // 256 slots per tile
 #ifndef DINT_GROUPS
 #define DINT_GROUPS 2
-#endif
-#ifndef DINT_EARLY_METAS
-#define DINT_EARLY_METAS 0
-#endif
-#ifndef DINT_UNIT_CHAIN
-#define DINT_UNIT_CHAIN 0  // 1: single-dictionary units request their successor's first tiles (measured: no gain)
 #endif
 constexpr uint32_t kGroups = DINT_GROUPS;             // 256-output groups expanded together (one round)
 constexpr uint32_t kRounds = 8 / kGroups;             // rounds per batch (single-dictionary segments)
@@ -83,36 +80,42 @@ constexpr uint32_t kMaxCap = 2048;                    // outputs per expansion b
 // entries for codewords that are not live in a batch), staging cells
 constexpr uint32_t kFwWords = 2 * 64 + 4;              // 64 pairs: flag positions are taken mod 2048
 constexpr uint32_t kDeltaWords = kTileSlots + 4;
-#ifndef DINT_STAGE_QUADS
-#define DINT_STAGE_QUADS 128
+constexpr uint32_t kStageWords = 4 * kTileSlots;       // one 16-byte cell per slot: cell (k, lane) = 64 k + lane
+#ifdef DINT_PROFILE
+constexpr uint32_t kProfWords = 16;
+#else
+constexpr uint32_t kProfWords = 0;
 #endif
-constexpr uint32_t kStageQuads = DINT_STAGE_QUADS;     // 16-byte cells: cold payloads and exception literals of a batch
-constexpr uint32_t kStageWords = 4 * kStageQuads;      // (its first half doubles as the fetch worklist)
-constexpr uint32_t kScratchWords = kFwWords + kDeltaWords + kStageWords;
+constexpr uint32_t kScratchWords = kFwWords + kDeltaWords + kStageWords + kProfWords;
 constexpr uint32_t kClassTableWords = 328;            // slot classification table: 648 u16 rows, padded
 constexpr uint32_t kHotImageWords = kLdsWords - kClassTableWords - kWavesPerBlock * kScratchWords;
-constexpr uint32_t kZeroWords = 256;                  // longest run codeword
-constexpr uint32_t kColdBase = 1u << 23;              // source offsets >= this live in global memory
-constexpr uint32_t kColdBase4 = 4 * kColdBase;        // the same in bytes
+constexpr uint32_t kZeroHalves = 256;                 // longest run codeword, in u16
+// metadata word of a codeword: (size - 1) << 24 | kMetaCold | kMetaSlow | cells << 20 | LDS byte offset
+constexpr uint32_t kMetaCold = 1u << 23;              // the integers come through staging cells (row table)
+constexpr uint32_t kMetaSlow = 1u << 22;              // ... or, with this bit, from gtable through slow_stores
+constexpr uint32_t kMetaOffMask = (1u << 20) - 1;     // hot: byte offset of the integers (u16 each) in the LDS image; else 0
+                                                      // bits 20-21: staging cells a cold codeword takes (1: up to 8 integers, 2)
 constexpr uint32_t kQueueShards = 8;                  // dynamic unit queue: one counter per shard
 constexpr uint32_t kQueueStride = 32;                 // words between counters (own 128-byte line each)
+constexpr uint32_t kMaxUnitInts = 1u << 28;           // byte offsets inside a unit's output stay 32-bit
 
 // One dictionary of the (possibly multi-) dictionary file.
 struct dict_desc {
-    uint32_t meta_base;    // first slot of this dictionary in gmeta
+    uint32_t meta_base;    // first slot of this dictionary in gmeta / the row table
     uint32_t hot_base;     // LDS word offset of its hot meta table
     uint32_t hot_k;        // codewords < hot_k have meta + payload in the LDS image
     uint32_t pad;
 };
 
-// Device view of a dictionary file.
+// Device view of a dictionary file (layout: dint_hip.hip, stage_dictionary).
 struct dict_view {
-    const uint32_t* gmeta;      // per codeword slot: (size-1) << 24 | kColdBase | word offset into gtable
-    const uint32_t* gtable;     // [256 zeros][payload words...]
-    const uint32_t* lds_image;  // [256 zeros]{[hot meta of dictionary d]}[hot payloads], hot_words long
+    const uint8_t* tables;      // gmeta (u32 per slot) | rows (32 bytes per slot) | goff (u32 per slot) | gtable (u32 payload words)
+    const uint32_t* lds_image;  // [256 u16 zeros]{[hot meta of dictionary d]}[hot payloads as u16], hot_words long
     const dict_desc* descs;     // one per dictionary (multi: 6)
-    uint32_t gmeta_words;
-    uint32_t gtable_words;
+    uint32_t tables_bytes;
+    uint32_t rows_base;         // byte offset of the row table inside `tables`
+    uint32_t goff_base;         // ... of the slow path's offsets into gtable (u32 per slot)
+    uint32_t gtable_base;       // ... of gtable
     uint32_t hot_words;         // multiple of 4
     dict_desc first;            // descs[0], for the single-dictionary kernel
 };
@@ -133,15 +136,13 @@ struct decode_args {
                            // c > 1 = leads a bundle of c consecutive tiny units (bundle_schedule_kernel)
     const uint32_t* items; // with sched: the units with sched != 0, in order — what the queue hands out
     const uint32_t* n_items;
+    const uint8_t* item_cnt;  // with sched: sched[items[w]] per work item
     const uint32_t* spans; // nullable; per unit an upper bound of its stream bytes (else: up to the next unit's start)
     uint32_t plus_one;     // in-index freqs parts: every decoded integer + 1 (dict_posting_list.hpp:164-169)
 };
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-struct __attribute__((packed, aligned(4))) u32x4_a4 {
-    u32x4 v;
-};
 struct __attribute__((packed, aligned(1))) u32x4_a1 {
     u32x4 v;
 };
@@ -151,20 +152,31 @@ struct __attribute__((packed, aligned(1))) u32x2_a1 {
 struct __attribute__((packed, aligned(1))) u32_a1 {
     uint32_t v;
 };
+typedef __attribute__((address_space(3))) void lds_void;
 
 __device__ __forceinline__ uint32_t lane_id() {
     return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
-// Inclusive prefix sum over the 64 lanes, in registers: four row_shr steps inside
-// each row of 16, then row_bcast:15 / row_bcast:31 across rows (gfx9 DPP).
+// Inclusive prefix sum over the 64 lanes, in registers: four row_shr steps inside each row of 16, then
+// row_bcast:15 / row_bcast:31 across rows (gfx9 DPP) — written out: the builtin form compiled to three
+// instructions a step (mov 0, mov_dpp, add) wherever the combine pass gave up. A VALU result needs two wait
+// states before a DPP instruction reads it.
 __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
-    x += __builtin_amdgcn_update_dpp(0u, x, 0x111, 0xf, 0xf, false);  // row_shr:1
-    x += __builtin_amdgcn_update_dpp(0u, x, 0x112, 0xf, 0xf, false);  // row_shr:2
-    x += __builtin_amdgcn_update_dpp(0u, x, 0x114, 0xf, 0xf, false);  // row_shr:4
-    x += __builtin_amdgcn_update_dpp(0u, x, 0x118, 0xf, 0xf, false);  // row_shr:8
-    x += __builtin_amdgcn_update_dpp(0u, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
-    x += __builtin_amdgcn_update_dpp(0u, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
+    asm("s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(x));
     return x;
 }
 
@@ -180,8 +192,20 @@ __device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t x) {
     return x;
 }
 
+// The value of the lane below (lane 0: zero) / above (lane 63: zero): one DPP move instead of a trip
+// through the LDS crossbar (ds_bpermute, what __shfl_up / __shfl_down compile to).
+__device__ __forceinline__ uint32_t from_lane_below(uint32_t x) {
+    return __builtin_amdgcn_update_dpp(0u, x, 0x138, 0xf, 0xf, true);  // wave_shr:1
+}
+__device__ __forceinline__ uint32_t from_lane_above(uint32_t x) {
+    return __builtin_amdgcn_update_dpp(0u, x, 0x130, 0xf, 0xf, true);  // wave_shl:1
+}
+
 __device__ __forceinline__ uint32_t readlane(uint32_t x, uint32_t l) { return __builtin_amdgcn_readlane(x, l); }
 __device__ __forceinline__ uint32_t uniform(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ uint64_t uniform64(uint64_t x) {
+    return (uint64_t(uniform(uint32_t(x >> 32))) << 32) | uniform(uint32_t(x));
+}
 
 // Orders this wave's LDS traffic between phases that communicate across lanes.
 // LDS operations of one wave execute in issue order, so no hardware barrier is
@@ -203,20 +227,12 @@ __device__ __forceinline__ uint64_t load_lane_slots(const uint8_t* enc, uint64_t
                                                     uint64_t enc_bytes) {
     constexpr uint32_t kBytes = kSPL * W / 8;
     const uint64_t byte_off = tile_byte + uint64_t(kBytes) * lane;
-    if (tile_byte + uint64_t(kBytes) * kWave <= enc_bytes) {  // wave-uniform
+    if (tile_byte <= enc_bytes && enc_bytes - tile_byte >= uint64_t(kBytes) * kWave) {  // wave-uniform
         if (W == 16) {
-#if DINT_STREAM_LOADS_NT
-            const u32x2 r = __builtin_nontemporal_load(&reinterpret_cast<const u32x2_a1*>(enc + byte_off)->v);
-#else
             const u32x2 r = reinterpret_cast<const u32x2_a1*>(enc + byte_off)->v;
-#endif
             return (uint64_t(r.y) << 32) | r.x;
         }
-#if DINT_STREAM_LOADS_NT
-        return __builtin_nontemporal_load(&reinterpret_cast<const u32_a1*>(enc + byte_off)->v);
-#else
         return reinterpret_cast<const u32_a1*>(enc + byte_off)->v;
-#endif
     }
     const uint64_t last_valid = enc_bytes - kBytes;  // enc_bytes >= 8 is checked by the host
     const uint64_t o = byte_off < last_valid ? byte_off : last_valid;
@@ -234,6 +250,10 @@ __device__ __forceinline__ uint64_t load_lane_slots(const uint8_t* enc, uint64_t
 struct tile_regs {
     uint32_t s[kSPL];  // slot values
     uint32_t m[kSPL];  // metadata of each slot read as a codeword (garbage for payload slots)
+};
+struct meta_regs {     // a tile's metadata on its way in: the two sources are merged where the wait is
+    uint32_t h[kSPL];  // from the LDS image (meaningful for s < hot_k)
+    uint32_t c[kSPL];  // from L2 (s >= hot_k)
 };
 
 template <int W>
@@ -286,12 +306,74 @@ __device__ __forceinline__ void build_class_table(uint16_t* table) {
 #else
 #define MARK(name) do {} while (0)
 #endif
+// Under -DDINT_PROFILE (a diagnostic build, tools/variants/) the marks also stamp the shader clock.
+#ifdef DINT_PROFILE
+#include "dint_profile.hpp"
+#else
+struct prof_t {};
+#define SECTION(pf, id, name) MARK(name)
+#endif
 
-// Segment chaining. Multi-dictionary units: a block's bytes are known only when the previous block
+// What a wavefront carries through every unit it decodes.
+struct wave_ctx {
+    const uint32_t* lds;           // the workgroup's LDS (the dictionary image first)
+    const uint16_t* cls;           // slot classification table
+    uint32_t* scratch;             // this wave's {flag pairs | delta table | staging cells}
+    uint32_t lane;
+    __amdgpu_buffer_rsrc_t rs_dict;  // gmeta | rows | gtable: one descriptor, hardware bounds
+    uint32_t rows_base, goff_base, gtable_base;
+};
+
+__device__ __forceinline__ uint32_t* fw_of(uint32_t* scratch) { return scratch; }
+__device__ __forceinline__ uint32_t* delta_of(uint32_t* scratch) { return scratch + kFwWords; }
+__device__ __forceinline__ uint32_t* stage_of(uint32_t* scratch) { return scratch + kFwWords + kDeltaWords; }
+
+// Metadata of the four slots of a lane: LDS for the hot codewords (unconditional reads, all four in flight
+// together: cold lanes read word 0), L2 for the cold ones under their exec mask — into registers of their
+// own, so that nothing has to wait for the LDS reads before the loads are issued (the two are merged where
+// the tile is unpacked, one tile later). Two address spaces, never a pointer select (that would become one
+// slow flat load).
+__device__ __forceinline__ void request_metas(const wave_ctx& c, uint32_t hot_base, uint32_t hot_k, uint32_t meta_base,
+                                              const tile_regs& t, meta_regs& mr) {
+    // (the word behind a dictionary's hot metas is a dummy: the cold lanes read it, min instead of compare + select)
+#pragma unroll
+    for (uint32_t k = 0; k != kSPL; ++k) mr.h[k] = c.lds[hot_base + (t.s[k] < hot_k ? t.s[k] : hot_k)];
+#pragma unroll
+    for (uint32_t k = 0; k != kSPL; ++k)
+        if (t.s[k] >= hot_k) mr.c[k] = __builtin_amdgcn_raw_buffer_load_b32(c.rs_dict, 4 * (meta_base + t.s[k]), 0, DINT_GATHER_AUX);
+}
+// ... where the wait is: everything has landed (the asm makes the values the asm's, not a load's: nothing
+// for the compiler to wait for later)
+__device__ __forceinline__ void take_metas(uint32_t hot_k, meta_regs& mr, tile_regs& t) {
+    asm volatile("" : "+v"(mr.c[0]), "+v"(mr.c[1]), "+v"(mr.c[2]), "+v"(mr.c[3]));
+    asm volatile("" : "+v"(mr.h[0]), "+v"(mr.h[1]), "+v"(mr.h[2]), "+v"(mr.h[3]));
+#pragma unroll
+    for (uint32_t k = 0; k != kSPL; ++k) t.m[k] = t.s[k] < hot_k ? mr.h[k] : mr.c[k];
+}
+
+// The rows of the cold slots of a tile: 32 bytes per dictionary slot — the entry's integers as sixteen u16 —
+// addressed by the slot value alone. The first half (8 integers: all a codeword of size <= 8 needs) is
+// requested by the slot's own lane at the end of the PREVIOUS tile, one 16-byte load per cold slot, and
+// written into the codeword's staging cell where the tile waits; the second half (cold codewords of 16
+// integers: 3.5 % of the slots of a Gov2-shaped stream) is requested there, into the same registers, and
+// lands behind the flag/delta phase. Whether a slot is a codeword at all is not known when the first halves
+// are requested (classification comes later): a payload slot that looks like a cold codeword fetches a row
+// nobody reads.
+// (LDS-DMA — buffer_load ... lds with per-lane offsets, no registers — delivers the right bytes,
+// tools/micro/lds_dma.hip, but its destination is fixed by the lane number: a cell per SLOT instead of per
+// cold codeword, 8 KB per wave with 32-byte rows — the LDS the dictionary's hot part lives on.)
+struct row_regs {
+    u32x4 q[kSPL];
+};
+__device__ __forceinline__ void request_rows(const wave_ctx& c, uint32_t hot_k, uint32_t meta_base, const tile_regs& t, row_regs& r) {
+#pragma unroll
+    for (uint32_t k = 0; k != kSPL; ++k)
+        if (t.s[k] >= hot_k) r.q[k] = __builtin_amdgcn_raw_buffer_load_b128(c.rs_dict, c.rows_base + 32 * (meta_base + t.s[k]), 0, DINT_GATHER_AUX);
+}
+
+// Segment chaining (multi-dictionary units): a block's bytes are known only when the previous block
 // has been parsed, so a block on its own pays the full memory latency of its selector and its slots
-// before it can start. Single-dictionary units: nine in ten posting lists are shorter than one tile
-// (Gov2-shaped lengths), each is its own unit, and a wave knows its next unit while it decodes the
-// current one. Chained, the first kChainBytes of the next block (16 per lane, from the byte
+// before it can start. Chained, the first kChainBytes of the next block (16 per lane, from the byte
 // after its selector on) and its selector are requested as soon as the current block's end is known
 // — after the scans, before its expansion and stores — and are re-laid-out lane to lane
 // (ds_bpermute) into the first two tiles of the next segment.
@@ -299,7 +381,6 @@ constexpr uint32_t kChainBytes = 16 * kWave;
 struct chain_io {
     u32x4 data;     // bytes [16 * lane, 16 * lane + 16) of the segment's slot stream
     uint32_t sel;   // the byte before them (the block's selector) in bits 0-7
-    uint64_t next_off;  // in: where the next segment's selector byte is, or ~0: right after this segment
     bool more;      // in: a segment follows this one
     bool valid;     // out: data / sel hold the next segment's bytes
 };
@@ -326,283 +407,286 @@ __device__ __forceinline__ uint64_t chain_tile(const u32x4& d, uint32_t t, uint3
     return c == 0 ? x : c == 1 ? y : c == 2 ? z : w;
 }
 
-// What a tile's front end hands to its expansion, per lane (slot k = 0..3 of the lane) and per wave.
+// What a tile's front end hands to its tables and expansion, per lane (slot k = 0..3 of the lane) and per wave.
 struct tile_slots {
-    uint32_t live[kSPL];    // all ones: a codeword header inside the segment
-    uint32_t off4[kSPL];    // byte offset of its first output behind the lane's first
-    uint32_t lord[kSPL];    // its ordinal behind the lane's first codeword
-    uint32_t src4[kSPL];    // source byte address (LDS; cold: table offset + kColdBase4)
-    uint32_t pk[kSPL];      // staging cells it needs | 1 << 16 if they are fetched from the table
-    uint32_t cpre[kSPL];    // prefix of pk inside the lane
-    uint32_t lit[kSPL];     // all ones: exception header (its value is in excval)
-    uint32_t excval[kSPL];
+    uint32_t off[kSPL];     // first output of slot k's codeword behind the lane's first (integers)
+    uint32_t src2[kSPL];    // LDS byte address of its integers (u16 each): hot payload, zero region, its staging cell(s);
+                            // bit 0: the cell holds a 32-bit exception literal
+    uint32_t need[kSPL];    // staging cells it takes: 0, 1 (exception literal; cold codeword of up to 8 integers), 2 (larger)
     uint32_t lsum, obase;   // outputs of the lane's live codewords, position of the first
-    uint32_t rbase, nlive;  // ordinal of its first live codeword, how many it has
-    uint32_t cl, qb, wb;    // pk sum of the lane; first cell / first fetch of the lane
     uint32_t total;         // outputs of the tile (wave-uniform)
-    uint32_t plus_one;      // add one to every output (wave-uniform; the in-index freqs parts)
-    bool tile_exc, tile_staged;  // some lane holds an exception / needs staging (wave-uniform)
+    // tiles that are not plain (an exception or a payload slot somewhere, the segment's last tile, a bundle):
+    uint32_t row;           // the lane's classification row: bit 11 / bits 12-13 / bits 14-15 = ordinal of slot 1 / 2 / 3
+                            // behind the lane's first codeword; bits 4-7: exception headers
+    uint32_t liveb;         // bit k: slot k is a codeword header inside the segment
+    uint32_t rbase, nlive;  // ordinal of the lane's first live codeword, how many it has
+    __device__ __forceinline__ uint32_t lord(uint32_t k) const {
+        return k == 0 ? 0u : k == 1 ? (row >> 11) & 1u : k == 2 ? (row >> 12) & 3u : (row >> 14) & 3u;
+    }
 };
+constexpr uint32_t kPlainRow = (1u << 11) | (2u << 12) | (3u << 14);  // four codeword headers, nothing special
+constexpr uint32_t kStageCells = kStageWords / 4;
 
-// Steps 3 and 4 of a tile: batches of at most ROUNDS x GROUPS x 256 outputs and kStageQuads staging
-// cells (normally one: the whole tile) — cold fetch, flag/delta tables, staging, expansion, stores.
-// `before_stores` runs once before the first store is issued: the caller parks there the waits for
-// everything it has prefetched (see decode_segment).
-template <uint32_t ROUNDS, uint32_t GROUPS, class BeforeStores>
-__device__ __forceinline__ void expand_tile(const tile_slots& t, uint32_t out_int0, const uint32_t* lds, uint32_t* scratch,
-                                            const __amdgpu_buffer_rsrc_t rs_table, const __amdgpu_buffer_rsrc_t rs_out,
-                                            uint32_t* const out, uint32_t lane, BeforeStores&& before_stores) {
+// Staging cells of a tile: one 16-byte cell per exception literal and per cold codeword of up to 8 integers,
+// two for the larger ones; allocated in slot order by one wave scan over t.need. -> the cell's LDS byte
+// address per slot; returns the cells the tile takes (wave-uniform).
+__device__ __forceinline__ uint32_t allocate_cells(const tile_slots& t, uint32_t stage_byte0, uint32_t (&cell_addr)[kSPL]) {
+    const uint32_t pre1 = t.need[0], pre2 = pre1 + t.need[1], pre3 = pre2 + t.need[2], mine = pre3 + t.need[3];
+    const uint32_t incl = wave_inclusive_sum(mine);
+    cell_addr[0] = stage_byte0 + 16 * (incl - mine);
+    cell_addr[1] = cell_addr[0] + 16 * pre1;
+    cell_addr[2] = cell_addr[0] + 16 * pre2;
+    cell_addr[3] = cell_addr[0] + 16 * pre3;
+    return readlane(incl, 63);
+}
+
+// ---- the flag / delta / rank-base tables of a batch: one LDS phase, written by the codewords' lanes ----
+// A flag bit at each codeword's first output (the flag words are zero: cleared at the end of the previous
+// batch), `source - position` by ordinal, and the rank base (codewords before the word, minus one) of every
+// flag word that begins inside this lane's outputs.
+//
+// A plain tile — four codeword headers in every lane, nothing clamped, one batch: ordinals are 4 lane + k, the
+// four deltas of a lane are one 16-byte store, nothing is masked.
+__device__ __forceinline__ void tables_plain(const tile_slots& t, uint8_t* fw, uint8_t* delta, uint32_t lane) {
+    uint32_t rel[kSPL];
+    rel[0] = t.obase;
+#pragma unroll
+    for (uint32_t k = 1; k != kSPL; ++k) rel[k] = t.obase + t.off[k];
+    u32x4 d;
+#pragma unroll
+    for (uint32_t k = 0; k != kSPL; ++k) {
+        uint32_t* const fword = reinterpret_cast<uint32_t*>(fw + ((rel[k] >> 2) & 0x1F8u));
+        __hip_atomic_fetch_or(fword, 1u << (rel[k] & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        d[k] = t.src2[k] - 2 * rel[k];
+    }
+    *reinterpret_cast<u32x4*>(delta + 16 * lane) = d;
+    const uint32_t rel_end = t.obase + t.lsum;
+#pragma nounroll
+    for (uint32_t w = (t.obase + 31u) >> 5; 32u * w < rel_end; ++w) {  // 0 or 1 rounds for most lanes
+        const uint32_t lim = 32u * w - t.obase;  // codewords of this lane that start before the word: 0 (lim = 0) .. 4
+        const uint32_t cnt = (lim != 0 ? 1u : 0u) + (t.off[1] < lim ? 1u : 0u) + (t.off[2] < lim ? 1u : 0u) + (t.off[3] < lim ? 1u : 0u);
+        *reinterpret_cast<uint32_t*>(fw + 8 * w + 4) = 4 * lane + cnt - 1u;
+    }
+}
+
+// Any tile, one batch of it: the lanes `inb`, outputs and ordinals counted from `done` / `rdone`. Every slot
+// runs the same instructions: a codeword that is not live in this batch ORs a zero into an in-range flag word
+// and parks its delta in a dummy.
+__device__ __forceinline__ void tables_general(const tile_slots& t, uint8_t* fw, uint8_t* delta, bool inb, uint32_t done,
+                                               uint32_t rdone) {
+    const uint32_t inbM = inb ? ~0u : 0u;
+    const uint32_t rel0 = t.obase - done, ord0 = t.rbase - rdone;
+#pragma unroll
+    for (uint32_t k = 0; k != kSPL; ++k) {
+        const uint32_t lv = uint32_t(__builtin_amdgcn_sbfe(t.liveb, k, 1)) & inbM;
+        const uint32_t rel = rel0 + t.off[k];
+        uint32_t* const fword = reinterpret_cast<uint32_t*>(fw + ((rel >> 2) & 0x1F8u));
+        __hip_atomic_fetch_or(fword, lv & (1u << (rel & 31u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const uint32_t ord = (lv & (ord0 + t.lord(k))) | (~lv & (kTileSlots + k));
+        *reinterpret_cast<uint32_t*>(delta + 4 * ord) = t.src2[k] - 2 * rel;
+    }
+    if (inb) {
+        const uint32_t rel_end = rel0 + t.lsum;
+#pragma nounroll
+        for (uint32_t w = (rel0 + 31u) >> 5; 32u * w < rel_end; ++w) {
+            const uint32_t lim = 32u * w - rel0;
+            uint32_t cnt = 0;
+#pragma unroll
+            for (uint32_t k = 0; k != kSPL; ++k) cnt += ((t.liveb >> k) & (t.off[k] < lim ? 1u : 0u));
+            *reinterpret_cast<uint32_t*>(fw + 8 * (w & 63u) + 4) = ord0 + cnt - 1u;
+        }
+    }
+}
+
+// ---- expansion of a batch of `bt` outputs, GROUPS * 256 per round: each lane takes 4 consecutive outputs of
+// every 256-output group — flag word + rank base -> 4 ranks -> 4 deltas -> 4 LDS gathers (u16) -> one 16-byte
+// non-temporal store; every source is an LDS byte address by now. Stores are whole 16-byte quads: the
+// descriptor clips what lies past the segment's n integers (range checking is per dword), and what a quad
+// writes past this batch's end inside the segment is rewritten by the batches and tiles that follow (same
+// wave, program order). WIDE: the batch may hold 32-bit exception literals — bit 0 of a delta (sources and
+// positions are even) says the upper half follows the lower one in the staging cell.
+template <uint32_t ROUNDS, uint32_t GROUPS, bool WIDE>
+__device__ __forceinline__ void expand_batch(uint32_t bt, uint32_t out_int, const uint8_t* lds_bytes, const uint8_t* fw,
+                                             const uint8_t* delta, const __amdgpu_buffer_rsrc_t rs_out, uint32_t lane,
+                                             uint32_t plus_one) {
+    // lane constants: this lane owns outputs 4*lane .. 4*lane+3 of every group
+    const uint32_t sh = (4 * lane) & 31u;                 // bit position of its nibble in its flag word
+    const uint32_t pair_byte = (lane >> 3) * 8;           // its {flag, base} pair inside a group's 8 pairs
+#pragma unroll
+    for (uint32_t rd = 0; rd != ROUNDS; ++rd) {
+        if (rd * GROUPS * 4 * kWave < bt) {  // wave-uniform
+            const uint32_t obyte = 4 * out_int + rd * GROUPS * 16 * kWave;  // output byte offset of the round
+            uint32_t x[GROUPS][4];
+#pragma unroll
+            for (uint32_t g = 0; g != GROUPS; ++g) {
+                if ((rd * GROUPS + g) * 4 * kWave < bt) {  // wave-uniform
+                    const u32x2 pr = *reinterpret_cast<const u32x2*>(fw + (rd * GROUPS + g) * 64 + pair_byte);
+                    const uint32_t w = pr.x;
+                    const uint32_t base = pr.y + uint32_t(__builtin_popcount(__builtin_amdgcn_ubfe(w, 0u, sh)));  // flags below its nibble
+                    const uint32_t nib = w >> sh;
+                    uint32_t r[4];
+                    r[0] = base + (nib & 1u);
+                    r[1] = base + uint32_t(__builtin_popcount(nib & 3u));
+                    r[2] = base + uint32_t(__builtin_popcount(nib & 7u));
+                    r[3] = base + uint32_t(__builtin_popcount(nib & 15u));
+                    const uint32_t pos2 = (rd * GROUPS + g) * 8 * kWave + 8 * lane;  // source byte position in the batch
+                    if (!WIDE) {
+#pragma unroll
+                        for (int k = 0; k != 4; ++k) {
+                            const uint32_t ad = *reinterpret_cast<const uint32_t*>(delta + 4 * r[k]) + pos2 + 2 * k;
+                            x[g][k] = *reinterpret_cast<const uint16_t*>(lds_bytes + ad);
+                        }
+                    } else {
+                        uint32_t ad[4], wide = 0;
+#pragma unroll
+                        for (int k = 0; k != 4; ++k) {
+                            const uint32_t d = *reinterpret_cast<const uint32_t*>(delta + 4 * r[k]);
+                            wide |= (d & 1u) << k;
+                            ad[k] = (d & ~1u) + pos2 + 2 * k;
+                            x[g][k] = *reinterpret_cast<const uint16_t*>(lds_bytes + ad[k]);
+                        }
+#pragma unroll
+                        for (int k = 0; k != 4; ++k)
+                            if ((wide >> k) & 1u) x[g][k] |= uint32_t(*reinterpret_cast<const uint16_t*>(lds_bytes + ad[k] + 2)) << 16;
+                    }
+                }
+            }
+            MARK("9_stores");
+#pragma unroll
+            for (uint32_t g = 0; g != GROUPS; ++g) {
+                const uint32_t p0 = (rd * GROUPS + g) * 4 * kWave + 4 * lane;
+                if ((rd * GROUPS + g) * 4 * kWave < bt) {  // wave-uniform
+                    if (p0 < bt) {
+                        u32x4 xv = {x[g][0], x[g][1], x[g][2], x[g][3]};
+                        if (plus_one) xv += 1u;  // wave-uniform branch: nothing on the plain decode path
+                        __builtin_amdgcn_raw_buffer_store_b128(xv, rs_out, 16 * g * kWave + 16 * lane, obyte, DINT_STORE_AUX);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Steps 3 and 4 of a tile: tables, expansion, stores — in one batch when the tile decodes to at most
+// ROUNDS x GROUPS x 256 integers (every tile of a real stream), else in batches of lanes (a tile full of long
+// runs: up to 256 x 256 integers). `plain`: tables_plain applies. `wide`: the tile holds a 32-bit exception
+// literal. `before_gathers` runs before the gathers of every batch: the caller lands there what it requested
+// at the wait point (decode_segment).
+// (The one-batch path is straight-line on purpose: inside a loop over batches everything the tables are built
+// from would stay live through the expansion — 55 more registers, measured.)
+template <uint32_t ROUNDS, uint32_t GROUPS, class BeforeGathers>
+__device__ __forceinline__ void expand_tile(const tile_slots& t, bool plain, bool wide, uint32_t plus_one, uint32_t out_int0,
+                                            const uint32_t* lds, uint32_t* scratch, const __amdgpu_buffer_rsrc_t rs_out,
+                                            uint32_t lane, prof_t& pf, BeforeGathers&& before_gathers) {
+    (void)pf;
     constexpr uint32_t kCap = ROUNDS * GROUPS * 256;
     static_assert(kCap <= kMaxCap, "the flag bitmap holds 2048 positions");
     // per-wave scratch (byte offsets): {flag word, rank base} pairs | delta table | staging cells
-    uint8_t* const fw = reinterpret_cast<uint8_t*>(scratch);                  // 64 pairs of 8 bytes (+1 spare)
-    uint8_t* const delta = reinterpret_cast<uint8_t*>(scratch + kFwWords);    // 256 entries + 4 dummies
-    uint8_t* const stage = reinterpret_cast<uint8_t*>(scratch + kFwWords + kDeltaWords);  // 128 cells of 16 bytes
+    uint8_t* const fw = reinterpret_cast<uint8_t*>(fw_of(scratch));        // 64 pairs of 8 bytes (+1 spare)
+    uint8_t* const delta = reinterpret_cast<uint8_t*>(delta_of(scratch));  // 256 entries + 4 dummies
     const uint8_t* const lds_bytes = reinterpret_cast<const uint8_t*>(lds);
-    const uint32_t stage_off = uint32_t(stage - lds_bytes);                   // the cells as gather sources
-    // lane constants of the expansion: this lane owns outputs 4*lane .. 4*lane+3 of every group
-    const uint32_t sh = (4 * lane) & 31u;                 // bit position of its nibble in its flag word
-    const uint32_t pair_byte = (lane >> 3) * 8;           // its {flag, base} pair inside a group's 8 pairs
-    (void)out;
-    MARK("4_batch_select");
-    // ---- 3./4. batches of <= kCap outputs and <= kStageQuads cells (normally one: the whole tile)
-    // (a do-while: the compiler must see that the wait inside precedes the register rotation
-    // below on every path, or it waits again there — after the stores, for their acknowledgements)
-    uint32_t done = 0, rdone = 0, qdone = 0, wdone = 0;
+    SECTION(pf, 4, "4_tables");
+    if (__builtin_expect(t.total <= kCap, 1)) {
+        const uint32_t total = t.total;
+        if (plain) tables_plain(t, fw, delta, lane);
+        else tables_general(t, fw, delta, t.lsum != 0, 0u, 0u);
+        wave_lds_fence();
+        SECTION(pf, 7, "7_rows2");
+        before_gathers();
+        SECTION(pf, 9, "9_expand");
+        if (__builtin_expect(wide, 0)) expand_batch<ROUNDS, GROUPS, true>(total, out_int0, lds_bytes, fw, delta, rs_out, lane, plus_one);
+        else expand_batch<ROUNDS, GROUPS, false>(total, out_int0, lds_bytes, fw, delta, rs_out, lane, plus_one);
+        // the flag words go back to zero for the next batch (this wave's LDS operations execute in order)
+        *reinterpret_cast<uint32_t*>(fw + 8 * lane) = 0;
+        wave_lds_fence();
+        return;
+    }
+    uint32_t done = 0, rdone = 0;
     do {
-        const bool inb = t.lsum != 0 && t.obase >= done && (t.obase + t.lsum - done) <= kCap &&
-                         (t.qb + (t.cl & 0xFFFFu) - qdone) <= kStageQuads &&
-                         (kStageQuads <= 2 * kWave || (t.wb + (t.cl >> 16) - wdone) <= 2 * kWave);  // two fetches per lane
+        // the lanes of this batch: as many as the flag bitmap has room for
+        const bool inb = t.lsum != 0 && t.obase >= done && (t.obase + t.lsum - done) <= kCap;
         const uint64_t bm = __ballot(inb);
         const uint32_t last = 63u - uint32_t(__builtin_clzll(bm | 1ull));
         const uint32_t bend = readlane(t.obase + t.lsum, last);
         const uint32_t rend = readlane(t.rbase + t.nlive, last);
-        const uint32_t qend = readlane(t.qb + (t.cl & 0xFFFFu), last);
-        const uint32_t wend = readlane(t.wb + (t.cl >> 16), last);
         if (bend <= done) {  // (malformed input: nothing decodable left in this tile)
-            before_stores();  // every way out of the loop passes the caller's wait point
+            before_gathers();
             break;
         }
-        const uint32_t bt = bend - done;        // outputs in this batch, 1..kCap
-        const uint32_t nfetch = wend - wdone;   // cold codewords to fetch, <= kStageQuads
-        const uint32_t inbM = inb ? ~0u : 0u;
-
-        MARK("5_worklist");
-        // (a) worklist of the cold codewords {table byte offset, cell | quads << 16}, then each
-        // lane takes up to two of them and fetches their first two quads (sizes 1..8); the
-        // fetches fly while the batch tables are built
-        uint32_t srcb[kSPL];
-#pragma unroll
-        for (uint32_t k = 0; k != kSPL; ++k) srcb[k] = t.src4[k];
-        // (deliberately uninitialised: each is written and read under the same lane predicate)
-        u32x2 e0, e1;
-        u32x4 q00, q01, q10, q11;
-        if (t.tile_staged) {
-#pragma unroll
-            for (uint32_t k = 0; k != kSPL; ++k) {
-                const uint32_t lv = t.live[k] & inbM;
-                const uint32_t cell = t.qb - qdone + (t.cpre[k] & 0xFFFFu);
-                if (lv != 0 && (t.pk[k] & 0xFFFFu) != 0) srcb[k] = stage_off + 16u * cell;
-                // every slot writes an entry: the ones with nothing to fetch park it past the list
-                const bool fetch = lv != 0 && (t.pk[k] >> 16) != 0;
-                const u32x2 e = {t.src4[k] - kColdBase4, cell | (t.pk[k] << 16)};
-                *reinterpret_cast<u32x2*>(stage + 8u * (fetch ? t.wb - wdone + (t.cpre[k] >> 16) : kStageQuads + k)) = e;
-            }
-            wave_lds_fence();
-            if (lane < nfetch) e0 = *reinterpret_cast<const u32x2*>(stage + 8u * lane);
-            if (nfetch > 64u && lane + 64u < nfetch) e1 = *reinterpret_cast<const u32x2*>(stage + 8u * (lane + 64u));
-            wave_lds_fence();
-#ifndef DINT_EXP_NOFETCH  // timing experiment: no cold payload reads (results are wrong)
-            if (lane < nfetch) {
-                q00 = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e0.x, 0, 0);
-                if (((e0.y >> 16) & 7u) > 1u) q01 = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e0.x + 16u, 0, 0);
-            }
-            if (nfetch > 64u && lane + 64u < nfetch) {
-                q10 = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e1.x, 0, 0);
-                if (((e1.y >> 16) & 7u) > 1u) q11 = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e1.x + 16u, 0, 0);
-            }
-#endif
-        }
-
-        MARK("6_flags");
-        // (b) flags and deltas. Every slot runs the same instructions: a codeword that is not
-        // live in this batch ORs a zero into an in-range flag word and parks its delta in a dummy.
-        *reinterpret_cast<uint32_t*>(fw + 8 * lane) = 0;  // clear all 64 flag words
+        tables_general(t, fw, delta, inb, done, rdone);
         wave_lds_fence();
-        const uint32_t rel0 = t.obase - done, ord0 = t.rbase - rdone;
-#pragma unroll
-        for (uint32_t k = 0; k != kSPL; ++k) {
-            const uint32_t lv = t.live[k] & inbM;
-            const uint32_t rel = rel0 + (t.off4[k] >> 2);
-            uint32_t* const fword = reinterpret_cast<uint32_t*>(fw + ((rel >> 2) & 0x1F8u));
-            __hip_atomic_fetch_or(fword, lv & (1u << (rel & 31u)), __ATOMIC_RELAXED,
-                                  __HIP_MEMORY_SCOPE_WAVEFRONT);
-            const uint32_t ord = (lv & (ord0 + t.lord[k])) | (~lv & (kTileSlots + k));
-            *reinterpret_cast<uint32_t*>(delta + 4 * ord) = srcb[k] - 4 * rel;
-        }
-        wave_lds_fence();
-        {
-            uint32_t* const pair = reinterpret_cast<uint32_t*>(fw + 8 * lane);
-            const uint32_t pc = uint32_t(__builtin_popcount(pair[0]));
-            const uint32_t pi = wave_inclusive_sum(pc);
-            pair[1] = pi - pc - 1u;  // flags before this word, minus one
-        }
-        MARK("7_stage_write");
-
-        // (c) the fetched quads and the exception literals go into their cells
-        if (t.tile_staged) {
-            if (lane < nfetch) {
-                uint8_t* const c = stage + 16u * (e0.y & 0xFFFFu);
-                *reinterpret_cast<u32x4*>(c) = q00;
-                if (((e0.y >> 16) & 7u) > 1u) *reinterpret_cast<u32x4*>(c + 16) = q01;
-            }
-            if (nfetch > 64u && lane + 64u < nfetch) {
-                uint8_t* const c = stage + 16u * (e1.y & 0xFFFFu);
-                *reinterpret_cast<u32x4*>(c) = q10;
-                if (((e1.y >> 16) & 7u) > 1u) *reinterpret_cast<u32x4*>(c + 16) = q11;
-            }
-            // size-16 cold codewords (rare): quads 2 and 3, fetched and waited for on the spot
-            const bool big0 = lane < nfetch && ((e0.y >> 16) & 7u) > 2u;
-            const bool big1 = nfetch > 64u && lane + 64u < nfetch && ((e1.y >> 16) & 7u) > 2u;
-#ifdef DINT_EXP_NOFETCH
-            if (false) {
-#else
-            if (__ballot(big0 || big1) != 0) {
-#endif
-                if (big0) {
-                    uint8_t* const c = stage + 16u * (e0.y & 0xFFFFu);
-                    *reinterpret_cast<u32x4*>(c + 32) = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e0.x + 32u, 0, 0);
-                    if (((e0.y >> 16) & 7u) > 3u)
-                        *reinterpret_cast<u32x4*>(c + 48) = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e0.x + 48u, 0, 0);
-                }
-                if (big1) {
-                    uint8_t* const c = stage + 16u * (e1.y & 0xFFFFu);
-                    *reinterpret_cast<u32x4*>(c + 32) = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e1.x + 32u, 0, 0);
-                    if (((e1.y >> 16) & 7u) > 3u)
-                        *reinterpret_cast<u32x4*>(c + 48) = __builtin_amdgcn_raw_buffer_load_b128(rs_table, e1.x + 48u, 0, 0);
-                }
-            }
-            if (t.tile_exc) {
-#pragma unroll
-                for (uint32_t k = 0; k != kSPL; ++k)
-                    if ((t.live[k] & inbM & t.lit[k]) != 0)
-                        *reinterpret_cast<uint32_t*>(stage + 16u * (t.qb - qdone + (t.cpre[k] & 0xFFFFu))) = t.excval[k];
-            }
-        }
-        wave_lds_fence();
-
-        // the wait point of the tile: the staged data is in, nothing has been stored yet. The caller
-        // parks the waits for its own prefetches here and issues the next ones right behind them.
-        // (the fetch registers too, on every path: a load the compiler cannot prove consumed would make it
-        // wait wherever that register is next written — after the stores)
-        asm volatile("" : "+v"(q00), "+v"(q01), "+v"(q10), "+v"(q11));
-        before_stores();
-        MARK("8_expand");
-        // (d) expansion, GROUPS * 256 outputs per round: each lane takes 4 consecutive outputs of
-        // every 256-output group; every source is an LDS byte address by now. Stores are whole
-        // 16-byte quads: the descriptor clips what lies past the segment's n integers (range
-        // checking is per dword), and what a quad writes past this batch's end inside the segment
-        // is rewritten by the batches and tiles that follow (same wave, program order).
-#pragma unroll
-        for (uint32_t rd = 0; rd != ROUNDS; ++rd) {
-            if (rd * GROUPS * 4 * kWave < bt) {  // wave-uniform
-#ifdef DINT_EXP_STORE_LOCAL  // timing experiment: same store instructions, all into the segment's first 4 KB
-                const uint32_t obyte = 0;
-#else
-                const uint32_t obyte = 4 * (out_int0 + done) + rd * GROUPS * 16 * kWave;  // output byte offset of the round
-#endif
-                uint32_t x[GROUPS][4];
-#pragma unroll
-                for (uint32_t g = 0; g != GROUPS; ++g) {
-                    if ((rd * GROUPS + g) * 4 * kWave < bt) {  // wave-uniform
-                        const u32x2 pr = *reinterpret_cast<const u32x2*>(fw + (rd * GROUPS + g) * 64 + pair_byte);
-                        const uint32_t w = pr.x;
-                        const uint32_t base = pr.y + uint32_t(__builtin_popcount(__builtin_amdgcn_ubfe(w, 0u, sh)));  // flags below its nibble
-                        const uint32_t nib = w >> sh;
-                        uint32_t r[4];
-                        r[0] = base + (nib & 1u);
-                        r[1] = base + uint32_t(__builtin_popcount(nib & 3u));
-                        r[2] = base + uint32_t(__builtin_popcount(nib & 7u));
-                        r[3] = base + uint32_t(__builtin_popcount(nib & 15u));
-                        const uint32_t pos4 = (rd * GROUPS + g) * 16 * kWave + 16 * lane;  // byte position in the batch
-#pragma unroll
-                        for (int k = 0; k != 4; ++k) {
-                            const uint32_t ad = *reinterpret_cast<const uint32_t*>(delta + 4 * r[k]) + pos4 + 4 * k;
-                            x[g][k] = *reinterpret_cast<const uint32_t*>(lds_bytes + ad);
-                        }
-                    }
-                }
-                MARK("9_stores");
-                // the prefetched registers must have landed before the first store is issued
-#pragma unroll
-                for (uint32_t g = 0; g != GROUPS; ++g) {
-                    const uint32_t p0 = (rd * GROUPS + g) * 4 * kWave + 4 * lane;
-                    if ((rd * GROUPS + g) * 4 * kWave < bt) {  // wave-uniform
-#ifdef DINT_EXP_NOSTORE
-                        if (x[g][0] == 0xDEADBEEFu && x[g][1] == 0x12345u) out[g] = x[g][2] + x[g][3];
-#else
-                        if (p0 < bt) {
-                            u32x4 xv = {x[g][0], x[g][1], x[g][2], x[g][3]};
-                            if (t.plus_one) xv += 1u;  // wave-uniform branch: nothing on the plain decode path
-                            __builtin_amdgcn_raw_buffer_store_b128(xv, rs_out, 16 * g * kWave + 16 * lane, obyte, DINT_STORE_AUX);
-                        }
-#endif
-                    }
-                }
-            }
-        }
+        before_gathers();
+        expand_batch<ROUNDS, GROUPS, true>(bend - done, out_int0 + done, lds_bytes, fw, delta, rs_out, lane, plus_one);
+        *reinterpret_cast<uint32_t*>(fw + 8 * lane) = 0;
         wave_lds_fence();
         done = bend;
         rdone = rend;
-        qdone = qend;
-        wdone = wend;
     } while (done < t.total);
+}
 
+// The slow codewords of a tile, written by their own lanes straight to the output, behind the tile's
+// stores (which put zeros there): dictionary entries that hold a value of 65536 or more, and whatever found
+// no staging cell (more than 256 cells in one tile: no real stream, but a legal one) — looked up again here:
+// rare enough not to ride through the expansion in registers. `slowb` bit k: slot k; `pos0` = the tile's first
+// output inside the segment of `seg_n` integers; `slot_addr` = this lane's first slot in the stream, W bits
+// per slot.
+template <int W>
+__device__ __forceinline__ void slow_stores(const wave_ctx& c, const tile_slots& t, uint32_t slowb, uint32_t plus_one, uint32_t pos0,
+                                            uint32_t seg_n, const uint8_t* slot_addr, uint32_t hot_base, uint32_t hot_k,
+                                            uint32_t meta_base, const __amdgpu_buffer_rsrc_t rs_out) {
+    // the zeros must be in memory first: two stores of one wave to one address are only ordered by the wait
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#pragma unroll
+    for (uint32_t k = 0; k != kSPL; ++k) {
+        if ((slowb >> k) & 1u) {
+            const uint32_t pos = pos0 + t.obase + t.off[k];
+            const uint8_t* const sp = slot_addr + (W / 8) * k;
+            const uint32_t sv = W == 16 ? uint32_t(sp[0]) | (uint32_t(sp[1]) << 8) : uint32_t(sp[0]);
+            if (sv < 2) {  // an exception whose literal found no staging cell: from the stream again
+                const uint8_t* const lp = sp + W / 8;
+                uint32_t v = uint32_t(lp[0]) | (uint32_t(lp[1]) << 8);
+                if (sv == 1) v |= (uint32_t(lp[2]) << 16) | (uint32_t(lp[3]) << 24);
+                __builtin_amdgcn_raw_buffer_store_b32(v + plus_one, rs_out, 4 * pos, 0, DINT_STORE_AUX);
+            } else {
+                const uint32_t m = sv < hot_k ? c.lds[hot_base + sv] : __builtin_amdgcn_raw_buffer_load_b32(c.rs_dict, 4 * (meta_base + sv), 0, 0);
+                const uint32_t goff = __builtin_amdgcn_raw_buffer_load_b32(c.rs_dict, c.goff_base + 4 * (meta_base + sv), 0, 0);
+                const uint32_t size = (m >> 24) + 1u, room = seg_n - pos;
+                const uint32_t cnt = size < room ? size : room;
+#pragma nounroll
+                for (uint32_t j = 0; j < cnt; ++j) {
+                    const uint32_t v = __builtin_amdgcn_raw_buffer_load_b32(c.rs_dict, c.gtable_base + 4 * (goff + j), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(v + plus_one, rs_out, 4 * (pos + j), 0, DINT_STORE_AUX);
+                }
+            }
+        }
+    }
 }
 
 // ROUNDS x GROUPS x 256 = outputs per expansion batch: 2 x 4 for the long single-dictionary
 // segments; a multi-dictionary segment is one block of at most 256 integers, 1 x 1.
 template <int W, uint32_t ROUNDS, uint32_t GROUPS, bool CHAINED>
-__device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const uint32_t* lds, const uint16_t* cls,
-                                                   uint32_t* scratch, const dict_desc& dd, uint64_t in_off,
-                                                   uint32_t n, uint32_t* const out, uint32_t lane, chain_io& ch) {
+__device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const wave_ctx& c, const dict_desc& dd, uint64_t in_off,
+                                                   uint32_t n, uint32_t* const out, chain_io& ch, prof_t& pf) {
+    SECTION(pf, 11, "segment_prologue");
     constexpr uint32_t kSlotBytes = W / 8;
     constexpr uint32_t kTileBytes = kTileSlots * kSlotBytes;
-    const uint16_t* const rows = cls + (W == 16 ? 0 : kRows16);
-
+    const uint16_t* const rows = c.cls + (W == 16 ? 0 : kRows16);
+    const uint32_t lane = c.lane;
     const uint32_t hot_k = dd.hot_k;
-    const __amdgpu_buffer_rsrc_t rs_meta =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.dict.gmeta), 0, int(a.dict.gmeta_words * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_table =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.dict.gtable), 0, int(a.dict.gtable_words * 4), 0x00020000);
     // hardware bounds: nothing past this segment's n integers can be written
-    const uint64_t out_bits = reinterpret_cast<uint64_t>(out);
-    uint32_t* const out_u = reinterpret_cast<uint32_t*>((uint64_t(uniform(uint32_t(out_bits >> 32))) << 32) |
-                                                        uniform(uint32_t(out_bits)));
+    uint32_t* const out_u = reinterpret_cast<uint32_t*>(uniform64(reinterpret_cast<uint64_t>(out)));
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out_u, 0, int(uniform(n) * 4), 0x00020000);
+    uint8_t* const lds_rw = reinterpret_cast<uint8_t*>(const_cast<uint32_t*>(c.lds));
+    const uint32_t stage_byte0 = uint32_t(reinterpret_cast<const uint8_t*>(stage_of(c.scratch)) - lds_rw);  // the cells, as LDS byte addresses
 
-    // Metadata of the four slots of a lane: LDS for the hot codewords (unconditional reads, all four
-    // in flight together: cold lanes read word 0), then L2 for the cold ones under their exec mask.
-    // Two address spaces, never a pointer select (that would become one slow flat load).
-    auto load_metas = [&](tile_regs& t) {
-#pragma unroll
-        for (uint32_t k = 0; k != kSPL; ++k) t.m[k] = lds[t.s[k] < hot_k ? dd.hot_base + t.s[k] : 0u];
-        asm volatile("" : "+v"(t.m[0]), "+v"(t.m[1]), "+v"(t.m[2]), "+v"(t.m[3]));  // keep the DS reads DS reads
-#pragma unroll
-        for (uint32_t k = 0; k != kSPL; ++k) {
-#ifdef DINT_EXP_NOMETA  // timing experiment: no L2 metadata reads (results are wrong)
-            if (t.s[k] >= hot_k)
-                t.m[k] = (lds[dd.hot_base + 7u + (t.s[k] & 1023u)] & 0xFF000000u) | kColdBase | (t.s[k] & 0xFFFFu);
-#else
-            if (t.s[k] >= hot_k) t.m[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_meta, 4 * (dd.meta_base + t.s[k]), 0, 0);
-#endif
-        }
-    };
-
-    // pipeline: tile t in `cur` (slots + metadata), tile t+1 in `nxt`, tile t+2's slots in flight
-    const uint64_t in_off_u = (uint64_t(uniform(uint32_t(in_off >> 32))) << 32) | uniform(uint32_t(in_off));
+    // pipeline: tile t in `cur` (slots + metadata; the rows of its cold slots on their way into `rr`), tile
+    // t+1's slots in `nxt` (its metadata requested half-way through tile t, its rows at the end of tile t),
+    // tile t+2's slots in raw2, tile t+3's requested at the top of tile t
+    const uint64_t in_off_u = uniform64(in_off);
     uint64_t slot_byte = in_off_u;  // first byte of the tile whose slots are loaded next (wave-uniform)
     tile_regs cur, nxt;
+    meta_regs mr;
+    row_regs rr;  // (deliberately uninitialised: each register is written and read under the same lane predicate)
     uint64_t raw1, raw2 = 0;
     if (CHAINED) {  // tiles 0 and 1 arrived with the previous block (or were requested by the caller)
         unpack_slots<W>(chain_tile<W>(ch.data, 0, lane), cur);
@@ -616,10 +700,13 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
         raw2 = load_lane_slots<W>(a.enc, slot_byte, lane, a.enc_bytes);
     }
     ch.valid = false;
-    load_metas(cur);
+    request_metas(c, dd.hot_base, hot_k, dd.meta_base, cur, mr);
+    request_rows(c, hot_k, dd.meta_base, cur, rr);
     // Everything loaded so far has landed before the loop is entered: inside it, a wait may only
-    // ever sit right before a tile's stores (see the prefetch note below), never after them.
-    asm volatile("" ::"v"(raw1), "v"(raw2), "v"(cur.m[0]), "v"(cur.m[1]), "v"(cur.m[2]), "v"(cur.m[3]));
+    // ever sit right before a tile's expansion (see the prefetch note below), never after its stores.
+    asm volatile("" : "+v"(raw1), "+v"(raw2));
+    take_metas(hot_k, mr, cur);
+    unpack_slots<W>(raw1, nxt);
 
     uint32_t produced = 0;
     uint32_t carry = 0;            // payload slots an exception of the previous tile still owns
@@ -628,83 +715,22 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
     MARK("loop_top");
 
     while (produced < n) {
-        const uint32_t next_lo = uint32_t(raw1);  // first slots of the next tile (exception spill)
         // The far prefetch — the slots of the tile after next, straight from HBM — goes out first: it has to
-        // be back before this tile's stores (every wait is a wait for everything), so it gets the whole tile.
-        // (Issued a third of a tile before the wait, it cost a fifth of the kernel time whenever the stream
-        // was not cached: any collection whose stream outgrows the 256 MB memory-side cache. Issuing it
-        // right after the previous wait instead would keep its register in flight across the loop's
-        // back edge, where the compiler copies it — and waits, after the stores.)
+        // be back before this tile's expansion (every wait is a wait for everything), so it gets the whole
+        // front end. (Requested at the wait point instead, as the youngest load in flight there, it would have
+        // a whole tile; measured: no gain — the kernel waits for the vector-memory front end, not for HBM.)
         slot_byte += kTileBytes;
         const uint64_t raw3 = load_lane_slots<W>(a.enc, slot_byte, lane, a.enc_bytes);
-#if DINT_EARLY_METAS
-        // the next tile's metadata too (L2 for its cold codewords): same reasoning
-        unpack_slots<W>(raw1, nxt);
-        load_metas(nxt);
-#endif
 
-        // Perturbation experiments (timing only): which resource does the kernel sit on? Pad every tile
-        // with N independent instructions of one class and watch the time.
-#ifdef DINT_EXP_PAD_VALU
-        {
-            uint32_t pad = lane;
-#pragma unroll
-            for (int i = 0; i != DINT_EXP_PAD_VALU; ++i) asm volatile("v_add_u32 %0, %0, 1" : "+v"(pad));
-            asm volatile("" ::"v"(pad));
-        }
-#endif
-#ifdef DINT_EXP_PAD_SALU
-        {
-            uint32_t pad = 0;
-#pragma unroll
-            for (int i = 0; i != DINT_EXP_PAD_SALU; ++i) asm volatile("s_add_u32 %0, %0, 1" : "+s"(pad));
-            asm volatile("" ::"s"(pad));
-        }
-#endif
-#ifdef DINT_EXP_PAD_LDS
-        {
-            uint32_t acc = 0;
-#pragma unroll
-            for (int i = 0; i != DINT_EXP_PAD_LDS; ++i) {
-                uint32_t v = lds[(lane * 33u + i * 67u) & 1023u];
-                asm volatile("" : "+v"(v));
-                acc += v;
-            }
-            asm volatile("" ::"v"(acc));
-        }
-#endif
-#ifdef DINT_EXP_PAD_LDS_IND  // independent reads: LDS throughput, hardly any latency
-        {
-            uint32_t v[DINT_EXP_PAD_LDS_IND];
-#pragma unroll
-            for (int i = 0; i != DINT_EXP_PAD_LDS_IND; ++i) v[i] = lds[(lane * 33u + i * 67u) & 1023u];
-            uint32_t acc = 0;
-#pragma unroll
-            for (int i = 0; i != DINT_EXP_PAD_LDS_IND; ++i) { asm volatile("" : "+v"(v[i])); acc |= v[i]; }
-            asm volatile("" ::"v"(acc));
-        }
-#endif
-#ifdef DINT_EXP_PAD_LDS_IND128
-        {
-            u32x4 v[DINT_EXP_PAD_LDS_IND128];
-#pragma unroll
-            for (int i = 0; i != DINT_EXP_PAD_LDS_IND128; ++i)
-                v[i] = *reinterpret_cast<const u32x4*>(lds + ((lane * 4u + i * 260u) & 4095u));
-            uint32_t acc = 0;
-#pragma unroll
-            for (int i = 0; i != DINT_EXP_PAD_LDS_IND128; ++i) { asm volatile("" : "+v"(v[i])); acc |= v[i].x ^ v[i].w; }
-            asm volatile("" ::"v"(acc));
-        }
-#endif
-        MARK("1_classify");
+        SECTION(pf, 1, "1_classify");
         // ---- 1. classification: table lookup, repeated until the lane-to-lane carries agree ----
         uint32_t smin = cur.s[0];
 #pragma unroll
         for (uint32_t k = 1; k != kSPL; ++k) smin = smin < cur.s[k] ? smin : cur.s[k];
-        const bool special = __ballot(smin < 2) != 0 || carry != 0;
-        uint32_t paybits = 0, excbits = 0, row = 0;
+        const bool special = __builtin_expect(__ballot(smin < 2) != 0 || carry != 0, 0);
+        const bool tile_slow_dict = __ballot(((cur.m[0] | cur.m[1] | cur.m[2] | cur.m[3]) & kMetaSlow) != 0) != 0;
+        uint32_t row = kPlainRow;
         uint32_t carry_out = 0;
-        uint32_t excval[kSPL];  // set and read only when tile_exc
         bool tile_exc = false;
         if (special) {
             // base-3 digits of the four slots: 2 - min(slot, 2)
@@ -714,207 +740,230 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const u
             uint32_t st_in = lane == 0 ? carry : 0u;
             for (;;) {
                 row = rows[st_in * 81 + lo];
-                uint32_t prev = __shfl_up((row >> 8) & 7u, 1);
+                uint32_t prev = from_lane_below((row >> 8) & 7u);
                 if (lane == 0) prev = carry;
                 if (__ballot(prev != st_in) == 0) break;
                 st_in = prev;
             }
-            paybits = row & 15u;
-            excbits = (row >> 4) & 15u;
             carry_out = readlane((row >> 8) & 7u, 63);
-            tile_exc = __ballot(excbits != 0) != 0;
+            tile_exc = __ballot((row & 0xF0u) != 0) != 0;
+        }
+
+        SECTION(pf, 2, "2_sizes");
+        // ---- 2. sizes, offsets; where each codeword's integers are -----------------------------------
+        tile_slots t;
+        uint32_t e[kSPL];  // size - 1
+#pragma unroll
+        for (uint32_t k = 0; k != kSPL; ++k) {
+            e[k] = cur.m[k] >> 24;
+            t.need[k] = __builtin_amdgcn_ubfe(cur.m[k], 20, 2);
+            t.src2[k] = cur.m[k] & kMetaOffMask;  // hot: the image (runs: the zeros); cold, slow: zero for now
+        }
+        uint32_t excval[kSPL];  // set and read only when tile_exc
+        if (special) {
+            // payload slots decode to nothing and take nothing; an exception header is one integer from one cell
+#pragma unroll
+            for (uint32_t k = 0; k != kSPL; ++k) {
+                const bool pay = ((row >> k) & 1u) != 0, exc = ((row >> (4 + k)) & 1u) != 0;
+                e[k] = pay ? ~0u : (exc ? 0u : e[k]);
+                t.need[k] = pay ? 0u : (exc ? 1u : t.need[k]);
+            }
             if (tile_exc) {
                 // slot values after this lane's: the next lane's first ones (lane 63: next tile's)
                 if (W == 16) {
-                    uint32_t nlo = __shfl_down((cur.s[1] << 16) | cur.s[0], 1);
-                    if (lane == 63) nlo = readlane(next_lo, 0);
-                    uint32_t e[kSPL + 2];
+                    uint32_t nlo = from_lane_above((cur.s[1] << 16) | cur.s[0]);
+                    if (lane == 63) nlo = readlane((nxt.s[1] << 16) | nxt.s[0], 0);
+                    uint32_t v[kSPL + 2];
 #pragma unroll
-                    for (uint32_t k = 0; k != kSPL; ++k) e[k] = cur.s[k];
-                    e[kSPL] = nlo & 0xFFFFu;
-                    e[kSPL + 1] = nlo >> 16;
+                    for (uint32_t k = 0; k != kSPL; ++k) v[k] = cur.s[k];
+                    v[kSPL] = nlo & 0xFFFFu;
+                    v[kSPL + 1] = nlo >> 16;
 #pragma unroll
                     for (uint32_t k = 0; k != kSPL; ++k)
-                        excval[k] = e[k] == 0 ? e[k + 1] : (e[k + 1] | (e[k + 2] << 16));
+                        excval[k] = v[k] == 0 ? v[k + 1] : (v[k + 1] | (v[k + 2] << 16));
                 } else {
-                    uint32_t nlo = __shfl_down(cur.s[0] | (cur.s[1] << 8) | (cur.s[2] << 16) | (cur.s[3] << 24), 1);
-                    if (lane == 63) nlo = readlane(next_lo, 0);
-                    uint32_t e[kSPL + 4];
+                    uint32_t nlo = from_lane_above(cur.s[0] | (cur.s[1] << 8) | (cur.s[2] << 16) | (cur.s[3] << 24));
+                    if (lane == 63) nlo = readlane(nxt.s[0] | (nxt.s[1] << 8) | (nxt.s[2] << 16) | (nxt.s[3] << 24), 0);
+                    uint32_t v[kSPL + 4];
 #pragma unroll
-                    for (uint32_t k = 0; k != kSPL; ++k) e[k] = cur.s[k];
+                    for (uint32_t k = 0; k != kSPL; ++k) v[k] = cur.s[k];
 #pragma unroll
-                    for (uint32_t k = 0; k != 4; ++k) e[kSPL + k] = (nlo >> (8 * k)) & 0xFFu;
+                    for (uint32_t k = 0; k != 4; ++k) v[kSPL + k] = (nlo >> (8 * k)) & 0xFFu;
 #pragma unroll
                     for (uint32_t k = 0; k != kSPL; ++k) {
-                        const uint32_t lo16 = e[k + 1] | (e[k + 2] << 8);
-                        excval[k] = e[k] == 0 ? lo16 : (lo16 | (e[k + 3] << 16) | (e[k + 4] << 24));
+                        const uint32_t lo16 = v[k + 1] | (v[k + 2] << 8);
+                        excval[k] = v[k] == 0 ? lo16 : (lo16 | (v[k + 3] << 16) | (v[k + 4] << 24));
                     }
                 }
             }
         }
-
-        MARK("2_sizes");
-        // ---- 2. sizes, offsets, ordinals (sizes and sources in BYTES of output / payload) --------
-        // live[k]: all ones when slot k is a codeword header that belongs to this segment
-        uint32_t sz4[kSPL], src4[kSPL], live[kSPL], lord[kSPL], lit[kSPL];
-#pragma unroll
-        for (uint32_t k = 0; k != kSPL; ++k) {
-            const uint32_t m = cur.m[k];
-            sz4[k] = ((m >> 22) & 0x3FCu) + 4u;
-            src4[k] = (m << 2) & 0x3FFFFFCu;  // cold metas carry kColdBase in their offset field
-            live[k] = ~0u;
-            lord[k] = k;
-            lit[k] = 0;
-        }
+        t.off[0] = 0;
+        t.off[1] = e[0] + 1u;
+        t.off[2] = t.off[1] + e[1] + 1u;
+        t.off[3] = t.off[2] + e[2] + 1u;
+        t.lsum = t.off[3] + e[3] + 1u;
         uint32_t hdrcnt = 4;
+        uint32_t pincl;
         if (special) {
-#pragma unroll
-            for (uint32_t k = 0; k != kSPL; ++k) {
-                const uint32_t payM = uint32_t(int32_t(row << (31 - k)) >> 31);  // all ones: payload slot
-                const uint32_t excM = uint32_t(int32_t(row << (27 - k)) >> 31);  // all ones: exception header
-                sz4[k] = ((sz4[k] & ~excM) | (4u & excM)) & ~payM;
-                lit[k] = excM;
-                live[k] = ~payM;
-            }
-            lord[1] = (row >> 11) & 1u;
-            lord[2] = (row >> 12) & 3u;
-            lord[3] = (row >> 14) & 3u;
-            hdrcnt = 4 - uint32_t(__builtin_popcount(paybits));
+            hdrcnt = uint32_t(__builtin_popcount(~row & 15u));
+            pincl = wave_inclusive_sum((hdrcnt << 24) | t.lsum);
+        } else {
+            pincl = wave_inclusive_sum(t.lsum);  // (the ordinals of a plain tile are 4 lane + k)
         }
-        uint32_t off4[kSPL];
-        off4[0] = 0;
-#pragma unroll
-        for (uint32_t k = 1; k != kSPL; ++k) off4[k] = off4[k - 1] + sz4[k - 1];
-        uint32_t lsum = (off4[kSPL - 1] + sz4[kSPL - 1]) >> 2;
-        const uint32_t packed = (hdrcnt << 24) | lsum;
-        const uint32_t pincl = wave_inclusive_sum(packed);
-        const uint32_t pexcl = pincl - packed;
-        const uint32_t obase = pexcl & 0xFFFFFFu;  // first output of this lane's codewords
-        const uint32_t rbase = pexcl >> 24;        // ordinal of this lane's first codeword
+        t.obase = (pincl & 0xFFFFFFu) - t.lsum;    // first output of this lane's codewords
         const uint32_t remaining = n - produced;
-        uint32_t total = readlane(pincl, 63) & 0xFFFFFFu;
-        uint32_t nlive = hdrcnt;
-        const bool last_tile = total >= remaining;
-        if (last_tile) {  // last tile of the segment: clamp, and find where the stream ends
-            total = remaining;
-            uint32_t cand = 0;
-            nlive = 0;
+        t.total = readlane(pincl, 63) & 0xFFFFFFu;
+        const bool last_tile = t.total >= remaining;
+        const bool plain = !special && !last_tile && t.total <= ROUNDS * GROUPS * 256;
+        uint32_t slowb = 0;  // bit k: slot k goes through slow_stores
+        if (!plain) {
+            t.row = row;
+            t.liveb = ~row & 15u;
+            // ordinal of this lane's first codeword (exclusive before the shift: the inclusive count can be 256)
+            t.rbase = special ? (pincl - ((hdrcnt << 24) | t.lsum)) >> 24 : 4 * lane;
+            t.nlive = hdrcnt;
+            if (last_tile) {  // last tile of the segment: clamp, and find where the stream ends
+                t.total = remaining;
+                uint32_t cand = 0, lb = 0;
+                t.nlive = 0;
 #pragma unroll
-            for (uint32_t k = 0; k != kSPL; ++k) {
-                const uint32_t pos = obase + (off4[k] >> 2);
-                const bool act = live[k] != 0 && pos < remaining;
-                if (act) {
-                    const uint32_t room4 = 4 * (remaining - pos);
-                    sz4[k] = sz4[k] < room4 ? sz4[k] : room4;
-                    const bool exc = (excbits >> k) & 1u;
-                    cand = kSPL * lane + k + 1 + (exc ? (W == 16 ? cur.s[k] + 1 : 2 * cur.s[k] + 2) : 0u);
-                    ++nlive;
+                for (uint32_t k = 0; k != kSPL; ++k) {
+                    const uint32_t pos = t.obase + t.off[k];
+                    const bool act = ((t.liveb >> k) & 1u) != 0 && pos < remaining;
+                    if (act) {
+                        const bool exc = ((row >> (4 + k)) & 1u) != 0;
+                        cand = kSPL * lane + k + 1 + (exc ? (W == 16 ? cur.s[k] + 1 : 2 * cur.s[k] + 2) : 0u);
+                        ++t.nlive;
+                        lb |= 1u << k;
+                    } else {
+                        t.need[k] = 0;
+                    }
                 }
-                live[k] = act ? ~0u : 0u;
+                t.liveb = lb;
+                t.lsum = t.obase < remaining ? (t.obase + t.lsum < remaining ? t.lsum : remaining - t.obase) : 0u;
+                const uint64_t am = __ballot(cand != 0);
+                end_slot = readlane(cand, 63u - uint32_t(__builtin_clzll(am | 1ull)));
             }
-            lsum = obase < remaining ? (obase + lsum < remaining ? lsum : remaining - obase) : 0u;
-            const uint64_t am = __ballot(cand != 0);
-            end_slot = readlane(cand, 63u - uint32_t(__builtin_clzll(am | 1ull)));
-        }
-        // staging demand of each slot: 16-byte cells | (1 << 16 if they are fetched from the table).
-        // Cold codewords (meta from L2: kColdBase set) take ceil(size / 4) cells, exception literals
-        // one; hot codewords and runs (zero region) none.
-        uint32_t pk[kSPL], cpre[kSPL];
+            if (tile_slow_dict) {
 #pragma unroll
-        for (uint32_t k = 0; k != kSPL; ++k) {
-            const uint32_t coldM = live[k] & ~lit[k] & (0u - ((src4[k] >> 25) & 1u));
-            pk[k] = (coldM & ((1u << 16) | ((sz4[k] + 12u) >> 4))) | (live[k] & lit[k] & 1u);
-        }
-        cpre[0] = 0;
+                for (uint32_t k = 0; k != kSPL; ++k)
+                    slowb |= ((cur.m[k] >> 22) & (t.liveb >> k) & ~(row >> (4 + k)) & 1u) << k;
+            }
+        } else if (tile_slow_dict) {
 #pragma unroll
-        for (uint32_t k = 1; k != kSPL; ++k) cpre[k] = cpre[k - 1] + pk[k - 1];
-        const uint32_t cl = cpre[kSPL - 1] + pk[kSPL - 1];
-        const bool tile_staged = __ballot(cl != 0) != 0;
-        uint32_t cexcl = 0;
-        if (tile_staged) cexcl = wave_inclusive_sum(cl) - cl;
-        const uint32_t qb = cexcl & 0xFFFFu, wb = cexcl >> 16;  // first cell / first fetch of this lane
-        MARK("3_prefetch");
-        // ---- prefetch: metadata of tile t+1 (its slots are already here), slots of tile t+2. Issued
-        // before this tile's cold fetches and stores; waited for together with the fetches, right
-        // before the stores (vmcnt is one in-order counter for loads AND stores on gfx950: a wait
-        // placed after the stores would also wait for their acknowledgements).
+            for (uint32_t k = 0; k != kSPL; ++k) slowb |= ((cur.m[k] >> 22) & 1u) << k;
+        }
+        // ---- staging cells: exception literals and cold codewords --------------------------------------
+        uint32_t cell_addr[kSPL];
+        const uint32_t cells = allocate_cells(t, stage_byte0, cell_addr);
+        if (cells > kStageCells) {  // wave-uniform; what lies past the staging area turns slow: zeros, then slow_stores
+#pragma unroll
+            for (uint32_t k = 0; k != kSPL; ++k)
+                if (t.need[k] != 0 && cell_addr[k] + 16 * t.need[k] > stage_byte0 + 16 * kStageCells) {
+                    t.need[k] = 0;
+                    slowb |= 1u << k;
+                }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k != kSPL; ++k) t.src2[k] = t.need[k] != 0 ? cell_addr[k] : t.src2[k];
+        bool tile_wide = false;
+        if (tile_exc) {
+            // An exception's literal goes into its staging cell as 32 bits. The expansion gathers its low half
+            // like any other integer, and — told by bit 0 of the source address — the upper half of one >= 65536.
+            bool wide = false;
+#pragma unroll
+            for (uint32_t k = 0; k != kSPL; ++k)
+                if (((row >> (4 + k)) & 1u) != 0 && t.need[k] != 0) {
+                    *reinterpret_cast<uint32_t*>(lds_rw + cell_addr[k]) = excval[k];
+                    t.src2[k] |= excval[k] > 0xFFFFu ? 1u : 0u;
+                    wide = wide || excval[k] > 0xFFFFu;
+                    t.need[k] = 0;  // (no row lands there)
+                }
+            tile_wide = __ballot(wide) != 0;
+        }
+        const bool tile_slow = __ballot(slowb != 0) != 0;
+        const bool tile_big = __ballot((t.need[0] | t.need[1] | t.need[2] | t.need[3]) > 1u) != 0;
+        SECTION(pf, 3, "3_prefetch");
+        // ---- prefetch: metadata of tile t+1 (its slots are already here). Issued before this tile's
+        // stores; waited for right before the expansion (vmcnt is one in-order counter for loads AND
+        // stores on gfx950: a wait placed after the stores would also wait for their acknowledgements).
         // The last tile of a segment has no successor to prefetch; a chained one asks for the next block.
         if (!last_tile) {
-#if !DINT_EARLY_METAS
-            unpack_slots<W>(raw1, nxt);
-            load_metas(nxt);
-#endif
+            request_metas(c, dd.hot_base, hot_k, dd.meta_base, nxt, mr);
         } else {
 #pragma unroll
-            for (uint32_t k = 0; k != kSPL; ++k) nxt.s[k] = nxt.m[k] = 0;
+            for (uint32_t k = 0; k != kSPL; ++k) mr.h[k] = 0;
             if (CHAINED) {
-                const uint64_t nb = ch.next_off != ~0ull ? ch.next_off : tile_base + uint64_t(kSlotBytes) * end_slot;
+                const uint64_t nb = tile_base + uint64_t(kSlotBytes) * end_slot;
                 if (ch.more && nb + 1 + kChainBytes <= a.enc_bytes) chain_request(a.enc, nb, lane, ch);
             }
         }
-        tile_slots t;
-#pragma unroll
-        for (uint32_t k = 0; k != kSPL; ++k) {
-            t.live[k] = live[k];
-            t.off4[k] = off4[k];
-            t.lord[k] = lord[k];
-            t.src4[k] = src4[k];
-            t.pk[k] = pk[k];
-            t.cpre[k] = cpre[k];
-            t.lit[k] = lit[k];
-            t.excval[k] = excval[k];
-        }
-        t.lsum = lsum, t.obase = obase, t.rbase = rbase, t.nlive = nlive, t.cl = cl, t.qb = qb, t.wb = wb;
-        t.total = total, t.tile_exc = tile_exc, t.tile_staged = tile_staged;
-        t.plus_one = a.plus_one;
-        // the prefetched registers must have landed before the first store is issued
-        // ("+v": from here on the values are the asm's, not a load's — nothing for the compiler to wait for later)
+        // ---- the wait point of the tile: everything prefetched has landed — nothing has been stored yet,
+        // so this is no wait for store acknowledgements ("+v": from here on the values are the asm's, not a
+        // load's — nothing for the compiler to wait for later, behind the stores)
+        SECTION(pf, 8, "8_wait");
         uint64_t raw3w = raw3;
-        expand_tile<ROUNDS, GROUPS>(t, produced, lds, scratch, rs_table, rs_out, out, lane, [&]() {
-            asm volatile("" : "+v"(raw3w), "+v"(nxt.m[0]), "+v"(nxt.m[1]), "+v"(nxt.m[2]), "+v"(nxt.m[3]));
-            if (CHAINED) asm volatile("" : "+v"(ch.sel), "+v"(ch.data.x), "+v"(ch.data.y), "+v"(ch.data.z), "+v"(ch.data.w));
+        asm volatile("" : "+v"(raw3w));
+        take_metas(hot_k, mr, nxt);
+        if (CHAINED) asm volatile("" : "+v"(ch.sel), "+v"(ch.data.x), "+v"(ch.data.y), "+v"(ch.data.z), "+v"(ch.data.w));
+        // this tile's rows into their cells; the second halves of the large ones requested (same registers)
+#pragma unroll
+        for (uint32_t k = 0; k != kSPL; ++k) asm volatile("" : "+v"(rr.q[k]));
+#pragma unroll
+        for (uint32_t k = 0; k != kSPL; ++k)
+            if (t.need[k] != 0) *reinterpret_cast<u32x4*>(lds_rw + t.src2[k]) = rr.q[k];
+        if (tile_big) {
+#pragma unroll
+            for (uint32_t k = 0; k != kSPL; ++k)
+                if (t.need[k] > 1u)
+                    rr.q[k] = __builtin_amdgcn_raw_buffer_load_b128(c.rs_dict, c.rows_base + 32 * (dd.meta_base + cur.s[k]) + 16, 0, 0);
+        }
+        expand_tile<ROUNDS, GROUPS>(t, plain, tile_wide, a.plus_one, produced, c.lds, c.scratch, rs_out, lane, pf, [&]() {
+#pragma unroll
+            for (uint32_t k = 0; k != kSPL; ++k) asm volatile("" : "+v"(rr.q[k]));
+            if (tile_big) {
+#pragma unroll
+                for (uint32_t k = 0; k != kSPL; ++k)
+                    if (t.need[k] > 1u) *reinterpret_cast<u32x4*>(lds_rw + t.src2[k] + 16) = rr.q[k];
+            }
+            wave_lds_fence();
         });
 
-        MARK("10_rotate");
-        produced += total;
+        SECTION(pf, 10, "10_tail");
+        if (tile_slow)
+            slow_stores<W>(c, t, slowb, a.plus_one, produced, n, a.enc + tile_base + uint64_t(kSPL * kSlotBytes) * lane, dd.hot_base,
+                           hot_k, dd.meta_base, rs_out);
+        // the rows of the next tile's cold slots: the whole front end of the next tile lies between this
+        // request and the wait
+        SECTION(pf, 15, "10_rows");
+        if (!last_tile) request_rows(c, hot_k, dd.meta_base, nxt, rr);
+        SECTION(pf, 5, "10_rotate");
+        produced += t.total;
         carry = carry_out;
         if (produced < n) tile_base += kTileBytes;
 
         // ---- rotate the pipeline ---------------------------------------------------
         cur = nxt;
-        raw1 = CHAINED ? raw3w : raw2;
+        unpack_slots<W>(CHAINED ? raw3w : raw2, nxt);
         raw2 = raw3w;
     }
-    MARK("epilogue");
+    SECTION(pf, 13, "epilogue");
     return tile_base + uint64_t(kSlotBytes) * end_slot;
 }
 
 // A single-dictionary unit (rectangular or packed: the streams are byte-identical,
 // only the dictionary source layout differed on the host) is one 16-bit segment.
-__device__ __forceinline__ void decode_unit_single(const decode_args& a, const uint32_t* lds, const uint16_t* cls,
-                                                   uint32_t* scratch, uint64_t unit_index, uint32_t lane, chain_io& ch,
-                                                   uint64_t next_in_off) {
+// (Chaining such units like the blocks of a multi-dictionary unit — the next unit's first tiles
+// requested while the current one is expanded — was measured in round 1: 5 % slower.)
+__device__ __forceinline__ void decode_unit_single(const decode_args& a, const wave_ctx& c, uint64_t unit_index, prof_t& pf) {
     const dint_unit* up = a.units + unit_index;
     const uint64_t out_off = up->out_off;
     const uint32_t n = up->n;
-    if (n == 0 || out_off + n > a.out_capacity || (a.only_full && n != 256)) {
-        ch.valid = false;
-        return;
-    }
-    const uint64_t in_off = (uint64_t(uniform(uint32_t(up->in_off >> 32))) << 32) | uniform(uint32_t(up->in_off));
-    // chained unless the unit sits in the last kChainBytes of the buffer: its first two tiles were
-    // requested by this wave's previous unit (or are requested here), and it requests the next unit's
-    const bool chained = DINT_UNIT_CHAIN && in_off >= 1 && in_off + kChainBytes <= a.enc_bytes;
-    ch.more = next_in_off != ~0ull && next_in_off >= 1;
-    ch.next_off = next_in_off - 1;  // chain_request reads the byte before the data as a "selector"
-    uint64_t end;
-    if (chained) {
-        if (!ch.valid) chain_request(a.enc, in_off - 1, lane, ch);
-        end = decode_segment<16, kRounds, kGroups, true>(a, lds, cls, scratch, a.dict.first, in_off, n, a.out + out_off, lane, ch);
-    } else {
-        end = decode_segment<16, kRounds, kGroups, false>(a, lds, cls, scratch, a.dict.first, in_off, n, a.out + out_off, lane, ch);
-    }
-    if (a.end_off && lane == 0) a.end_off[unit_index] = end;
+    if (n == 0 || n > kMaxUnitInts || out_off > a.out_capacity || a.out_capacity - out_off < n || (a.only_full && n != 256)) return;
+    const uint64_t in_off = uniform64(up->in_off);
+    chain_io ch{};
+    const uint64_t end = decode_segment<16, kRounds, kGroups, false>(a, c, a.dict.first, in_off, n, a.out + out_off, ch, pf);
+    if (a.end_off && c.lane == 0) a.end_off[unit_index] = end;
 }
 
 // ---- bundles of tiny units -----------------------------------------------------------------------
@@ -1018,7 +1067,7 @@ __global__ __launch_bounds__(1024) void bundle_offsets_kernel(uint32_t* block_it
 }
 
 __global__ __launch_bounds__(256) void bundle_items_kernel(const uint8_t* sched, uint64_t n_units, const uint32_t* block_offsets,
-                                                           uint32_t* items) {
+                                                           uint32_t* items, uint8_t* item_cnt) {
     __shared__ uint32_t pre[256];
     const uint32_t tid = threadIdx.x;
     const uint64_t i = uint64_t(blockIdx.x) * 256 + tid;
@@ -1031,26 +1080,30 @@ __global__ __launch_bounds__(256) void bundle_items_kernel(const uint8_t* sched,
         pre[tid] += v;
         __syncthreads();
     }
-    if (f) items[block_offsets[blockIdx.x] + pre[tid] - 1] = uint32_t(i);
+    if (f) {
+        const uint32_t at = block_offsets[blockIdx.x] + pre[tid] - 1;
+        items[at] = uint32_t(i);
+        item_cnt[at] = sched[i];
+    }
 }
 
 // One tile over `cnt` (2..64) consecutive tiny units starting at unit u0. MULTI: every unit is one block
 // of a multi-dictionary stream — its selector byte picks the dictionary and the slot width, per unit,
 // hence per lane.
 template <bool MULTI>
-__device__ __forceinline__ void decode_bundle(const decode_args& a, const uint32_t* lds, const uint16_t* cls, uint32_t* scratch,
-                                              uint64_t u0, uint32_t cnt, uint32_t lane) {
-    const __amdgpu_buffer_rsrc_t rs_meta =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.dict.gmeta), 0, int(a.dict.gmeta_words * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_table =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.dict.gtable), 0, int(a.dict.gtable_words * 4), 0x00020000);
+__device__ __forceinline__ void decode_bundle(const decode_args& a, const wave_ctx& c, uint64_t u0, uint32_t cnt, prof_t& pf) {
+    SECTION(pf, 12, "bundle_front");
+    const uint32_t lane = c.lane;
+    uint32_t* const scratch = c.scratch;
+    const uint32_t* const lds = c.lds;
+    const uint16_t* const cls = c.cls;
 
     // ---- the units' descriptors, one per lane; lanes and outputs of each by one packed scan ----
     const bool has = lane < cnt;
     const dint_unit* up = a.units + u0 + (has ? lane : 0u);
     const uint64_t my_in = up->in_off;
     const uint32_t my_n = has ? up->n : 0u;
-    uint32_t nxt_lo = __shfl_down(uint32_t(my_in), 1), nxt_hi = __shfl_down(uint32_t(my_in >> 32), 1);
+    uint32_t nxt_lo = from_lane_above(uint32_t(my_in)), nxt_hi = from_lane_above(uint32_t(my_in >> 32));
     if (lane + 1 == cnt) {
         const uint64_t e = u0 + cnt < a.n_units ? a.units[u0 + cnt].in_off : a.enc_bytes;
         nxt_lo = uint32_t(e);
@@ -1078,10 +1131,10 @@ __device__ __forceinline__ void decode_bundle(const decode_args& a, const uint32
     const uint32_t used = readlane(inc0, 63) >> 16;    // lanes in use, < 64
     const uint32_t total = readlane(inc0, 63) & 0xFFFFu;
     const uint64_t out0 = a.units[u0].out_off;
-    if (total == 0 || out0 + total > a.out_capacity) return;
+    if (total == 0 || out0 > a.out_capacity || a.out_capacity - out0 < total) return;
 
     // ---- lane -> unit: heads scattered into LDS, prefix maximum; then the unit's parameters ----
-    uint32_t* const map = scratch;  // the flag pairs' space, free until expand_tile
+    uint32_t* const map = delta_of(scratch);  // the delta table's space, free until expand_tile
     map[lane] = 0;
     wave_lds_fence();
     if (has) map[my_lane0] = lane + 1;
@@ -1089,20 +1142,20 @@ __device__ __forceinline__ void decode_bundle(const decode_args& a, const uint32
     const uint32_t seg = wave_inclusive_max(map[lane]) - 1u;  // lane 0 is always a head
     wave_lds_fence();
     const bool lane_used = lane < used;
-    const int sl = int(seg);
-    const uint64_t seg_in = (uint64_t(uint32_t(__shfl(uint32_t(my_in >> 32), sl))) << 32) | uint32_t(__shfl(uint32_t(my_in), sl));
-    const uint32_t seg_n = __shfl(my_n, sl);
-    const uint32_t seg_lane0 = __shfl(my_lane0, sl);
-    const uint32_t seg_out0 = __shfl(my_out0, sl);
+    const int sl_ = int(seg);
+    const uint64_t seg_in = (uint64_t(uint32_t(__shfl(uint32_t(my_in >> 32), sl_))) << 32) | uint32_t(__shfl(uint32_t(my_in), sl_));
+    const uint32_t seg_n = __shfl(my_n, sl_);
+    const uint32_t seg_lane0 = __shfl(my_lane0, sl_);
+    const uint32_t seg_out0 = __shfl(my_out0, sl_);
     const bool seg_head = lane == seg_lane0;
-    const bool narrow = MULTI && __shfl(my_narrow, sl) != 0;
-    const uint32_t hot_base = MULTI ? uint32_t(__shfl(my_hot_base, sl)) : my_hot_base;
-    const uint32_t hot_k = MULTI ? uint32_t(__shfl(my_hot_k, sl)) : my_hot_k;
-    const uint32_t meta_base = MULTI ? uint32_t(__shfl(my_meta_base, sl)) : my_meta_base;
+    const bool narrow = MULTI && __shfl(my_narrow, sl_) != 0;
+    const uint32_t hot_base = MULTI ? uint32_t(__shfl(my_hot_base, sl_)) : my_hot_base;
+    const uint32_t hot_k = MULTI ? uint32_t(__shfl(my_hot_k, sl_)) : my_hot_k;
+    const uint32_t meta_base = MULTI ? uint32_t(__shfl(my_meta_base, sl_)) : my_meta_base;
     const uint64_t slot0 = seg_in + (MULTI ? 1u : 0u);          // the unit's first slot
     const uint32_t stride = narrow ? 4u : 8u;                    // stream bytes per lane
 
-    // ---- slots and metadata ---------------------------------------------------------------------
+    // ---- slots, metadata, the cold slots' rows -----------------------------------------------------
     tile_regs cur;
     uint32_t raw_lo = 0;  // the lane's first four bytes (the next lane's: what an exception at its end spills into)
     {
@@ -1118,12 +1171,11 @@ __device__ __forceinline__ void decode_bundle(const decode_args& a, const uint32
             for (uint32_t k = 0; k != kSPL; ++k) cur.s[k] = (raw_lo >> (8 * k)) & 0xFFu;
         }
     }
-#pragma unroll
-    for (uint32_t k = 0; k != kSPL; ++k) cur.m[k] = lds[cur.s[k] < hot_k ? hot_base + cur.s[k] : 0u];
-    asm volatile("" : "+v"(cur.m[0]), "+v"(cur.m[1]), "+v"(cur.m[2]), "+v"(cur.m[3]));
-#pragma unroll
-    for (uint32_t k = 0; k != kSPL; ++k)
-        if (cur.s[k] >= hot_k) cur.m[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_meta, 4 * (meta_base + cur.s[k]), 0, 0);
+    meta_regs mr;
+    row_regs rr;
+    request_metas(c, hot_base, hot_k, meta_base, cur, mr);
+    request_rows(c, hot_k, meta_base, cur, rr);
+    take_metas(hot_k, mr, cur);
 
     // ---- classification: as in decode_segment, the carries cut at every unit's first lane ----------
     tile_slots t;
@@ -1136,23 +1188,24 @@ __device__ __forceinline__ void decode_bundle(const decode_args& a, const uint32
         const uint32_t rows_at = narrow ? kRows16 : 0u;  // the 8-bit rows follow the 16-bit ones
         for (;;) {
             row = cls[rows_at + st_in * 81 + lo];
-            uint32_t prev = __shfl_up((row >> 8) & 7u, 1);
+            uint32_t prev = from_lane_below((row >> 8) & 7u);
             if (seg_head) prev = 0;
             if (__ballot(prev != st_in) == 0) break;
             st_in = prev;
         }
     }
-    const uint32_t excbits = (row >> 4) & 15u;
-    t.tile_exc = __ballot(lane_used && excbits != 0) != 0;
-    if (t.tile_exc) {
-        const uint32_t nlo = __shfl_down(raw_lo, 1);  // an exception's payload never leaves its unit's lanes
+    const uint32_t excbits = lane_used ? (row >> 4) & 15u : 0u;
+    const bool tile_exc = __ballot(excbits != 0) != 0;
+    uint32_t excval[kSPL] = {0, 0, 0, 0};
+    if (tile_exc) {
+        const uint32_t nlo = from_lane_above(raw_lo);  // an exception's payload never leaves its unit's lanes
         uint32_t e[kSPL + 2];
 #pragma unroll
         for (uint32_t k = 0; k != kSPL; ++k) e[k] = cur.s[k];
         e[kSPL] = nlo & 0xFFFFu;
         e[kSPL + 1] = nlo >> 16;
 #pragma unroll
-        for (uint32_t k = 0; k != kSPL; ++k) t.excval[k] = e[k] == 0 ? e[k + 1] : (e[k + 1] | (e[k + 2] << 16));
+        for (uint32_t k = 0; k != kSPL; ++k) excval[k] = e[k] == 0 ? e[k + 1] : (e[k + 1] | (e[k + 2] << 16));
         if (MULTI && narrow) {  // 8-bit slots: the value is the next 2 or 4 of them
             uint32_t b[kSPL + 4];
 #pragma unroll
@@ -1162,86 +1215,90 @@ __device__ __forceinline__ void decode_bundle(const decode_args& a, const uint32
 #pragma unroll
             for (uint32_t k = 0; k != kSPL; ++k) {
                 const uint32_t lo16 = b[k + 1] | (b[k + 2] << 8);
-                t.excval[k] = b[k] == 0 ? lo16 : (lo16 | (b[k + 3] << 16) | (b[k + 4] << 24));
+                excval[k] = b[k] == 0 ? lo16 : (lo16 | (b[k + 3] << 16) | (b[k + 4] << 24));
             }
         }
     }
 
     // ---- sizes; positions inside each unit (one scan + the value at the unit's first lane); clamp ----
-    uint32_t sz4[kSPL];
-    const uint32_t usedM = lane_used ? ~0u : 0u;
+    uint8_t* const lds_rw = reinterpret_cast<uint8_t*>(const_cast<uint32_t*>(lds));
+    const uint32_t stage_byte0 = uint32_t(reinterpret_cast<const uint8_t*>(stage_of(scratch)) - lds_rw);
+    uint32_t sz[kSPL];
+    uint32_t slowb = 0;
+    uint32_t liveb = lane_used ? ~row & 15u : 0u;
 #pragma unroll
     for (uint32_t k = 0; k != kSPL; ++k) {
         const uint32_t m = cur.m[k];
-        const uint32_t payM = uint32_t(int32_t(row << (31 - k)) >> 31);
-        const uint32_t excM = uint32_t(int32_t(row << (27 - k)) >> 31);
-        sz4[k] = ((((m >> 22) & 0x3FCu) + 4u) & ~excM) | (4u & excM);
-        sz4[k] &= ~payM & usedM;
-        t.src4[k] = (m << 2) & 0x3FFFFFCu;
-        t.lit[k] = excM;
-        t.live[k] = ~payM & usedM;
+        const bool exc = ((excbits >> k) & 1u) != 0, live = ((liveb >> k) & 1u) != 0;
+        sz[k] = live ? (exc ? 1u : (m >> 24) + 1u) : 0u;
+        t.need[k] = live ? (exc ? 1u : __builtin_amdgcn_ubfe(m, 20, 2)) : 0u;
+        t.src2[k] = m & kMetaOffMask;
+        slowb |= ((live && !exc && ((m >> 22) & 1u) != 0) ? 1u : 0u) << k;
     }
-    t.lord[0] = 0;
-    t.lord[1] = (row >> 11) & 1u;
-    t.lord[2] = (row >> 12) & 3u;
-    t.lord[3] = (row >> 14) & 3u;
-    t.off4[0] = 0;
+    t.off[0] = 0;
 #pragma unroll
-    for (uint32_t k = 1; k != kSPL; ++k) t.off4[k] = t.off4[k - 1] + sz4[k - 1];
-    const uint32_t raw_sum = (t.off4[kSPL - 1] + sz4[kSPL - 1]) >> 2;
+    for (uint32_t k = 1; k != kSPL; ++k) t.off[k] = t.off[k - 1] + sz[k - 1];
+    const uint32_t raw_sum = t.off[kSPL - 1] + sz[kSPL - 1];
     const uint32_t inc1 = wave_inclusive_sum(raw_sum);
     // (the read is unconditional: ds_bpermute returns nothing from lanes that do not take part)
     const uint32_t inc1_before = uint32_t(__shfl(inc1, int(seg_lane0 + 63u) & 63));
     const uint32_t before_seg = seg_lane0 == 0 ? 0u : inc1_before;
     const uint32_t p0 = inc1 - raw_sum - before_seg;  // position of the lane's first codeword inside its unit
-    uint32_t nlive = 0, lsum = 0;
+    uint32_t nlive = 0, lsum = 0, lb = 0;
 #pragma unroll
     for (uint32_t k = 0; k != kSPL; ++k) {
-        const uint32_t pos = p0 + (t.off4[k] >> 2);
-        const bool act = t.live[k] != 0 && pos < seg_n;
-        const uint32_t room4 = 4 * (seg_n - pos);
-        sz4[k] = act ? (sz4[k] < room4 ? sz4[k] : room4) : 0u;
-        t.live[k] = act ? ~0u : 0u;
+        const uint32_t pos = p0 + t.off[k];
+        const bool act = ((liveb >> k) & 1u) != 0 && pos < seg_n;
+        const uint32_t room = seg_n - pos;
+        lb |= (act ? 1u : 0u) << k;
         nlive += act ? 1u : 0u;
-        lsum += sz4[k] >> 2;
+        lsum += act ? (sz[k] < room ? sz[k] : room) : 0u;
+        if (!act) t.need[k] = 0;
     }
+    liveb = lb;
+    slowb &= liveb;
+    t.row = row;
+    t.liveb = liveb;
     t.lsum = lsum;
     t.nlive = nlive;
     t.obase = seg_out0 + p0;
     t.rbase = wave_inclusive_sum(nlive) - nlive;
     t.total = total;
-    t.plus_one = a.plus_one;
-
-    // ---- staging demand, as in decode_segment ---------------------------------------------------------
+    uint32_t cell_addr[kSPL];
+    const uint32_t cells = allocate_cells(t, stage_byte0, cell_addr);
+    if (cells > kStageCells) {  // (as in decode_segment)
 #pragma unroll
-    for (uint32_t k = 0; k != kSPL; ++k) {
-        const uint32_t coldM = t.live[k] & ~t.lit[k] & (0u - ((t.src4[k] >> 25) & 1u));
-        t.pk[k] = (coldM & ((1u << 16) | ((sz4[k] + 12u) >> 4))) | (t.live[k] & t.lit[k] & 1u);
+        for (uint32_t k = 0; k != kSPL; ++k)
+            if (t.need[k] != 0 && cell_addr[k] + 16 * t.need[k] > stage_byte0 + 16 * kStageCells) {
+                t.need[k] = 0;
+                slowb |= 1u << k;
+            }
     }
-    t.cpre[0] = 0;
 #pragma unroll
-    for (uint32_t k = 1; k != kSPL; ++k) t.cpre[k] = t.cpre[k - 1] + t.pk[k - 1];
-    t.cl = t.cpre[kSPL - 1] + t.pk[kSPL - 1];
-    t.tile_staged = __ballot(t.cl != 0) != 0;
-    uint32_t cexcl = 0;
-    if (t.tile_staged) cexcl = wave_inclusive_sum(t.cl) - t.cl;
-    t.qb = cexcl & 0xFFFFu;
-    t.wb = cexcl >> 16;
+    for (uint32_t k = 0; k != kSPL; ++k) t.src2[k] = t.need[k] != 0 ? cell_addr[k] : t.src2[k];
+    bool tile_wide = false;
+    if (tile_exc) {
+        bool wide = false;
+#pragma unroll
+        for (uint32_t k = 0; k != kSPL; ++k)
+            if (((excbits >> k) & 1u) != 0 && t.need[k] != 0) {  // an exception's literal into its staging cell
+                *reinterpret_cast<uint32_t*>(lds_rw + cell_addr[k]) = excval[k];
+                t.src2[k] |= excval[k] > 0xFFFFu ? 1u : 0u;
+                wide = wide || excval[k] > 0xFFFFu;
+                t.need[k] = 0;
+            }
+        tile_wide = __ballot(wide) != 0;
+    }
+    const bool tile_slow = __ballot(slowb != 0) != 0;
+    const bool tile_big = __ballot((t.need[0] | t.need[1] | t.need[2] | t.need[3]) > 1u) != 0;
 
-#ifdef DINT_DEBUG_BUNDLE
-    if (u0 <= 3 && lane < 6)
-        printf("u0 %llu cnt %u lane %u seg %u in %llu n %u lane0 %u out0 %u | s %u %u %u %u row %x live %x %x %x %x sz %u %u %u %u p0 %u obase %u lsum %u nlive %u rbase %u exc %u %u %u %u pk %x %x %x %x total %u used %u\n",
-               (unsigned long long)u0, cnt, lane, seg, (unsigned long long)seg_in, seg_n, seg_lane0, seg_out0, cur.s[0], cur.s[1], cur.s[2], cur.s[3], row,
-               t.live[0] & 1, t.live[1] & 1, t.live[2] & 1, t.live[3] & 1, sz4[0], sz4[1], sz4[2], sz4[3], p0, t.obase, t.lsum, t.nlive, t.rbase,
-               t.excval[0], t.excval[1], t.excval[2], t.excval[3], t.pk[0], t.pk[1], t.pk[2], t.pk[3], total, used);
-#endif
     // where each unit's stream ends: after its last live codeword (and that one's payload). That codeword
     // sits in the unit's highest lane that has a live one: the next such lane belongs to another unit.
     if (a.end_off) {
         uint32_t last_end = 0;  // slots from the lane's first to the end of its last live codeword
 #pragma unroll
         for (uint32_t k = 0; k != kSPL; ++k)
-            if (t.live[k] != 0)
+            if ((liveb >> k) & 1u)
                 last_end = k + 1 + (((excbits >> k) & 1u) ? (narrow ? 2 * cur.s[k] + 2u : cur.s[k] + 1u) : 0u);
         const uint64_t havers = __ballot(last_end != 0);
         const uint64_t above = lane == 63 ? 0ull : havers & ~((2ull << lane) - 1ull);
@@ -1252,30 +1309,56 @@ __device__ __forceinline__ void decode_bundle(const decode_args& a, const uint32
     }
 
     uint32_t* const out = a.out + out0;
-    const uint64_t out_bits = reinterpret_cast<uint64_t>(out);
-    uint32_t* const out_u = reinterpret_cast<uint32_t*>((uint64_t(uniform(uint32_t(out_bits >> 32))) << 32) |
-                                                        uniform(uint32_t(out_bits)));
+    uint32_t* const out_u = reinterpret_cast<uint32_t*>(uniform64(reinterpret_cast<uint64_t>(out)));
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out_u, 0, int(total * 4), 0x00020000);
-    expand_tile<kRounds, kGroups>(t, 0u, lds, scratch, rs_table, rs_out, out, lane, []() {});
+    // the rows into their cells; the second halves of the large ones behind the flag/delta phase
+#pragma unroll
+    for (uint32_t k = 0; k != kSPL; ++k) asm volatile("" : "+v"(rr.q[k]));
+#pragma unroll
+    for (uint32_t k = 0; k != kSPL; ++k)
+        if (t.need[k] != 0) *reinterpret_cast<u32x4*>(lds_rw + t.src2[k]) = rr.q[k];
+    if (tile_big) {
+#pragma unroll
+        for (uint32_t k = 0; k != kSPL; ++k)
+            if (t.need[k] > 1u)
+                rr.q[k] = __builtin_amdgcn_raw_buffer_load_b128(c.rs_dict, c.rows_base + 32 * (meta_base + cur.s[k]) + 16, 0, 0);
+    }
+    expand_tile<kRounds, kGroups>(t, false, tile_wide, a.plus_one, 0u, lds, scratch, rs_out, lane, pf, [&]() {
+#pragma unroll
+        for (uint32_t k = 0; k != kSPL; ++k) asm volatile("" : "+v"(rr.q[k]));
+        if (tile_big) {
+#pragma unroll
+            for (uint32_t k = 0; k != kSPL; ++k)
+                if (t.need[k] > 1u) *reinterpret_cast<u32x4*>(lds_rw + t.src2[k] + 16) = rr.q[k];
+        }
+        wave_lds_fence();
+    });
+    if (tile_slow) {
+        // (positions in slow_stores are relative to the bundle; a unit's clamp is what `room` must be)
+        const uint8_t* const my_slots = a.enc + slot0 + stride * (lane - seg_lane0);
+        if (MULTI && narrow) slow_stores<8>(c, t, slowb, a.plus_one, 0u, seg_out0 + seg_n, my_slots, hot_base, hot_k, meta_base, rs_out);
+        else slow_stores<16>(c, t, slowb, a.plus_one, 0u, seg_out0 + seg_n, my_slots, hot_base, hot_k, meta_base, rs_out);
+    }
+    SECTION(pf, 13, "epilogue");
 }
 
 // A multi-dictionary unit: blocks of 256 integers (the last one shorter), each opened
 // by a selector byte: < 6 -> 16-bit codewords against dictionary `selector`, else 8-bit
 // codewords against dictionary `selector - 6` (vroom_env/dint_codecs.hpp:521-619).
 // Blocks carry no length, so they are decoded one after the other.
-__device__ __forceinline__ void decode_unit_multi(const decode_args& a, const uint32_t* lds, const uint16_t* cls,
-                                                  uint32_t* scratch, uint64_t unit_index, uint32_t lane) {
+__device__ __forceinline__ void decode_unit_multi(const decode_args& a, const wave_ctx& c, uint64_t unit_index, prof_t& pf) {
+    const uint32_t lane = c.lane;
     const dint_unit* up = a.units + unit_index;
     const uint64_t out_off = up->out_off;
     const uint32_t n = up->n;
-    if (n == 0 || out_off + n > a.out_capacity || (a.only_full && n != 256)) return;
+    if (n == 0 || n > kMaxUnitInts || out_off > a.out_capacity || a.out_capacity - out_off < n || (a.only_full && n != 256)) return;
     uint64_t pos = up->in_off;
     chain_io ch{};
     for (uint32_t done = 0; done < n;) {
         const uint32_t bsize = n - done < 256u ? n - done : 256u;
-        pos = (uint64_t(uniform(uint32_t(pos >> 32))) << 32) | uniform(uint32_t(pos));
+        pos = uniform64(pos);
         // chained unless the block sits in the last kChainBytes of the buffer
-        const bool chained = pos + 1 + kChainBytes <= a.enc_bytes;
+        const bool chained = pos <= a.enc_bytes && a.enc_bytes - pos >= 1 + kChainBytes;
         if (chained && !ch.valid) chain_request(a.enc, pos, lane, ch);  // first block of the unit
         uint32_t sel;
         if (chained) {
@@ -1293,13 +1376,12 @@ __device__ __forceinline__ void decode_unit_multi(const decode_args& a, const ui
         dd.pad = 0;
         uint32_t* const out = a.out + out_off + done;
         ch.more = done + bsize < n;
-        ch.next_off = ~0ull;  // the next block starts where this one ends
         if (chained) {
-            if (narrow) pos = decode_segment<8, 1, 1, true>(a, lds, cls, scratch, dd, pos + 1, bsize, out, lane, ch);
-            else pos = decode_segment<16, 1, 1, true>(a, lds, cls, scratch, dd, pos + 1, bsize, out, lane, ch);
+            if (narrow) pos = decode_segment<8, 1, 1, true>(a, c, dd, pos + 1, bsize, out, ch, pf);
+            else pos = decode_segment<16, 1, 1, true>(a, c, dd, pos + 1, bsize, out, ch, pf);
         } else {
-            if (narrow) pos = decode_segment<8, 1, 1, false>(a, lds, cls, scratch, dd, pos + 1, bsize, out, lane, ch);
-            else pos = decode_segment<16, 1, 1, false>(a, lds, cls, scratch, dd, pos + 1, bsize, out, lane, ch);
+            if (narrow) pos = decode_segment<8, 1, 1, false>(a, c, dd, pos + 1, bsize, out, ch, pf);
+            else pos = decode_segment<16, 1, 1, false>(a, c, dd, pos + 1, bsize, out, ch, pf);
         }
         done += bsize;
     }
@@ -1311,19 +1393,41 @@ __device__ __forceinline__ void decode_unit_multi(const decode_args& a, const ui
 // so a static unit -> wave map leaves most of the chip idle behind the slowest
 // waves. kQueueShards counters, one per group of workgroups; a wave draws its next
 // work item while it is still decoding the current one.
-#ifdef DINT_EXP_FINISH
-__device__ unsigned long long g_finish[8192];
-#endif
+// The kernel arguments arrive as one 16-register scalar load; left like that, the compiler keeps (and under
+// pressure spills and reloads) the whole tuple whenever one field is live — 66 v_readlane per tile in
+// round 1. Passing every field through an empty asm makes each its own 32- or 64-bit scalar.
+__device__ __forceinline__ decode_args own_scalars(const decode_args& k) {
+    decode_args a = k;
+    asm volatile("" : "+s"(a.dict.tables), "+s"(a.dict.lds_image), "+s"(a.dict.descs), "+s"(a.dict.tables_bytes),
+                 "+s"(a.dict.rows_base), "+s"(a.dict.goff_base), "+s"(a.dict.gtable_base), "+s"(a.dict.hot_words),
+                 "+s"(a.dict.first.meta_base), "+s"(a.dict.first.hot_base), "+s"(a.dict.first.hot_k));
+    asm volatile("" : "+s"(a.enc), "+s"(a.enc_bytes), "+s"(a.units), "+s"(a.n_units), "+s"(a.out),
+                 "+s"(a.out_capacity), "+s"(a.end_off), "+s"(a.queue), "+s"(a.n_shards), "+s"(a.only_full));
+    asm volatile("" : "+s"(a.sched), "+s"(a.items), "+s"(a.n_items), "+s"(a.item_cnt), "+s"(a.spans), "+s"(a.plus_one));
+    return a;
+}
+
 template <bool MULTI>
-__device__ __forceinline__ void decode_kernel_body(const decode_args& a) {
+__device__ __forceinline__ void decode_kernel_body(const decode_args& kernarg) {
+    const decode_args a = own_scalars(kernarg);
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     for (uint32_t i = threadIdx.x; i < a.dict.hot_words; i += kBlockThreads) lds[i] = a.dict.lds_image[i];
     uint16_t* const cls = reinterpret_cast<uint16_t*>(lds + a.dict.hot_words);
     build_class_table(cls);
-    __syncthreads();
     const uint32_t lane = lane_id();
     const uint32_t wave = uniform(threadIdx.x / kWave);
-    uint32_t* scratch = lds + a.dict.hot_words + kClassTableWords + wave * kScratchWords;
+    uint32_t* const scratch = lds + a.dict.hot_words + kClassTableWords + wave * kScratchWords;
+    for (uint32_t i = lane; i < kFwWords; i += kWave) scratch[i] = 0;  // the flag words start out zero
+    __syncthreads();
+    wave_ctx c;
+    c.lds = lds;
+    c.cls = cls;
+    c.scratch = scratch;
+    c.lane = lane;
+    c.rs_dict = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.dict.tables), 0, int(a.dict.tables_bytes), 0x00020000);
+    c.rows_base = a.dict.rows_base;
+    c.goff_base = a.dict.goff_base;
+    c.gtable_base = a.dict.gtable_base;
     // Work queue. Every shard — the workgroups with the same blockIdx % n_shards: one XCD under
     // round-robin placement — walks its own CONTIGUOUS part of the work items and, when that is done,
     // helps with the next shards' parts. Contiguous, because an XCD that strides over the whole
@@ -1335,42 +1439,58 @@ __device__ __forceinline__ void decode_kernel_body(const decode_args& a) {
     const uint64_t n_work = a.sched ? uint64_t(uniform(*a.n_items)) : a.n_units;
     const uint64_t per_shard = (n_work + a.n_shards - 1) / a.n_shards;
     uint32_t cur = shard, tried = 0;
-    auto draw = [&]() -> uint64_t {  // next work item, or ~0: nothing left anywhere
-        while (tried < a.n_shards) {
+    // A draw is two steps: the ticket (one returning atomic on the shard's counter) is asked for while the
+    // previous work item is still being decoded, and only looked at when that one is done — the atomic's
+    // round trip (2.5k cycles per work item, 6 % of the kernel in round 1's profile) hides behind the decode.
+    auto ask = [&]() -> uint32_t {
+        uint32_t j = 0;
+        if (lane == 0) j = __hip_atomic_fetch_add(a.queue + cur * kQueueStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return j;
+    };
+    auto take = [&](uint32_t ticket) -> uint64_t {  // the work item of a ticket, or ~0: nothing left anywhere
+        uint32_t j = uniform(ticket);
+        for (;;) {
             const uint64_t first = per_shard * cur;
             const uint64_t size = first >= n_work ? 0 : (n_work - first < per_shard ? n_work - first : per_shard);
-            uint32_t j = 0;
-            if (lane == 0) j = __hip_atomic_fetch_add(a.queue + cur * kQueueStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            j = uniform(j);
             if (j < size) return first + j;
-            cur = cur + 1 == a.n_shards ? 0 : cur + 1;
-            ++tried;
+            cur = cur + 1 == a.n_shards ? 0 : cur + 1;  // this shard is done: help the next one
+            if (++tried >= a.n_shards) return ~0ull;
+            j = uniform(ask());
         }
-        return ~0ull;
     };
-    chain_io ch{};
-    uint64_t w = draw();
+    // what a work item is: a unit on its own, or the first of `cnt` bundled ones
+    auto item_of = [&](uint64_t w, uint64_t& u, uint32_t& cnt) {
+        u = a.sched ? uint64_t(a.items[w]) : w;
+        cnt = a.sched ? uint32_t(a.item_cnt[w]) : 1u;
+    };
+    prof_t pf;
+#ifdef DINT_PROFILE
+    prof_begin(pf, scratch + kScratchWords - kProfWords, lane);
+#endif
+    // (Prefetching the next item's description as well — two items ahead — was measured: no gain; what a wave
+    // waits for here is the vector-memory front end, not the round trip.)
+    uint64_t w = take(ask());
     while (w != ~0ull) {
-        const uint64_t w_next = draw();
-        const uint64_t u = a.sched ? uint64_t(uniform(a.items[w])) : w;
-        const uint32_t cnt = a.sched ? uint32_t(uniform(a.sched[u])) : 1u;
+        SECTION(pf, 14, "draw");
+        uint32_t ticket = ask();
+        uint64_t u;
+        uint32_t cnt;
+        item_of(w, u, cnt);
+        const uint64_t uu = uniform64(u);
+        const uint32_t cc = uniform(cnt);
         if (MULTI) {
-            if (cnt > 1) decode_bundle<true>(a, lds, cls, scratch, u, cnt, lane);
-            else decode_unit_multi(a, lds, cls, scratch, u, lane);
-        } else if (cnt > 1) {
-            decode_bundle<false>(a, lds, cls, scratch, u, cnt, lane);
+            if (cc > 1) decode_bundle<true>(a, c, uu, cc, pf);
+            else decode_unit_multi(a, c, uu, pf);
+        } else if (__builtin_expect(cc > 1, 0)) {
+            decode_bundle<false>(a, c, uu, cc, pf);
         } else {
-            uint64_t next_in = ~0ull;
-            if (DINT_UNIT_CHAIN && w_next != ~0ull) {
-                const uint64_t un = a.sched ? uint64_t(uniform(a.items[w_next])) : w_next;
-                if (!a.sched || uniform(a.sched[un]) == 1u) next_in = a.units[un].in_off;
-            }
-            decode_unit_single(a, lds, cls, scratch, u, lane, ch, next_in);
+            decode_unit_single(a, c, uu, pf);
         }
-        w = w_next;
+        asm volatile("" : "+v"(ticket));
+        w = take(ticket);
     }
-#ifdef DINT_EXP_FINISH  // diagnostic: when did this wave run out of work? (tail of the kernel)
-    if (lane == 0) g_finish[blockIdx.x * kWavesPerBlock + wave] = __builtin_amdgcn_s_memrealtime();
+#ifdef DINT_PROFILE
+    prof_end(pf);
 #endif
 }
 
