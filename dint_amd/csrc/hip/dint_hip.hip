@@ -173,14 +173,14 @@ struct dint_dict {
 
 namespace {
 
-// Device layout of a dictionary file. One allocation [gmeta | rows | goff | gtable | LDS image | descriptors]:
-//   gmeta[i] = one word per offsets slot of the file (multi: the 6 dictionaries back to back):
-//              (size-1) << 24 | kMetaCold | kMetaSlow, or | staging cells (1: up to 8 integers, 2) << 20;
-//              runs carry only their size (their source is the zero region of the LDS image);
+// Device layout of a dictionary file. One allocation [heads | tails | goff | gtable | LDS image | descriptors],
+// one record per offsets slot of the file (multi: the 6 dictionaries back to back):
+//   heads[i] = 16 bytes: the metadata word (size-1) << 24 | kMetaCold | kMetaSlow, or | staging cells << 20
+//              (1: up to 6 integers, 2: up to 14, 3), then the entry's first six integers as u16 — what a cold
+//              slot fetches with ONE lane request, addressed by the slot value alone, and all a codeword of up
+//              to 6 integers needs; runs carry only their size (their source is the zero region of the LDS image);
+//   tails[i] = 32 bytes: integers 6..21 as u16 (the second and third request of the larger cold codewords);
 //   goff[i]  = the entry's word offset into gtable (slow path only);
-//   rows     = 32 bytes per slot: the entry's integers as sixteen u16 (zero padded) — what a cold codeword
-//              fetches into its LDS cell(s), ONE 16-byte lane request for up to 8 integers, addressed by the
-//              slot number alone (no offset lookup between the slot and its payload);
 //   gtable   = [the file's payload words][16 words of padding], 32-bit: the slow path's source;
 //   LDS image = [256 u16 zeros]{[hot meta of dictionary d: hot_k[d] words]}[hot payloads as u16];
 //   hot meta = (size-1) << 24 | byte offset of the payload inside the image (runs -> the zeros), one dummy
@@ -285,8 +285,8 @@ int upload_hot_set(dint_dict& dd, hot_layout const& lay) {
 
 int stage_dictionary(dint_dict& dd, parsed_dict const& pd) {
     const size_t slots = pd.size.size();
-    std::vector<uint32_t> gmeta(slots);
-    std::vector<uint16_t> rows(slots * 16, 0);
+    std::vector<uint32_t> heads(slots * 4, 0);   // per slot: metadata word, integers 0..5 as u16
+    std::vector<uint16_t> tails(slots * 16, 0);  // per slot: integers 6..21 as u16
     std::vector<uint32_t> goff(slots, 0);
     std::vector<uint32_t> gtable(pd.table);
     gtable.resize(gtable.size() + kMaxEntry, 0);
@@ -297,42 +297,45 @@ int stage_dictionary(dint_dict& dd, parsed_dict const& pd) {
             if (sz == 0 || sz > 256) return DINT_ERR_FORMAT;
             const uint32_t pw = (i >= kReserved && sz <= kMaxEntry) ? sz : 0;
             if (pw == 0) {  // runs copy zeros: their source is the zero region at the start of the LDS image
-                gmeta[slot] = (sz - 1) << 24;
+                heads[slot * 4] = (sz - 1) << 24;
                 continue;
             }
             bool slow = false;
             for (uint32_t w = 0; w != pw; ++w) slow = slow || pd.table[pd.off[slot] + w] > 0xFFFFu;
             // (goff: every entry's offset into gtable — a tile with more cold codewords than staging cells sends
             // the surplus through the slow path too)
-            gmeta[slot] = ((sz - 1) << 24) | kMetaCold | (slow ? kMetaSlow : (pw > 8 ? 2u : 1u) << 20);
+            const uint32_t cells = pw <= 6 ? 1u : pw <= 14 ? 2u : 3u;
+            heads[slot * 4] = ((sz - 1) << 24) | kMetaCold | (slow ? kMetaSlow : cells << 20);
             goff[slot] = pd.off[slot];
-            if (!slow)
-                for (uint32_t w = 0; w != pw; ++w) rows[slot * 16 + w] = uint16_t(pd.table[pd.off[slot] + w]);
+            if (!slow) {
+                uint16_t* const h = reinterpret_cast<uint16_t*>(&heads[slot * 4 + 1]);
+                for (uint32_t w = 0; w != pw; ++w) (w < 6 ? h[w] : tails[slot * 16 + w - 6]) = uint16_t(pd.table[pd.off[slot] + w]);
+            }
         }
     hot_layout lay;
     const int st = choose_hot_set(pd, lay);
     if (st != DINT_OK) return st;
 
     HIP_TRY(hipSetDevice(dd.device));
-    // One allocation, a multiple of 2 MB, for everything the kernel reads at random (metadata, rows, payload
+    // One allocation, a multiple of 2 MB, for everything the kernel reads at random (heads, tails, payload
     // table) and at start (LDS image, descriptors): the randomly gathered tables then sit in as few and as
     // large page-table fragments as the driver can give, whatever the state of the memory pool.
     auto up256 = [](size_t b) { return (b + 255) / 256 * 256; };
-    const size_t b_meta = up256(gmeta.size() * 4), b_rows = up256(rows.size() * 2), b_goff = up256(goff.size() * 4),
+    const size_t b_heads = up256(heads.size() * 4), b_tails = up256(tails.size() * 2), b_goff = up256(goff.size() * 4),
                  b_table = up256(gtable.size() * 4);
     const size_t b_image = up256(size_t(kHotImageWords) * 4), b_descs = up256(pd.num_dicts * sizeof(dict_desc));
     const size_t two_mb = size_t(2) << 20;
-    const size_t b_tables = b_meta + b_rows + b_goff + b_table;
+    const size_t b_tables = b_heads + b_tails + b_goff + b_table;
     const size_t total = (b_tables + b_image + b_descs + two_mb - 1) / two_mb * two_mb;
     if (b_tables >= (size_t(1) << 31)) return DINT_ERR_FORMAT;
     HIP_TRY(hipMalloc(&dd.d_block, total));
     uint8_t* base = static_cast<uint8_t*>(dd.d_block);
     dd.d_image = reinterpret_cast<uint32_t*>(base + b_tables);
     dd.d_descs = reinterpret_cast<dint_dev::dict_desc*>(base + b_tables + b_image);
-    HIP_TRY(hipMemcpy(base, gmeta.data(), gmeta.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(base + b_meta, rows.data(), rows.size() * 2, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(base + b_meta + b_rows, goff.data(), goff.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(base + b_meta + b_rows + b_goff, gtable.data(), gtable.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(base, heads.data(), heads.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(base + b_heads, tails.data(), tails.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(base + b_heads + b_tails, goff.data(), goff.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(base + b_heads + b_tails + b_goff, gtable.data(), gtable.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&dd.d_queues, size_t(dint_dict::kQueueSlots) * kQueueShards * kQueueStride * 4));
     for (uint32_t i = 0; i != dint_dict::kQueueSlots; ++i) {
         HIP_TRY(hipEventCreateWithFlags(&dd.slot_done[i], hipEventDisableTiming));
@@ -341,9 +344,10 @@ int stage_dictionary(dint_dict& dd, parsed_dict const& pd) {
     }
     dd.view.tables = base;
     dd.view.tables_bytes = uint32_t(b_tables);
-    dd.view.rows_base = uint32_t(b_meta);
-    dd.view.goff_base = uint32_t(b_meta + b_rows);
-    dd.view.gtable_base = uint32_t(b_meta + b_rows + b_goff);
+    dd.view.heads_base = 0;
+    dd.view.tails_base = uint32_t(b_heads);
+    dd.view.goff_base = uint32_t(b_heads + b_tails);
+    dd.view.gtable_base = uint32_t(b_heads + b_tails + b_goff);
     dd.view.lds_image = dd.d_image;
     dd.view.descs = dd.d_descs;
     dd.table_words = uint32_t(gtable.size());

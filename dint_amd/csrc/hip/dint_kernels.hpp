@@ -94,7 +94,7 @@ constexpr uint32_t kZeroHalves = 256;                 // longest run codeword, i
 constexpr uint32_t kMetaCold = 1u << 23;              // the integers come through staging cells (row table)
 constexpr uint32_t kMetaSlow = 1u << 22;              // ... or, with this bit, from gtable through slow_stores
 constexpr uint32_t kMetaOffMask = (1u << 20) - 1;     // hot: byte offset of the integers (u16 each) in the LDS image; else 0
-                                                      // bits 20-21: staging cells a cold codeword takes (1: up to 8 integers, 2)
+                                                      // bits 20-21: staging cells a cold codeword takes (1: up to 6 integers, 2: up to 14, 3)
 constexpr uint32_t kQueueShards = 8;                  // dynamic unit queue: one counter per shard
 constexpr uint32_t kQueueStride = 32;                 // words between counters (own 128-byte line each)
 constexpr uint32_t kMaxUnitInts = 1u << 28;           // byte offsets inside a unit's output stay 32-bit
@@ -109,11 +109,12 @@ struct dict_desc {
 
 // Device view of a dictionary file (layout: dint_hip.hip, stage_dictionary).
 struct dict_view {
-    const uint8_t* tables;      // gmeta (u32 per slot) | rows (32 bytes per slot) | goff (u32 per slot) | gtable (u32 payload words)
+    const uint8_t* tables;      // heads (16 bytes per slot) | tails (32 bytes per slot) | goff (u32 per slot) | gtable (u32 payload words)
     const uint32_t* lds_image;  // [256 u16 zeros]{[hot meta of dictionary d]}[hot payloads as u16], hot_words long
     const dict_desc* descs;     // one per dictionary (multi: 6)
     uint32_t tables_bytes;
-    uint32_t rows_base;         // byte offset of the row table inside `tables`
+    uint32_t heads_base;        // byte offset of the heads inside `tables`: {metadata word, integers 0..5 as u16} per slot
+    uint32_t tails_base;        // ... of the tails: integers 6..21 as u16 per slot
     uint32_t goff_base;         // ... of the slow path's offsets into gtable (u32 per slot)
     uint32_t gtable_base;       // ... of gtable
     uint32_t hot_words;         // multiple of 4
@@ -251,9 +252,11 @@ struct tile_regs {
     uint32_t s[kSPL];  // slot values
     uint32_t m[kSPL];  // metadata of each slot read as a codeword (garbage for payload slots)
 };
-struct meta_regs {     // a tile's metadata on its way in: the two sources are merged where the wait is
-    uint32_t h[kSPL];  // from the LDS image (meaningful for s < hot_k)
-    uint32_t c[kSPL];  // from L2 (s >= hot_k)
+struct meta_regs {     // the metadata of a tile's hot slots on its way in (LDS); the cold slots' comes with their heads
+    uint32_t h[kSPL];
+};
+struct head_regs {     // per cold slot: the 16-byte head of its dictionary entry — metadata word + its first 6 integers
+    u32x4 q[kSPL];     // (later in the tile: the next 8 integers of the entries that have them)
 };
 
 template <int W>
@@ -321,55 +324,44 @@ struct wave_ctx {
     uint32_t* scratch;             // this wave's {flag pairs | delta table | staging cells}
     uint32_t lane;
     __amdgpu_buffer_rsrc_t rs_dict;  // gmeta | rows | gtable: one descriptor, hardware bounds
-    uint32_t rows_base, goff_base, gtable_base;
+    uint32_t heads_base, tails_base, goff_base, gtable_base;
 };
 
 __device__ __forceinline__ uint32_t* fw_of(uint32_t* scratch) { return scratch; }
 __device__ __forceinline__ uint32_t* delta_of(uint32_t* scratch) { return scratch + kFwWords; }
 __device__ __forceinline__ uint32_t* stage_of(uint32_t* scratch) { return scratch + kFwWords + kDeltaWords; }
 
-// Metadata of the four slots of a lane: LDS for the hot codewords (unconditional reads, all four in flight
-// together: cold lanes read word 0), L2 for the cold ones under their exec mask — into registers of their
-// own, so that nothing has to wait for the LDS reads before the loads are issued (the two are merged where
-// the tile is unpacked, one tile later). Two address spaces, never a pointer select (that would become one
-// slow flat load).
+// What the front end needs to know about the four slots of a lane, requested while the previous tile is
+// being expanded: the metadata word of the hot codewords from the LDS image (unconditional reads, all four in
+// flight together; the cold lanes read a dummy word), and for every cold slot the 16-byte HEAD of its
+// dictionary entry from L2 — its metadata word and its first six integers (u16) in one lane request, addressed
+// by the slot value alone. (Round 1 and the first versions of this round fetched the metadata word and the
+// integers separately: two lane requests per cold codeword, and the vector-memory front end — 0.45 scattered
+// lane requests per CU and cycle, tools/micro/gather_rate.hip — was what the kernel waited for.) Whether a
+// slot is a codeword at all is not known yet (classification comes later): a payload slot that looks like a
+// cold codeword fetches a head nobody reads.
 __device__ __forceinline__ void request_metas(const wave_ctx& c, uint32_t hot_base, uint32_t hot_k, uint32_t meta_base,
-                                              const tile_regs& t, meta_regs& mr) {
+                                              const tile_regs& t, meta_regs& mr, head_regs& hr) {
     // (the word behind a dictionary's hot metas is a dummy: the cold lanes read it, min instead of compare + select)
 #pragma unroll
     for (uint32_t k = 0; k != kSPL; ++k) mr.h[k] = c.lds[hot_base + (t.s[k] < hot_k ? t.s[k] : hot_k)];
 #pragma unroll
     for (uint32_t k = 0; k != kSPL; ++k)
-        if (t.s[k] >= hot_k) mr.c[k] = __builtin_amdgcn_raw_buffer_load_b32(c.rs_dict, 4 * (meta_base + t.s[k]), 0, DINT_GATHER_AUX);
+        if (t.s[k] >= hot_k) hr.q[k] = __builtin_amdgcn_raw_buffer_load_b128(c.rs_dict, c.heads_base + 16 * (meta_base + t.s[k]), 0, 0);
 }
 // ... where the wait is: everything has landed (the asm makes the values the asm's, not a load's: nothing
 // for the compiler to wait for later)
-__device__ __forceinline__ void take_metas(uint32_t hot_k, meta_regs& mr, tile_regs& t) {
-    asm volatile("" : "+v"(mr.c[0]), "+v"(mr.c[1]), "+v"(mr.c[2]), "+v"(mr.c[3]));
+__device__ __forceinline__ void take_metas(uint32_t hot_k, meta_regs& mr, head_regs& hr, tile_regs& t) {
+#pragma unroll
+    for (uint32_t k = 0; k != kSPL; ++k) asm volatile("" : "+v"(hr.q[k]));
     asm volatile("" : "+v"(mr.h[0]), "+v"(mr.h[1]), "+v"(mr.h[2]), "+v"(mr.h[3]));
 #pragma unroll
-    for (uint32_t k = 0; k != kSPL; ++k) t.m[k] = t.s[k] < hot_k ? mr.h[k] : mr.c[k];
+    for (uint32_t k = 0; k != kSPL; ++k) t.m[k] = t.s[k] < hot_k ? mr.h[k] : hr.q[k].x;
 }
 
-// The rows of the cold slots of a tile: 32 bytes per dictionary slot — the entry's integers as sixteen u16 —
-// addressed by the slot value alone. The first half (8 integers: all a codeword of size <= 8 needs) is
-// requested by the slot's own lane at the end of the PREVIOUS tile, one 16-byte load per cold slot, and
-// written into the codeword's staging cell where the tile waits; the second half (cold codewords of 16
-// integers: 3.5 % of the slots of a Gov2-shaped stream) is requested there, into the same registers, and
-// lands behind the flag/delta phase. Whether a slot is a codeword at all is not known when the first halves
-// are requested (classification comes later): a payload slot that looks like a cold codeword fetches a row
-// nobody reads.
 // (LDS-DMA — buffer_load ... lds with per-lane offsets, no registers — delivers the right bytes,
 // tools/micro/lds_dma.hip, but its destination is fixed by the lane number: a cell per SLOT instead of per
-// cold codeword, 8 KB per wave with 32-byte rows — the LDS the dictionary's hot part lives on.)
-struct row_regs {
-    u32x4 q[kSPL];
-};
-__device__ __forceinline__ void request_rows(const wave_ctx& c, uint32_t hot_k, uint32_t meta_base, const tile_regs& t, row_regs& r) {
-#pragma unroll
-    for (uint32_t k = 0; k != kSPL; ++k)
-        if (t.s[k] >= hot_k) r.q[k] = __builtin_amdgcn_raw_buffer_load_b128(c.rs_dict, c.rows_base + 32 * (meta_base + t.s[k]), 0, DINT_GATHER_AUX);
-}
+// cold codeword, 4 KB more LDS per wave — the LDS the dictionary's hot part lives on.)
 
 // Segment chaining (multi-dictionary units): a block's bytes are known only when the previous block
 // has been parsed, so a block on its own pays the full memory latency of its selector and its slots
@@ -412,7 +404,7 @@ struct tile_slots {
     uint32_t off[kSPL];     // first output of slot k's codeword behind the lane's first (integers)
     uint32_t src2[kSPL];    // LDS byte address of its integers (u16 each): hot payload, zero region, its staging cell(s);
                             // bit 0: the cell holds a 32-bit exception literal
-    uint32_t need[kSPL];    // staging cells it takes: 0, 1 (exception literal; cold codeword of up to 8 integers), 2 (larger)
+    uint32_t need[kSPL];    // staging cells it takes: 0; 1 (exception literal; cold codeword of up to 6 integers); 2 (up to 14); 3
     uint32_t lsum, obase;   // outputs of the lane's live codewords, position of the first
     uint32_t total;         // outputs of the tile (wave-uniform)
     // tiles that are not plain (an exception or a payload slot somewhere, the segment's last tile, a bundle):
@@ -427,8 +419,9 @@ struct tile_slots {
 constexpr uint32_t kPlainRow = (1u << 11) | (2u << 12) | (3u << 14);  // four codeword headers, nothing special
 constexpr uint32_t kStageCells = kStageWords / 4;
 
-// Staging cells of a tile: one 16-byte cell per exception literal and per cold codeword of up to 8 integers,
-// two for the larger ones; allocated in slot order by one wave scan over t.need. -> the cell's LDS byte
+// Staging cells of a tile: one 16-byte cell per exception literal; per cold codeword one for its head (metadata
+// word + 6 integers: the integers start 4 bytes into the cell), a second for integers 6..13, a third for 14
+// and 15; allocated in slot order by one wave scan over t.need. -> the cell's LDS byte
 // address per slot; returns the cells the tile takes (wave-uniform).
 __device__ __forceinline__ uint32_t allocate_cells(const tile_slots& t, uint32_t stage_byte0, uint32_t (&cell_addr)[kSPL]) {
     const uint32_t pre1 = t.need[0], pre2 = pre1 + t.need[1], pre3 = pre2 + t.need[2], mine = pre3 + t.need[3];
@@ -570,8 +563,8 @@ __device__ __forceinline__ void expand_batch(uint32_t bt, uint32_t out_int, cons
 // Steps 3 and 4 of a tile: tables, expansion, stores — in one batch when the tile decodes to at most
 // ROUNDS x GROUPS x 256 integers (every tile of a real stream), else in batches of lanes (a tile full of long
 // runs: up to 256 x 256 integers). `plain`: tables_plain applies. `wide`: the tile holds a 32-bit exception
-// literal. `before_gathers` runs before the gathers of every batch: the caller lands there what it requested
-// at the wait point (decode_segment).
+// literal. `before_gathers` runs once, before the first gathers: the caller lands there what it requested at
+// the wait point, and requests the next tile's metadata (decode_segment).
 // (The one-batch path is straight-line on purpose: inside a loop over batches everything the tables are built
 // from would stay live through the expansion — 55 more registers, measured.)
 template <uint32_t ROUNDS, uint32_t GROUPS, class BeforeGathers>
@@ -610,12 +603,12 @@ __device__ __forceinline__ void expand_tile(const tile_slots& t, bool plain, boo
         const uint32_t bend = readlane(t.obase + t.lsum, last);
         const uint32_t rend = readlane(t.rbase + t.nlive, last);
         if (bend <= done) {  // (malformed input: nothing decodable left in this tile)
-            before_gathers();
+            if (done == 0) before_gathers();
             break;
         }
         tables_general(t, fw, delta, inb, done, rdone);
         wave_lds_fence();
-        before_gathers();
+        if (done == 0) before_gathers();
         expand_batch<ROUNDS, GROUPS, true>(bend - done, out_int0 + done, lds_bytes, fw, delta, rs_out, lane, plus_one);
         *reinterpret_cast<uint32_t*>(fw + 8 * lane) = 0;
         wave_lds_fence();
@@ -648,7 +641,7 @@ __device__ __forceinline__ void slow_stores(const wave_ctx& c, const tile_slots&
                 if (sv == 1) v |= (uint32_t(lp[2]) << 16) | (uint32_t(lp[3]) << 24);
                 __builtin_amdgcn_raw_buffer_store_b32(v + plus_one, rs_out, 4 * pos, 0, DINT_STORE_AUX);
             } else {
-                const uint32_t m = sv < hot_k ? c.lds[hot_base + sv] : __builtin_amdgcn_raw_buffer_load_b32(c.rs_dict, 4 * (meta_base + sv), 0, 0);
+                const uint32_t m = sv < hot_k ? c.lds[hot_base + sv] : __builtin_amdgcn_raw_buffer_load_b32(c.rs_dict, c.heads_base + 16 * (meta_base + sv), 0, 0);
                 const uint32_t goff = __builtin_amdgcn_raw_buffer_load_b32(c.rs_dict, c.goff_base + 4 * (meta_base + sv), 0, 0);
                 const uint32_t size = (m >> 24) + 1u, room = seg_n - pos;
                 const uint32_t cnt = size < room ? size : room;
@@ -686,7 +679,7 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const w
     uint64_t slot_byte = in_off_u;  // first byte of the tile whose slots are loaded next (wave-uniform)
     tile_regs cur, nxt;
     meta_regs mr;
-    row_regs rr;  // (deliberately uninitialised: each register is written and read under the same lane predicate)
+    head_regs hr;  // (deliberately uninitialised: each register is written and read under the same lane predicate)
     uint64_t raw1, raw2 = 0;
     if (CHAINED) {  // tiles 0 and 1 arrived with the previous block (or were requested by the caller)
         unpack_slots<W>(chain_tile<W>(ch.data, 0, lane), cur);
@@ -700,12 +693,10 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const w
         raw2 = load_lane_slots<W>(a.enc, slot_byte, lane, a.enc_bytes);
     }
     ch.valid = false;
-    request_metas(c, dd.hot_base, hot_k, dd.meta_base, cur, mr);
-    request_rows(c, hot_k, dd.meta_base, cur, rr);
+    request_metas(c, dd.hot_base, hot_k, dd.meta_base, cur, mr, hr);
     // Everything loaded so far has landed before the loop is entered: inside it, a wait may only
-    // ever sit right before a tile's expansion (see the prefetch note below), never after its stores.
+    // ever sit before a tile's stores (see the notes below), never right after them.
     asm volatile("" : "+v"(raw1), "+v"(raw2));
-    take_metas(hot_k, mr, cur);
     unpack_slots<W>(raw1, nxt);
 
     uint32_t produced = 0;
@@ -723,6 +714,8 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const w
         const uint64_t raw3 = load_lane_slots<W>(a.enc, slot_byte, lane, a.enc_bytes);
 
         SECTION(pf, 1, "1_classify");
+        // this tile's metadata: requested before the previous tile's stores (so this is no wait for them)
+        take_metas(hot_k, mr, hr, cur);
         // ---- 1. classification: table lookup, repeated until the lane-to-lane carries agree ----
         uint32_t smin = cur.s[0];
 #pragma unroll
@@ -883,20 +876,9 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const w
         }
         const bool tile_slow = __ballot(slowb != 0) != 0;
         const bool tile_big = __ballot((t.need[0] | t.need[1] | t.need[2] | t.need[3]) > 1u) != 0;
-        SECTION(pf, 3, "3_prefetch");
-        // ---- prefetch: metadata of tile t+1 (its slots are already here). Issued before this tile's
-        // stores; waited for right before the expansion (vmcnt is one in-order counter for loads AND
-        // stores on gfx950: a wait placed after the stores would also wait for their acknowledgements).
-        // The last tile of a segment has no successor to prefetch; a chained one asks for the next block.
-        if (!last_tile) {
-            request_metas(c, dd.hot_base, hot_k, dd.meta_base, nxt, mr);
-        } else {
-#pragma unroll
-            for (uint32_t k = 0; k != kSPL; ++k) mr.h[k] = 0;
-            if (CHAINED) {
-                const uint64_t nb = tile_base + uint64_t(kSlotBytes) * end_slot;
-                if (ch.more && nb + 1 + kChainBytes <= a.enc_bytes) chain_request(a.enc, nb, lane, ch);
-            }
+        if (CHAINED && last_tile) {  // a chained segment asks for the next block as soon as it knows where this one ends
+            const uint64_t nb = tile_base + uint64_t(kSlotBytes) * end_slot;
+            if (ch.more && nb + 1 + kChainBytes <= a.enc_bytes) chain_request(a.enc, nb, lane, ch);
         }
         // ---- the wait point of the tile: everything prefetched has landed — nothing has been stored yet,
         // so this is no wait for store acknowledgements ("+v": from here on the values are the asm's, not a
@@ -904,39 +886,47 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const w
         SECTION(pf, 8, "8_wait");
         uint64_t raw3w = raw3;
         asm volatile("" : "+v"(raw3w));
-        take_metas(hot_k, mr, nxt);
         if (CHAINED) asm volatile("" : "+v"(ch.sel), "+v"(ch.data.x), "+v"(ch.data.y), "+v"(ch.data.z), "+v"(ch.data.w));
-        // this tile's rows into their cells; the second halves of the large ones requested (same registers)
-#pragma unroll
-        for (uint32_t k = 0; k != kSPL; ++k) asm volatile("" : "+v"(rr.q[k]));
+        // the heads of this tile's cold codewords into their cells (the integers start 4 bytes in); the tails
+        // of the large ones requested: integers 6..13 into the same registers, 14 and 15 into one more each
+        uint32_t t3[kSPL];
 #pragma unroll
         for (uint32_t k = 0; k != kSPL; ++k)
-            if (t.need[k] != 0) *reinterpret_cast<u32x4*>(lds_rw + t.src2[k]) = rr.q[k];
+            if (t.need[k] != 0) {
+                *reinterpret_cast<u32x4*>(lds_rw + t.src2[k]) = hr.q[k];
+                t.src2[k] += 4;
+            }
         if (tile_big) {
 #pragma unroll
-            for (uint32_t k = 0; k != kSPL; ++k)
-                if (t.need[k] > 1u)
-                    rr.q[k] = __builtin_amdgcn_raw_buffer_load_b128(c.rs_dict, c.rows_base + 32 * (dd.meta_base + cur.s[k]) + 16, 0, 0);
+            for (uint32_t k = 0; k != kSPL; ++k) {
+                const uint32_t tail = c.tails_base + 32 * (dd.meta_base + cur.s[k]);
+                if (t.need[k] > 1u) hr.q[k] = __builtin_amdgcn_raw_buffer_load_b128(c.rs_dict, tail, 0, 0);
+                if (t.need[k] > 2u) t3[k] = __builtin_amdgcn_raw_buffer_load_b32(c.rs_dict, tail + 16, 0, 0);
+            }
         }
         expand_tile<ROUNDS, GROUPS>(t, plain, tile_wide, a.plus_one, produced, c.lds, c.scratch, rs_out, lane, pf, [&]() {
 #pragma unroll
-            for (uint32_t k = 0; k != kSPL; ++k) asm volatile("" : "+v"(rr.q[k]));
+            for (uint32_t k = 0; k != kSPL; ++k) asm volatile("" : "+v"(hr.q[k]), "+v"(t3[k]));
             if (tile_big) {
 #pragma unroll
-                for (uint32_t k = 0; k != kSPL; ++k)
-                    if (t.need[k] > 1u) *reinterpret_cast<u32x4*>(lds_rw + t.src2[k] + 16) = rr.q[k];
+                for (uint32_t k = 0; k != kSPL; ++k) {
+                    if (t.need[k] > 1u) *reinterpret_cast<u32x4*>(lds_rw + t.src2[k] + 12) = hr.q[k];
+                    if (t.need[k] > 2u) *reinterpret_cast<uint32_t*>(lds_rw + t.src2[k] + 28) = t3[k];
+                }
             }
             wave_lds_fence();
+            // ---- the next tile's metadata (its slots are already here): the hot codewords' from LDS, the cold
+            // ones' heads from L2 — requested before this tile's stores, so that the wait for them at the top of
+            // the next tile is no wait for the stores (vmcnt is one in-order counter for loads AND stores on
+            // gfx950). The last tile of a segment has no successor.
+            SECTION(pf, 3, "3_prefetch");
+            if (!last_tile) request_metas(c, dd.hot_base, hot_k, dd.meta_base, nxt, mr, hr);
         });
 
         SECTION(pf, 10, "10_tail");
         if (tile_slow)
             slow_stores<W>(c, t, slowb, a.plus_one, produced, n, a.enc + tile_base + uint64_t(kSPL * kSlotBytes) * lane, dd.hot_base,
                            hot_k, dd.meta_base, rs_out);
-        // the rows of the next tile's cold slots: the whole front end of the next tile lies between this
-        // request and the wait
-        SECTION(pf, 15, "10_rows");
-        if (!last_tile) request_rows(c, hot_k, dd.meta_base, nxt, rr);
         SECTION(pf, 5, "10_rotate");
         produced += t.total;
         carry = carry_out;
@@ -1172,10 +1162,9 @@ __device__ __forceinline__ void decode_bundle(const decode_args& a, const wave_c
         }
     }
     meta_regs mr;
-    row_regs rr;
-    request_metas(c, hot_base, hot_k, meta_base, cur, mr);
-    request_rows(c, hot_k, meta_base, cur, rr);
-    take_metas(hot_k, mr, cur);
+    head_regs hr;
+    request_metas(c, hot_base, hot_k, meta_base, cur, mr, hr);
+    take_metas(hot_k, mr, hr, cur);
 
     // ---- classification: as in decode_segment, the carries cut at every unit's first lane ----------
     tile_slots t;
@@ -1311,25 +1300,31 @@ __device__ __forceinline__ void decode_bundle(const decode_args& a, const wave_c
     uint32_t* const out = a.out + out0;
     uint32_t* const out_u = reinterpret_cast<uint32_t*>(uniform64(reinterpret_cast<uint64_t>(out)));
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out_u, 0, int(total * 4), 0x00020000);
-    // the rows into their cells; the second halves of the large ones behind the flag/delta phase
-#pragma unroll
-    for (uint32_t k = 0; k != kSPL; ++k) asm volatile("" : "+v"(rr.q[k]));
+    // the heads into their cells; the tails of the large ones behind the flag/delta phase (decode_segment)
+    uint32_t t3[kSPL];
 #pragma unroll
     for (uint32_t k = 0; k != kSPL; ++k)
-        if (t.need[k] != 0) *reinterpret_cast<u32x4*>(lds_rw + t.src2[k]) = rr.q[k];
+        if (t.need[k] != 0) {
+            *reinterpret_cast<u32x4*>(lds_rw + t.src2[k]) = hr.q[k];
+            t.src2[k] += 4;
+        }
     if (tile_big) {
 #pragma unroll
-        for (uint32_t k = 0; k != kSPL; ++k)
-            if (t.need[k] > 1u)
-                rr.q[k] = __builtin_amdgcn_raw_buffer_load_b128(c.rs_dict, c.rows_base + 32 * (meta_base + cur.s[k]) + 16, 0, 0);
+        for (uint32_t k = 0; k != kSPL; ++k) {
+            const uint32_t tail = c.tails_base + 32 * (meta_base + cur.s[k]);
+            if (t.need[k] > 1u) hr.q[k] = __builtin_amdgcn_raw_buffer_load_b128(c.rs_dict, tail, 0, 0);
+            if (t.need[k] > 2u) t3[k] = __builtin_amdgcn_raw_buffer_load_b32(c.rs_dict, tail + 16, 0, 0);
+        }
     }
     expand_tile<kRounds, kGroups>(t, false, tile_wide, a.plus_one, 0u, lds, scratch, rs_out, lane, pf, [&]() {
 #pragma unroll
-        for (uint32_t k = 0; k != kSPL; ++k) asm volatile("" : "+v"(rr.q[k]));
+        for (uint32_t k = 0; k != kSPL; ++k) asm volatile("" : "+v"(hr.q[k]), "+v"(t3[k]));
         if (tile_big) {
 #pragma unroll
-            for (uint32_t k = 0; k != kSPL; ++k)
-                if (t.need[k] > 1u) *reinterpret_cast<u32x4*>(lds_rw + t.src2[k] + 16) = rr.q[k];
+            for (uint32_t k = 0; k != kSPL; ++k) {
+                if (t.need[k] > 1u) *reinterpret_cast<u32x4*>(lds_rw + t.src2[k] + 12) = hr.q[k];
+                if (t.need[k] > 2u) *reinterpret_cast<uint32_t*>(lds_rw + t.src2[k] + 28) = t3[k];
+            }
         }
         wave_lds_fence();
     });
@@ -1399,7 +1394,7 @@ __device__ __forceinline__ void decode_unit_multi(const decode_args& a, const wa
 __device__ __forceinline__ decode_args own_scalars(const decode_args& k) {
     decode_args a = k;
     asm volatile("" : "+s"(a.dict.tables), "+s"(a.dict.lds_image), "+s"(a.dict.descs), "+s"(a.dict.tables_bytes),
-                 "+s"(a.dict.rows_base), "+s"(a.dict.goff_base), "+s"(a.dict.gtable_base), "+s"(a.dict.hot_words),
+                 "+s"(a.dict.heads_base), "+s"(a.dict.tails_base), "+s"(a.dict.goff_base), "+s"(a.dict.gtable_base), "+s"(a.dict.hot_words),
                  "+s"(a.dict.first.meta_base), "+s"(a.dict.first.hot_base), "+s"(a.dict.first.hot_k));
     asm volatile("" : "+s"(a.enc), "+s"(a.enc_bytes), "+s"(a.units), "+s"(a.n_units), "+s"(a.out),
                  "+s"(a.out_capacity), "+s"(a.end_off), "+s"(a.queue), "+s"(a.n_shards), "+s"(a.only_full));
@@ -1425,7 +1420,8 @@ __device__ __forceinline__ void decode_kernel_body(const decode_args& kernarg) {
     c.scratch = scratch;
     c.lane = lane;
     c.rs_dict = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.dict.tables), 0, int(a.dict.tables_bytes), 0x00020000);
-    c.rows_base = a.dict.rows_base;
+    c.heads_base = a.dict.heads_base;
+    c.tails_base = a.dict.tails_base;
     c.goff_base = a.dict.goff_base;
     c.gtable_base = a.dict.gtable_base;
     // Work queue. Every shard — the workgroups with the same blockIdx % n_shards: one XCD under

@@ -29,8 +29,8 @@ assert lib.dint_dict_create(kind, C.addressof(buf), len(dict_file), 0, C.byref(h
 prof = (C.c_ulonglong * 16)()
 WAVES = int(os.environ.get("WAVES", "4096"))
 stream = torch.cuda.current_stream(dev).cuda_stream
-names = {0: "outside (queue, exit)", 1: "classify", 2: "sizes + scans", 3: "metas of the next tile", 4: "flag/delta/rank tables",
-         5: "rotate + far prefetch", 7: "second halves of large rows", 8: "wait point + first halves", 9: "expand + stores", 10: "slow stores", 11: "segment prologue",
+names = {0: "outside (queue, exit)", 1: "classify", 2: "sizes + scans", 3: "metas + heads of the next tile", 4: "flag/delta/rank tables",
+         5: "rotate + far prefetch", 7: "tails land", 8: "wait point + heads land + tails requested", 9: "expand + stores", 10: "slow stores", 11: "segment prologue",
          12: "bundle front end", 13: "epilogue", 14: "queue ticket", 15: "rows of the next tile"}
 for it in range(4):
     assert lib.dint_decode_units(h, enc_dev.data_ptr(), enc.size, units_dev.data_ptr(), len(units), out_dev.data_ptr(),
