@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Decode-throughput benchmark of the MI355X DINT path (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]            # N > 1: starts one process per GPU itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step is one pass of the decode kernel over the rank's whole resident
@@ -18,38 +18,50 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
+WORKLOADS = {
+    # config 2 (Gov2-shaped: 25 M documents) and config 4 (ClueWeb09-shaped: 50 M documents,
+    # 1e10 postings over 8 GPUs = 1.25e9 per GPU)
+    "gov2": dict(universe=25_000_000, postings=1.0e9, replicate=5),
+    "clueweb": dict(universe=50_000_000, postings=1.25e9, replicate=1),
+}
+KERNEL_BY_TYPE = {"single_rect_dint": "decode_single_kernel", "single_packed_dint": "decode_single_kernel",
+                  "multi_packed_dint": "decode_multi_kernel"}
 
-def parse_args():
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)  # (the shader clock is still ramping for the first few launches)
-    ap.add_argument("--type", default="single_packed_dint",
-                    choices=["single_rect_dint", "single_packed_dint", "multi_packed_dint"])
-    ap.add_argument("--postings", type=float, default=1.0e9,
-                    help="postings encoded per GPU (weak scaling: fixed per GPU)")
-    ap.add_argument("--replicate", type=int, default=1,
-                    help="device-side copies of the encoded shard at distinct addresses (scale knob)")
-    ap.add_argument("--universe", type=int, default=25_000_000, help="documents (Gov2-shaped: 25M)")
+    ap.add_argument("--type", default="single_packed_dint", choices=sorted(KERNEL_BY_TYPE))
+    ap.add_argument("--workload", default="gov2", choices=sorted(WORKLOADS),
+                    help="gov2: universe 25M, 1e9 postings encoded per GPU, decoded x5 from distinct addresses (5e9 integers "
+                         "per step: SURVEY §8d config 2); clueweb: universe 50M, 1.25e9 postings per GPU (config 4 at 8 GPUs)")
+    ap.add_argument("--postings", type=float, default=None, help="postings encoded per GPU (weak scaling: fixed per GPU)")
+    ap.add_argument("--replicate", type=int, default=None,
+                    help="device-side copies of the encoded shard at distinct addresses, all decoded in one step")
+    ap.add_argument("--universe", type=int, default=None, help="documents")
     ap.add_argument("--unit-ints", type=int, default=8192)
     ap.add_argument("--dict-sample", type=float, default=2.0e7,
                     help="postings the DSF dictionary statistics are collected from")
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--cpu-seconds", type=float, default=10.0,
-                    help="summed decode time budget of the CPU baseline sample (0 = skip)")
+                    help="decode time budget of each leg of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--traffic-file", default=None,
+                    help="JSON written by tools/pmc_traffic.py from rocprofv3 --pmc passes of THIS command; without it "
+                         "roofline.traffic is null (HBM counters cannot be read from inside the run)")
     ap.add_argument("--no-verify", action="store_true", help="skip the full bit-exact output check")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def log(rank, *a):
@@ -57,37 +69,123 @@ def log(rank, *a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` on its own: start N fresh processes, one per GPU, and relay rank 0's line.
+    (This process has not touched the GPU; the children are new processes, not a re-exec.)"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(kind, dict_file, enc, list_byte_starts, seconds):
+    """The oracle's restatement of the reference decode, timed on this host: (i) one thread, per-list timing
+    summed exactly like vroom_env/decode.cpp:139-150; (ii) every core, the lists statically partitioned by
+    stream bytes, wall time. A bounded sample: each leg stops after about `seconds` of decode time."""
+    import threading
+
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle  # the CPU restatement, used here as the timed baseline only
+
+    od = oracle.OracleDict(kind, dict_file)
+    sec = ints = lists = passes = 0
+    while sec < seconds:
+        s1, i1, l1 = od.time_stream(enc, max_seconds=seconds - sec)
+        sec, ints, lists, passes = sec + s1, ints + i1, lists + l1, passes + 1
+    one = {"value": round(ints / sec / 1e6, 2), "unit": "M ints/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
+           "sample": f"{passes} pass(es) over the same encoded stream, {lists} list decodes ({ints} postings), per-list "
+                     f"timing summed as in vroom_env/decode.cpp:139-150, {sec:.1f}s of decode time"}
+    cores = len(os.sched_getaffinity(0))
+    bounds = [int(list_byte_starts[np.searchsorted(list_byte_starts, enc.size * k // cores)]) if k else 0 for k in range(cores)]
+    bounds.append(enc.size)
+    res = [None] * cores
+
+    def work(k):
+        a, b = bounds[k], bounds[k + 1]
+        res[k] = od.time_stream(enc[a:b], max_seconds=seconds) if b > a else (0.0, 0, 0)
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    wall = time.perf_counter() - t0
+    tot = sum(r[1] for r in res)
+    one["all_cores"] = {"value": round(tot / wall / 1e6, 2), "unit": "M ints/s", "cores": cores,
+                        "sample": f"{cores} threads, contiguous list ranges of equal stream bytes, {tot} postings in {wall:.1f}s wall"}
+    return one
+
+
 def main():
     args = parse_args()
-    rank = int(os.environ.get("RANK", "0"))
+    w = WORKLOADS[args.workload]
+    postings = int(args.postings if args.postings is not None else w["postings"])
+    R = max(1, args.replicate if args.replicate is not None else w["replicate"])
+    universe = args.universe if args.universe is not None else w["universe"]
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))  # before anything touches the GPU
+    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the decode path has no CPU fallback")
 
-    from dint_amd import device, host, sharding
+    import numpy as np
+    import torch
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    stub = os.environ.get("DINT_BENCH_STUB")  # tests only: a module that stands in for the device layer (tests/bench_stub.py)
+    if stub:
+        import importlib
+
+        device = importlib.import_module(stub)
+        backend, dev = "gloo", torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the decode path has no CPU fallback")
+        from dint_amd import device
+
+        torch.cuda.set_device(local_rank)
+        backend, dev = "nccl", torch.device("cuda", local_rank)
+    from dint_amd import host, sharding
+
     distributed = world > 1
     if distributed:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
 
     kind = host.KIND_BY_TYPE[args.type]
-    postings = int(args.postings)
     threads = max(1, host.default_threads() // world)
 
     # ---- set-up (untimed): collection shard, dictionary, encode, upload ----------
     t0 = time.time()
-    params = dict(universe=args.universe, seed=args.seed)
-    p = host.synth_params(**params)
+    p = host.synth_params(universe=universe, seed=args.seed)
     # The collection is `world * postings` postings; list lengths are drawn once
     # (same on every rank) and contiguous list ranges balanced by postings are
     # handed to the ranks (SURVEY §8e).
@@ -117,7 +215,6 @@ def main():
 
     d = device.Dictionary(kind, dict_file, device=local_rank)
     info = d.info()
-    R = max(1, args.replicate)
     n_ints = coll.num_postings * R
     enc_dev = torch.empty(enc.size * R, dtype=torch.uint8, device=dev)
     enc_one = torch.from_numpy(enc).to(dev)
@@ -132,25 +229,28 @@ def main():
     n_units = len(units_all)
     out_dev = torch.empty(n_ints, dtype=torch.int32, device=dev)
     end_dev = torch.zeros(n_units, dtype=torch.int64, device=dev)
-
-    log(rank, f"device buffers: enc {enc_dev.data_ptr():#x} out {out_dev.data_ptr():#x} units {units_dev.data_ptr():#x}")
+    log(rank, f"device buffers: enc {enc_dev.data_ptr():#x} ({enc_dev.data_ptr() % (2 << 20):#x} mod 2 MB) "
+              f"out {out_dev.data_ptr():#x} units {units_dev.data_ptr():#x}")
 
     def sync_all():
         if distributed:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
 
     # ---- warm-up ------------------------------------------------------------------
     for _ in range(args.warmup):
         d.decode_units(enc_dev, units_dev, n_units, out_dev, end_dev)
     sync_all()
 
-    # ---- timed region: exactly K steps ----------------------------------------------
+    # ---- timed region: exactly K steps (each returns the end offsets too, like the reference's decode) ----
     t_start = time.perf_counter()
     for _ in range(args.steps):
-        d.decode_units(enc_dev, units_dev, n_units, out_dev, None)
+        d.decode_units(enc_dev, units_dev, n_units, out_dev, end_dev)
     sync_all()
     elapsed = time.perf_counter() - t_start
+    # per-launch kernel time of the timed launches themselves: the event pairs the library recorded around them
+    kernel_ms = np.asarray(d.recent_kernel_ms(min(args.steps, 64)), dtype=np.float64)
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -161,61 +261,57 @@ def main():
     else:
         total_ints = n_ints
 
-    # ---- per-launch kernel time (HIP events on the launch stream) -------------------
-    kernel_ms = []
-    for _ in range(max(3, min(args.steps, 10))):
-        d.decode_units(enc_dev, units_dev, n_units, out_dev, None)
-        torch.cuda.synchronize(dev)
-        kernel_ms.append(d.last_kernel_ms())
-    kernel_ms_avg = float(np.mean(kernel_ms))
-
     # ---- correctness: bit-exact against the encoder's input -------------------------
     ends = end_dev.cpu().numpy().view(np.uint64)
     payload_bytes = int((ends - units_all["in_off"]).sum())
     bit_exact = None
     if not args.no_verify:
-        got = out_dev.cpu().numpy().view(np.uint32)
-        bit_exact = all(np.array_equal(got[r * coll.num_postings:(r + 1) * coll.num_postings], coll.gaps)
-                        for r in range(R))
+        bit_exact = True
+        for r in range(R):  # one replica at a time: the output is 4 bytes x 5e9 at the default size
+            got = out_dev[r * coll.num_postings:(r + 1) * coll.num_postings].cpu().numpy().view(np.uint32)
+            bit_exact = bit_exact and bool(np.array_equal(got, coll.gaps))
+            del got
         if distributed:
             ok = torch.tensor([1 if bit_exact else 0], dtype=torch.int32, device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             bit_exact = bool(ok.item())
         if not bit_exact:
             raise SystemExit("FATAL: decoded integers differ from the encoder's input")
-        del got
-
-    # ---- CPU baseline (rank 0, N=1 only): the oracle timed like vroom_env/decode.cpp ----
-    cpu = None
-    if rank == 0 and world == 1 and args.cpu_seconds > 0:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import oracle  # the CPU restatement, used here as the timed baseline only
-
-        od = oracle.OracleDict(kind, dict_file)
-        # whole passes over the stream (or a prefix of it, if one pass is longer than the budget)
-        # until about cpu_seconds of decode time have been summed
-        sec = ints = lists = passes = 0
-        while sec < args.cpu_seconds:
-            s1, i1, l1 = od.time_stream(enc, max_seconds=args.cpu_seconds - sec)
-            sec, ints, lists, passes = sec + s1, ints + i1, lists + l1, passes + 1
-        cpu = {
-            "value": round(ints / sec / 1e6, 2), "unit": "M ints/s", "cores": 1, "kind": "port",
-            "sample": f"{passes} pass(es) over the same encoded stream, {lists} list decodes ({ints} postings), "
-                      f"per-list timing summed as in vroom_env/decode.cpp:139-150, {sec:.1f}s of decode time",
-        }
 
     if rank == 0:
+        # ---- what the stream is made of (host pre-pass over one replica) -------------
+        st = d.stream_stats(enc)
+        slots = st.codewords + st.exceptions16 + st.exceptions32
+        stream = {
+            "ints_per_codeword": round(st.ints / max(1, slots), 3),
+            "exception_pct": round(100.0 * (st.exceptions16 + st.exceptions32) / max(1, slots), 4),
+            "exception32_pct": round(100.0 * st.exceptions32 / max(1, slots), 4),
+            "lds_hit_pct": round(100.0 * st.hot_codewords / max(1, st.codewords), 2),
+            "lds_hit_pct_of_ints": round(100.0 * st.hot_ints / max(1, st.ints), 2),
+        }
+        if kind == host.MULTI_PACKED:
+            stream["blocks_16bit_pct"] = round(100.0 * st.wide_blocks / max(1, st.wide_blocks + st.narrow_blocks), 2)
+
+        # ---- CPU baseline (N=1 only): the oracle timed like vroom_env/decode.cpp ------
+        cpu = None
+        if world == 1 and args.cpu_seconds > 0:
+            first = np.r_[True, units["list"][1:] != units["list"][:-1]]
+            # a list's header starts where the previous list's payload ended
+            prev_end = np.r_[np.uint64(0), ends[: len(units)][np.flatnonzero(np.r_[first[1:], True])][:-1]]
+            cpu = cpu_baseline(kind, dict_file, enc, prev_end.astype(np.int64), args.cpu_seconds)
+
         algo_bytes = 4 * n_ints + payload_bytes  # per launch, this rank
-        # HBM traffic per launch comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of
-        # this same command; tools/pmc_traffic.py stores bytes per decoded integer under profiles/.
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
-            with open(tfile) as f:
-                t = json.load(f)
-            if t.get("type") == args.type and t.get("postings_per_gpu") == n_ints:
-                traffic = round(t["hbm_bytes_per_launch"] / 1e9, 3)
-        achieved = algo_bytes / (kernel_ms_avg * 1e-3) / 1e9
+        traffic, traffic_note = None, "not measured in this process (rocprofv3 --pmc passes: tools/profile_round.sh)"
+        if args.traffic_file and os.path.exists(args.traffic_file):
+            with open(args.traffic_file) as f:
+                tf = json.load(f)
+            if tf.get("type") == args.type and tf.get("ints_per_launch") == n_ints:
+                traffic = {"write_gb": tf["write_gb"], "fetch_gb_raw": tf["fetch_gb_raw"],
+                           "fetch_gb_corrected": tf["fetch_gb_corrected"],
+                           "total_gb": round(tf["write_gb"] + tf["fetch_gb_corrected"], 3)}
+                traffic_note = tf.get("note", "")
+        k_mean = float(kernel_ms.mean())
+        achieved = algo_bytes / (k_mean * 1e-3) / 1e9
         value = total_ints * args.steps / elapsed / 1e6
         line = {
             "metric": f"M ints/sec decoded (vroom {args.type})",
@@ -232,14 +328,15 @@ def main():
             "data": "synthetic",
             "bit_exact": bit_exact,
             "config": {
-                "workload": f"{args.type} decode, DSF-65536-16 dictionary (hot set in LDS), Gov2-shaped synthetic "
-                            f"docIDs: universe {args.universe}, {postings} postings/GPU"
-                            + (f" x{R} device-side replicas" if R > 1 else ""),
-                "postings_per_gpu": n_ints,
+                "workload": f"{args.type} decode, DSF-65536-16 dictionary (hot set in LDS), {args.workload}-shaped synthetic "
+                            f"docIDs: universe {universe}, {postings} postings encoded per GPU"
+                            + (f", decoded x{R} per step from {R} device-side copies at distinct addresses" if R > 1 else ""),
+                "ints_per_gpu_per_step": n_ints,
                 "lists_per_gpu": int(np.count_nonzero(lens)) * R,
                 "units_per_gpu": n_units,
                 "unit_ints": args.unit_ints,
                 "bits_per_int": round(bpi, 3),
+                **stream,
                 "hot_codewords_in_lds": int(info.hot_entries),
                 "lds_bytes": int(info.lds_bytes),
                 "parallelism": f"list-range x{world}",
@@ -251,9 +348,12 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
-                "traffic_unit": "GB per launch (FETCH_SIZE + WRITE_SIZE, profiles/traffic.json)",
-                "kernel": "decode_single_kernel",
-                "kernel_ms": round(kernel_ms_avg, 4),
+                "traffic_note": traffic_note,
+                "kernel": KERNEL_BY_TYPE[args.type],
+                "kernel_ms": round(k_mean, 4),
+                "kernel_ms_min_median_max": [round(float(kernel_ms.min()), 4), round(float(np.median(kernel_ms)), 4),
+                                             round(float(kernel_ms.max()), 4)],
+                "kernel_launches_timed": int(kernel_ms.size),
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
             "cpu_baseline": cpu,

@@ -143,6 +143,9 @@ struct dint_dict {
     // host copies used by dint_index_stream
     std::vector<uint32_t> h_start;  // per dictionary first meta slot (+ end)
     std::vector<uint32_t> h_size;   // per meta slot
+    std::vector<uint32_t> h_hot_k;  // per dictionary: codewords below it have their integers in the LDS image
+    std::vector<uint8_t> h_slow;    // per meta slot: a slow entry (not on chip whatever its index)
+    uint64_t launches = 0;          // decode launches so far (slot = launch % kQueueSlots)
     // device buffers
     void* d_block = nullptr;  // one allocation: gmeta | rows | gtable | LDS image | descriptors
     uint32_t* d_image = nullptr;
@@ -156,7 +159,7 @@ struct dint_dict {
     bool no_bundles = false;  // DINT_NO_BUNDLES in the environment when the dictionary was created (diagnostic)
     // work-queue counters: one slot per in-flight launch, recycled round-robin
     // behind the event of the launch that used the slot last
-    static constexpr uint32_t kQueueSlots = 32;
+    static constexpr uint32_t kQueueSlots = 64;
     uint32_t* d_queues = nullptr;
     uint8_t* d_sched[kQueueSlots] = {};   // per slot: the bundle schedule of the launch (grow-only)
     size_t sched_cap[kQueueSlots] = {};
@@ -280,11 +283,14 @@ int upload_hot_set(dint_dict& dd, hot_layout const& lay) {
     dd.view.hot_words = uint32_t(lay.image.size());
     dd.view.first = lay.descs[0];
     dd.hot_entries = lay.hot_entries;
+    dd.h_hot_k.clear();
+    for (auto const& d : lay.descs) dd.h_hot_k.push_back(d.hot_k);
     return DINT_OK;
 }
 
 int stage_dictionary(dint_dict& dd, parsed_dict const& pd) {
     const size_t slots = pd.size.size();
+    dd.h_slow.assign(slots, 0);
     std::vector<uint32_t> heads(slots * 4, 0);   // per slot: metadata word, integers 0..5 as u16
     std::vector<uint16_t> tails(slots * 16, 0);  // per slot: integers 6..21 as u16
     std::vector<uint32_t> goff(slots, 0);
@@ -306,6 +312,7 @@ int stage_dictionary(dint_dict& dd, parsed_dict const& pd) {
             // the surplus through the slow path too)
             const uint32_t cells = pw <= 6 ? 1u : pw <= 14 ? 2u : 3u;
             heads[slot * 4] = ((sz - 1) << 24) | kMetaCold | (slow ? kMetaSlow : cells << 20);
+            if (slow) dd.h_slow[slot] = 1;
             goff[slot] = pd.off[slot];
             if (!slow) {
                 uint16_t* const h = reinterpret_cast<uint16_t*>(&heads[slot * 4 + 1]);
@@ -539,7 +546,7 @@ int dint_index_stream(const dint_dict* dd, const uint8_t* enc, size_t enc_bytes,
     const uint8_t* end = enc + enc_bytes;
     uint64_t out_pos = 0, lists = 0;
     const bool multi = dd->kind == DINT_DICT_MULTI_PACKED;
-    const uint32_t cut = unit_ints ? unit_ints : ~0u;
+    const uint32_t cut = unit_ints ? std::min<uint32_t>(unit_ints, DINT_MAX_UNIT_INTS) : DINT_MAX_UNIT_INTS;
 
     while (p != end) {
         uint32_t n, universe;
@@ -576,7 +583,8 @@ int dint_index_stream(const dint_dict* dd, const uint8_t* enc, size_t enc_bytes,
         } else {
             // one selector byte per 256 integers (vroom_env/dint_codecs.hpp:521-619)
             uint32_t done = 0;
-            const uint32_t blocks_per_unit = unit_ints ? std::max<uint32_t>(1, (unit_ints + kBlock - 1) / kBlock) : ~0u;
+            const uint32_t blocks_per_unit =
+                std::max<uint32_t>(1, (std::min<uint32_t>(unit_ints ? unit_ints : DINT_MAX_UNIT_INTS, DINT_MAX_UNIT_INTS)) / kBlock);
             uint32_t blocks_in_unit = 0;
             while (done < n) {
                 if (blocks_in_unit == blocks_per_unit) {
@@ -649,6 +657,7 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
     dint_dict* mut = const_cast<dint_dict*>(dd);
     std::lock_guard<std::mutex> lock(mut->launch_mutex);
     const uint32_t slot = mut->next_slot.fetch_add(1) % dint_dict::kQueueSlots;
+    mut->launches += 1;
     if (mut->slot_used[slot]) HIP_TRY(hipEventSynchronize(mut->slot_done[slot]));  // normally long complete
     a.queue = mut->d_queues + size_t(slot) * kQueueShards * kQueueStride;
     a.n_shards = std::min<uint32_t>(kQueueShards, grid);
@@ -1028,12 +1037,95 @@ int dint_last_kernel_ms(const dint_dict* dd, float* ms) {
     return DINT_OK;
 }
 
+int dint_recent_kernel_ms(const dint_dict* dd, float* ms, size_t max_n, size_t* n_out) {
+    if (!dd || (!ms && max_n) || !n_out) return DINT_ERR_ARG;
+    int last;
+    uint64_t launches;
+    {
+        std::lock_guard<std::mutex> lock(const_cast<dint_dict*>(dd)->launch_mutex);
+        last = dd->last_slot;
+        launches = dd->launches;
+    }
+    *n_out = 0;
+    if (last < 0) return DINT_OK;
+    const size_t have = size_t(std::min<uint64_t>(std::min<uint64_t>(launches, dint_dict::kQueueSlots), max_n));
+    for (size_t i = 0; i != have; ++i) {  // oldest first
+        const uint32_t slot = uint32_t((uint64_t(last) + dint_dict::kQueueSlots - (have - 1 - i)) % dint_dict::kQueueSlots);
+        HIP_TRY(hipEventSynchronize(dd->slot_stop[slot]));
+        HIP_TRY(hipEventElapsedTime(&ms[i], dd->slot_start[slot], dd->slot_stop[slot]));
+    }
+    *n_out = have;
+    return DINT_OK;
+}
+
+int dint_stream_stats_get(const dint_dict* dd, const uint8_t* enc, size_t enc_bytes, dint_stream_stats* st) {
+    if (!dd || (!enc && enc_bytes) || !st) return DINT_ERR_ARG;
+    *st = dint_stream_stats{};
+    const uint8_t* p = enc;
+    const uint8_t* end = enc + enc_bytes;
+    const bool multi = dd->kind == DINT_DICT_MULTI_PACKED;
+    auto codeword = [&](uint32_t d, uint32_t idx) -> uint32_t {  // -> integers it decodes to
+        const uint32_t slot = dd->h_start[d] + idx;
+        const uint32_t sz = dd->h_size[slot];
+        st->codewords += 1;
+        if (idx >= 2 && idx < kReserved) st->run_codewords += 1;
+        if (idx < dd->h_hot_k[d] && !dd->h_slow[slot]) {
+            st->hot_codewords += 1;
+            st->hot_ints += sz;
+        }
+        return sz;
+    };
+    while (p != end) {
+        uint32_t n, universe;
+        p = read_vbyte(p, end, &n);
+        if (p) p = read_vbyte(p, end, &universe);
+        if (!p) return DINT_ERR_FORMAT;
+        const uint8_t* const payload = p;
+        st->lists += 1;
+        st->ints += n;
+        uint32_t done = 0;
+        while (done < n) {
+            const uint32_t bsize = multi ? std::min<uint32_t>(kBlock, n - done) : n - done;
+            uint32_t d = 0;
+            bool narrow = false;
+            if (multi) {
+                if (p == end) return DINT_ERR_FORMAT;
+                const uint32_t sc = *p++;
+                if (sc >= 2 * kSelectors) return DINT_ERR_FORMAT;
+                narrow = sc >= kSelectors;
+                d = narrow ? sc - kSelectors : sc;
+                (narrow ? st->narrow_blocks : st->wide_blocks) += 1;
+            }
+            const uint32_t limit = dd->h_start[d + 1] - dd->h_start[d];
+            uint32_t i = 0;
+            while (i < bsize) {
+                if (end - p < (narrow ? 1 : 2)) return DINT_ERR_FORMAT;
+                const uint32_t idx = narrow ? *p : ld16(p);
+                if (idx >= 2) {
+                    if (idx >= limit) return DINT_ERR_FORMAT;
+                    i += codeword(d, idx);
+                    p += narrow ? 1 : 2;
+                } else {
+                    (idx == 1 ? st->exceptions32 : st->exceptions16) += 1;
+                    i += 1;
+                    p += (narrow ? 1 : 2) + (idx == 1 ? 4 : 2);
+                }
+                if (p > end) return DINT_ERR_FORMAT;
+            }
+            if (i != bsize && multi) return DINT_ERR_FORMAT;
+            done += bsize;
+        }
+        st->payload_bytes += uint64_t(p - payload);
+    }
+    return DINT_OK;
+}
+
 int dint_decode_list_host(const dint_dict* dd, const uint8_t* in, size_t in_bytes, uint32_t* out, size_t n,
                           size_t* consumed) {
     if (!dd || (!in && in_bytes) || (!out && n)) return DINT_ERR_ARG;
     if (consumed) *consumed = 0;
     if (n == 0) return DINT_OK;
-    if (in_bytes < 2 || n > 0xFFFFFFFFull) return DINT_ERR_ARG;
+    if (in_bytes < 2 || n > DINT_MAX_UNIT_INTS) return DINT_ERR_ARG;
     const size_t padded = in_bytes < 8 ? 8 : in_bytes;
     HIP_TRY(hipSetDevice(dd->device));
     uint8_t* d_enc = nullptr;

@@ -21,7 +21,8 @@ _LIB_PATH = os.environ.get("DINT_HIP_LIB") or os.path.join(_HERE, "libdint_hip.s
 ABI_SYMBOLS = (
     "dint_abi_version", "dint_strerror", "dint_last_hip_error", "dint_device_count",
     "dint_dict_create", "dint_dict_destroy", "dint_dict_info_get", "dint_index_stream", "dint_free",
-    "dint_decode_units", "dint_decode_list_host", "dint_last_kernel_ms",
+    "dint_decode_units", "dint_decode_list_host", "dint_last_kernel_ms", "dint_recent_kernel_ms",
+    "dint_stream_stats_get",
     "dint_index_posting_lists", "dint_decode_posting_blocks",
     "dint_query_index_create", "dint_query_index_destroy", "dint_and_queries",
 )
@@ -38,6 +39,12 @@ class DictInfo(C.Structure):
         ("entries", C.c_uint32), ("hot_entries", C.c_uint32), ("lds_bytes", C.c_uint32),
         ("table_words", C.c_uint32), ("compute_units", C.c_uint32),
     ]
+
+
+class StreamStats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in (
+        "lists", "ints", "payload_bytes", "codewords", "run_codewords", "exceptions16", "exceptions32",
+        "hot_codewords", "hot_ints", "wide_blocks", "narrow_blocks")]
 
 
 def _load():
@@ -64,6 +71,8 @@ def _load():
     lib.dint_decode_units.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, vp]
     lib.dint_decode_list_host.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
     lib.dint_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.dint_recent_kernel_ms.argtypes = [vp, vp, sz, C.POINTER(sz)]
+    lib.dint_stream_stats_get.argtypes = [vp, vp, sz, C.POINTER(StreamStats)]
     lib.dint_index_posting_lists.argtypes = [vp, sz, vp, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(u64)]
     lib.dint_decode_posting_blocks.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, sz, vp]
     lib.dint_query_index_create.argtypes = [vp, vp, sz, vp, sz, sz, C.POINTER(vp)]
@@ -161,6 +170,20 @@ class Dictionary:
         ms = C.c_float()
         _check(_lib.dint_last_kernel_ms(self._h, C.byref(ms)), "dint_last_kernel_ms")
         return ms.value
+
+    def recent_kernel_ms(self, max_n: int = 64) -> np.ndarray:
+        """Kernel times (ms) of the most recent launches, oldest first (from their own event pairs)."""
+        out = np.zeros(max_n, dtype=np.float32)
+        n = C.c_size_t()
+        _check(_lib.dint_recent_kernel_ms(self._h, out.ctypes.data, max_n, C.byref(n)), "dint_recent_kernel_ms")
+        return out[: n.value].copy()
+
+    def stream_stats(self, enc: np.ndarray) -> StreamStats:
+        """Host pre-pass: what the stream is made of (codewords, exceptions, on-chip share)."""
+        enc = np.ascontiguousarray(enc, dtype=np.uint8)
+        st = StreamStats()
+        _check(_lib.dint_stream_stats_get(self._h, enc.ctypes.data, enc.size, C.byref(st)), "dint_stream_stats_get")
+        return st
 
     def decode_list(self, enc: np.ndarray, offset: int, n: int):
         """The reference's Decoder::decode(dict, in, out, universe, n) call shape on host

@@ -25,7 +25,11 @@
 extern "C" {
 #endif
 
-#define DINT_ABI_VERSION 1
+#define DINT_ABI_VERSION 2
+
+/* A unit decodes to at most this many integers (the kernels address a unit's output with 32-bit byte
+ * offsets); dint_index_stream never cuts larger ones, dint_decode_units skips them. */
+#define DINT_MAX_UNIT_INTS (1u << 28)
 
 typedef enum dint_status {
     DINT_OK = 0,
@@ -88,6 +92,7 @@ int dint_dict_info_get(const dint_dict* dict, dint_dict_info* info);
  * list header, walks the codewords WITHOUT copying dictionary payloads, and
  * cuts each list into units of about `unit_ints` integers at codeword
  * boundaries (multi: at 256-integer block boundaries).
+ * unit_ints = 0: one unit per list (a list of more than DINT_MAX_UNIT_INTS integers is still cut).
  * Replaces: the per-list framing loop of vroom_env/decode.cpp:139-150.
  * `*units` is malloc'ed; release with dint_free. */
 int dint_index_stream(const dint_dict* dict, const uint8_t* enc, size_t enc_bytes,
@@ -114,8 +119,9 @@ int dint_decode_units(const dint_dict* dict, const uint8_t* d_enc, size_t enc_by
 
 /* Host-pointer convenience with the reference's call shape: decode ONE
  * sequence of n integers starting at in[0]; *consumed = bytes read. Uploads,
- * runs one unit on the device, downloads, synchronises. Correct for any n but
- * a single wavefront wide: batch through dint_decode_units for throughput.
+ * runs one unit on the device, downloads, synchronises. n <= DINT_MAX_UNIT_INTS
+ * (DINT_ERR_ARG beyond: index the stream and batch); a single wavefront wide:
+ * batch through dint_decode_units for throughput.
  * Replaces: Coder::decode(dict, in, out, universe, n) at vroom_env/decode.cpp:143. */
 int dint_decode_list_host(const dint_dict* dict, const uint8_t* in, size_t in_bytes,
                           uint32_t* out, size_t n, size_t* consumed);
@@ -179,10 +185,29 @@ void dint_query_index_destroy(dint_query_index* qi);
 int dint_and_queries(dint_query_index* qi, const uint32_t* terms, const uint64_t* query_offsets,
                      size_t n_queries, uint64_t* counts, void* stream);
 
-/* Sum of per-kernel device time (ms) between the two events the library
- * records around the decode kernel of the most recent dint_decode_units on
- * this dictionary; valid after the stream has been synchronised. */
+/* Device time (ms) between the two events the library records around the decode kernel of the most
+ * recent dint_decode_units on this dictionary (one event pair per in-flight launch: launches on
+ * different streams do not disturb each other's); synchronises that launch. */
 int dint_last_kernel_ms(const dint_dict* dict, float* ms);
+
+/* The same for the most recent launches, oldest first: up to max_n of the last 64 (the library keeps
+ * that many event pairs); *n = how many were written. Synchronises them. What bench.py reports its
+ * per-launch kernel time from: the events of the timed launches themselves. */
+int dint_recent_kernel_ms(const dint_dict* dict, float* ms, size_t max_n, size_t* n);
+
+/* What a vroom stream is made of, by the dictionary's device layout (host pre-pass, like
+ * dint_index_stream): codewords, exceptions, how many codewords find their integers on chip. */
+typedef struct dint_stream_stats {
+    uint64_t lists, ints, payload_bytes;
+    uint64_t codewords;        /* dictionary codewords (runs included), exceptions not */
+    uint64_t run_codewords;
+    uint64_t exceptions16, exceptions32;
+    uint64_t hot_codewords;    /* dictionary codewords whose integers are in the LDS image (runs included) */
+    uint64_t hot_ints;         /* integers they decode to */
+    uint64_t wide_blocks;      /* multi: blocks of 16-bit slots; narrow_blocks: of 8-bit slots */
+    uint64_t narrow_blocks;
+} dint_stream_stats;
+int dint_stream_stats_get(const dint_dict* dict, const uint8_t* enc, size_t enc_bytes, dint_stream_stats* out);
 
 #ifdef __cplusplus
 }

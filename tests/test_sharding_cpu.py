@@ -87,3 +87,23 @@ def test_two_ranks_on_gloo(tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
     assert all("ok" in o for o in outs)
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` (no torchrun) starts two fresh processes, which rendezvous, shard the lists
+    and reduce — on CPU over gloo, with the device layer stubbed at the test level (tests/bench_stub.py)."""
+    import json
+
+    env = dict(os.environ, DINT_BENCH_STUB="bench_stub", PYTHONPATH=os.path.join(ROOT, "tests"))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--postings", "200000", "--replicate", "2", "--universe", "300000", "--dict-sample", "100000",
+                        "--cpu-seconds", "0", "--no-verify"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["parallelism"] == "list-range x2"
+    assert line["value"] > 0 and line["roofline"]["traffic"] is None
