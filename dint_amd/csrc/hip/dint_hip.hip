@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <mutex>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1035,6 +1036,63 @@ int dint_last_kernel_ms(const dint_dict* dd, float* ms) {
     HIP_TRY(hipEventSynchronize(dd->slot_stop[slot]));
     HIP_TRY(hipEventElapsedTime(ms, dd->slot_start[slot], dd->slot_stop[slot]));
     return DINT_OK;
+}
+
+int dint_decode_block_host(const dint_dict* dd, const uint8_t* in, size_t in_bytes, uint32_t* out, uint32_t sum_of_values,
+                           size_t n, size_t* consumed) {
+    if (!dd || (!in && in_bytes) || (!out && n)) return DINT_ERR_ARG;
+    if (consumed) *consumed = 0;
+    if (n == 0) return DINT_OK;
+    if (n > kBlock || in_bytes < 1) return DINT_ERR_ARG;
+    if (n == kBlock) return dint_decode_list_host(dd, in, in_bytes, out, n, consumed);  // one unit of one block
+    // a short block: binary interpolative, one lane of the tails kernel
+    const size_t padded = in_bytes + 8;  // the bit reader fetches whole words
+    HIP_TRY(hipSetDevice(dd->device));
+    uint8_t* d_in = nullptr;
+    uint8_t* d_ws = nullptr;  // [block_ref][docs_end u64][end u64][tails u32][n_tails u32][out u32 x 256]
+    int st = DINT_OK;
+    auto cleanup = [&] {
+        if (d_in) (void)hipFree(d_in);
+        if (d_ws) (void)hipFree(d_ws);
+    };
+#define TRY_OR_CLEAN(call)            \
+    do {                              \
+        if (!hip_ok((call), #call)) { \
+            cleanup();                \
+            return DINT_ERR_HIP;      \
+        }                             \
+    } while (0)
+    TRY_OR_CLEAN(hipMalloc(&d_in, padded));
+    TRY_OR_CLEAN(hipMemset(d_in, 0, padded));
+    TRY_OR_CLEAN(hipMemcpy(d_in, in, in_bytes, hipMemcpyHostToDevice));
+    struct {
+        dint_block_ref ref;
+        uint64_t docs_end, end;
+        uint32_t tail, n_tails;
+    } h{};
+    const bool vbyte_sum = sum_of_values == 0xFFFFFFFFu;
+    h.ref = dint_block_ref{0, 0, uint32_t(n), 0, uint32_t(sum_of_values + uint32_t(n - 1)), 0};  // max - base - (n - 1) = the sum
+    h.n_tails = 1;
+    TRY_OR_CLEAN(hipMalloc(&d_ws, sizeof h + kBlock * 4));
+    TRY_OR_CLEAN(hipMemcpy(d_ws, &h, sizeof h, hipMemcpyHostToDevice));
+    auto* d_ref = reinterpret_cast<dint_block_ref*>(d_ws);
+    auto* d_docs_end = reinterpret_cast<uint64_t*>(d_ws + offsetof(decltype(h), docs_end));
+    auto* d_end = reinterpret_cast<uint64_t*>(d_ws + offsetof(decltype(h), end));
+    auto* d_tail = reinterpret_cast<uint32_t*>(d_ws + offsetof(decltype(h), tail));
+    auto* d_n_tails = reinterpret_cast<uint32_t*>(d_ws + offsetof(decltype(h), n_tails));
+    auto* d_out = reinterpret_cast<uint32_t*>(d_ws + sizeof h);
+    hipLaunchKernelGGL(interpolative_tails_kernel, dim3(1), dim3(64), kTailLdsBytes, nullptr, d_in, uint64_t(padded), d_ref,
+                       vbyte_sum ? d_docs_end : static_cast<uint64_t*>(nullptr), d_tail, d_n_tails, d_out, uint64_t(kBlock),
+                       d_end, 0u);
+    TRY_OR_CLEAN(hipGetLastError());
+    TRY_OR_CLEAN(hipDeviceSynchronize());
+    uint64_t end_off = 0;
+    TRY_OR_CLEAN(hipMemcpy(out, d_out, n * 4, hipMemcpyDeviceToHost));
+    TRY_OR_CLEAN(hipMemcpy(&end_off, d_end, 8, hipMemcpyDeviceToHost));
+    if (consumed) *consumed = size_t(end_off);
+#undef TRY_OR_CLEAN
+    cleanup();
+    return st;
 }
 
 int dint_recent_kernel_ms(const dint_dict* dd, float* ms, size_t max_n, size_t* n_out) {

@@ -26,6 +26,7 @@
 #include "dint_hip.h"
 #include "dictionaries.hpp"
 #include "encoders.hpp"
+#include "posting_list.hpp"
 
 namespace dint {
 
@@ -138,5 +139,42 @@ struct multi_opt_dint_device : multi_opt_dint {
         return detail::decode_list(dict, in, in_end, out, n);
     }
 };
+
+// ---- in-index block Coders (reference include/dint/dint_codecs.hpp:9-19, :269-274, :460-510) ----
+// The statics a dict_posting_list<Dictionary, Coder>-shaped caller uses: block_size, overflow,
+// encode(builder, in, sum_of_values, n, out) (CPU, posting_list.hpp) and
+// decode(dict, in, out, sum_of_values, n) -> in_end, which goes through dint_decode_block_host: full
+// blocks to the DINT kernels, short ones to the interpolative kernel. `overflow` is kept for callers
+// that size their buffers with it (dict_posting_list.hpp:104-105); the device path writes exactly n
+// integers and needs neither the extra words nor a zeroed buffer.
+namespace detail {
+template <typename Dictionary>
+uint8_t const* decode_block(Dictionary const& dict, uint8_t const* in, uint8_t const* in_end, uint32_t* out,
+                            uint32_t sum_of_values, size_t n) {
+    size_t consumed = 0;
+    check(dint_decode_block_host(dict.handle(), in, size_t(in_end - in), out, sum_of_values, n, &consumed),
+          "dint_decode_block_host");
+    return in + consumed;
+}
+}  // namespace detail
+
+template <typename HostBlockCoder>
+struct dint_block_device : HostBlockCoder {
+    static const uint64_t block_size = kBlockSize;
+    static const uint64_t overflow = 256;  // dint_block::overflow
+    // the reference's shape: assumes the bytes a block can occupy are readable behind `in` (true inside an
+    // index buffer; for the last block of a mapped file use the bounded overload)
+    template <typename Dictionary>
+    static uint8_t const* decode(Dictionary const& dict, uint8_t const* in, uint32_t* out, uint32_t sum_of_values, size_t n) {
+        return detail::decode_block(dict, in, in + detail::worst_case_bytes(n), out, sum_of_values, n);
+    }
+    template <typename Dictionary>
+    static uint8_t const* decode(Dictionary const& dict, uint8_t const* in, uint8_t const* in_end, uint32_t* out,
+                                 uint32_t sum_of_values, size_t n) {
+        return detail::decode_block(dict, in, in_end, out, sum_of_values, n);
+    }
+};
+using opt_dint_single_dict_block_device = dint_block_device<opt_dint_single_dict_block>;  // dint_codecs.hpp:141-283
+using opt_dint_multi_dict_block_device = dint_block_device<opt_dint_multi_dict_block>;    // :285-510
 
 }  // namespace dint

@@ -23,7 +23,7 @@ ABI_SYMBOLS = (
     "dint_dict_create", "dint_dict_destroy", "dint_dict_info_get", "dint_index_stream", "dint_free",
     "dint_decode_units", "dint_decode_list_host", "dint_last_kernel_ms", "dint_recent_kernel_ms",
     "dint_stream_stats_get",
-    "dint_index_posting_lists", "dint_decode_posting_blocks",
+    "dint_decode_block_host", "dint_index_posting_lists", "dint_decode_posting_blocks",
     "dint_query_index_create", "dint_query_index_destroy", "dint_and_queries",
 )
 
@@ -73,6 +73,7 @@ def _load():
     lib.dint_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.dint_recent_kernel_ms.argtypes = [vp, vp, sz, C.POINTER(sz)]
     lib.dint_stream_stats_get.argtypes = [vp, vp, sz, C.POINTER(StreamStats)]
+    lib.dint_decode_block_host.argtypes = [vp, vp, sz, vp, u32, sz, C.POINTER(sz)]
     lib.dint_index_posting_lists.argtypes = [vp, sz, vp, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(u64)]
     lib.dint_decode_posting_blocks.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, sz, vp]
     lib.dint_query_index_create.argtypes = [vp, vp, sz, vp, sz, sz, C.POINTER(vp)]
@@ -194,6 +195,17 @@ class Dictionary:
         _check(_lib.dint_decode_list_host(self._h, enc.ctypes.data + offset, enc.size - offset, out.ctypes.data, n,
                                           C.byref(consumed)), "dint_decode_list_host")
         return out, consumed.value
+
+
+def decode_block(dictionary: "Dictionary", buf: np.ndarray, offset: int, sum_of_values: int, n: int):
+    """The reference's in-index block Coder call, Coder::decode(dict, in, out, sum_of_values, n), on host
+    memory -> (out[0:n], bytes consumed)."""
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    out = np.empty(n, dtype=np.uint32)
+    consumed = C.c_size_t()
+    _check(_lib.dint_decode_block_host(dictionary._h, buf.ctypes.data + offset, buf.size - offset, out.ctypes.data,
+                                       sum_of_values & 0xFFFFFFFF, n, C.byref(consumed)), "dint_decode_block_host")
+    return out, consumed.value
 
 
 def index_posting_lists(index: np.ndarray, list_offsets: np.ndarray):

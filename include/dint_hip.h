@@ -128,6 +128,22 @@ int dint_decode_list_host(const dint_dict* dict, const uint8_t* in, size_t in_by
 
 /* ---- in-index path: posting lists in the dict_posting_list layout --------------------------- */
 
+/* Host-pointer call with the reference's in-index BLOCK Coder shape: decode ONE block of n <= 256
+ * integers starting at in[0]; *consumed = bytes read. n == 256: a DINT block — 16-bit codewords
+ * (single dictionaries), or a selector byte and 16- / 8-bit codewords (multi) — through the DINT
+ * kernels; n < 256: binary interpolative, `sum_of_values` being the sum of the block's integers or
+ * 0xFFFFFFFF for "a vbyte of it comes first" (what the reference passes for freqs blocks), through
+ * the interpolative kernel. Uploads, runs one block on the device, downloads, synchronises: the
+ * reference's granularity, one block per call — batch through dint_decode_posting_blocks for
+ * throughput. Nothing past out[n - 1] is written and `out` need not be zeroed (the reference needs
+ * both: block_size + overflow zeroed words, dict_posting_list.hpp:104-105, :296).
+ * Replaces: dint_block::decode / opt_dint_single_dict_block::decode /
+ *           opt_dint_multi_dict_block::decode (include/dint/dint_codecs.hpp:13-49, :269-274,
+ *           :460-510) and interpolative_block::decode (include/ds2i/block_codecs.hpp:130-150), as
+ *           called from dict_posting_list.hpp:298-301 and :313-315. */
+int dint_decode_block_host(const dint_dict* dict, const uint8_t* in, size_t in_bytes, uint32_t* out,
+                           uint32_t sum_of_values, size_t n, size_t* consumed);
+
 /* One 256-posting block (the last block of a list may be shorter) of a posting list laid out as
  * reference include/dint/dict_posting_list.hpp:10-56:
  *   vbyte(n) | u32 block_max[B] | u32 block_endpoint[B-1] | { docs part, freqs part } x B

@@ -1,0 +1,154 @@
+// A dict_posting_list<Dictionary, Coder>::document_enumerator-shaped caller over the device block Coders:
+// walks one posting list block by block exactly as the reference does (include/dint/dict_posting_list.hpp:
+// 90-107 constructor, :284-309 decode_docs_block, :311-318 decode_freqs_block, :111-124 next) — Coder::block_size
+// to cut the blocks, Coder::decode(*docs_dict, block_data, buf, max - base - (size - 1), size) returning where
+// the freqs part begins, Coder::decode(*freqs_dict, ...) with sum_of_values = -1 — and compares every
+// (docid, freq) with the expected arrays. Own code: only the call sequence is the reference's.
+// usage: block_walker <kind 1|2> <docs dict> <freqs dict> <list bytes> <docids u32> <freqs u32>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <vector>
+
+#include "dint/coders.hpp"
+#include "dint/vbyte.hpp"
+
+template <typename T>
+std::vector<T> slurp(const char* path) {
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    std::vector<T> v(size_t(f.tellg()) / sizeof(T));
+    f.seekg(0);
+    f.read(reinterpret_cast<char*>(v.data()), std::streamsize(v.size() * sizeof(T)));
+    return v;
+}
+
+template <typename Dictionary, typename Coder>
+class enumerator {
+public:
+    enumerator(Dictionary const* docs_dict, Dictionary const* freqs_dict, uint8_t const* data, uint8_t const* data_end)
+        : m_end(data_end), m_docs_dict(docs_dict), m_freqs_dict(freqs_dict) {
+        m_base = dint::vbyte::read(data, data_end, &m_n);
+        m_blocks = (m_n + Coder::block_size - 1) / Coder::block_size;
+        m_block_maxs = m_base;
+        m_block_endpoints = m_block_maxs + 4 * m_blocks;
+        m_blocks_data = m_block_endpoints + 4 * (m_blocks - 1);
+        // (poisoned, not zeroed: the device Coders must not depend on the reference's std::fill)
+        m_docs_buf.assign(Coder::block_size + Coder::overflow, 0xDEADBEEFu);
+        m_freqs_buf.assign(Coder::block_size + Coder::overflow, 0xDEADBEEFu);
+        decode_docs_block(0);
+    }
+    uint64_t size() const { return m_n; }
+    uint64_t docid() const { return m_cur_docid; }
+    uint64_t freq() {
+        if (!m_freqs_decoded) decode_freqs_block();
+        return m_freqs_buf[m_pos_in_block] + 1;
+    }
+    bool next() {  // false: past the end
+        ++m_pos_in_block;
+        if (m_pos_in_block == m_cur_block_size) {
+            if (m_cur_block + 1 == m_blocks) return false;
+            decode_docs_block(m_cur_block + 1);
+        } else {
+            m_cur_docid += m_docs_buf[m_pos_in_block] + 1;
+        }
+        return true;
+    }
+    bool poisoned() const {  // the overflow area: never written by the device Coders
+        for (size_t i = Coder::block_size; i != m_docs_buf.size(); ++i)
+            if (m_docs_buf[i] != 0xDEADBEEFu || m_freqs_buf[i] != 0xDEADBEEFu) return false;
+        return true;
+    }
+
+private:
+    uint32_t u32_at(uint8_t const* p, uint64_t i) const {
+        uint32_t v;
+        std::memcpy(&v, p + 4 * i, 4);
+        return v;
+    }
+    void decode_docs_block(uint64_t block) {
+        const uint32_t endpoint = block ? u32_at(m_block_endpoints, block - 1) : 0;
+        uint8_t const* block_data = m_blocks_data + endpoint;
+        m_cur_block_size = ((block + 1) * Coder::block_size <= m_n) ? uint32_t(Coder::block_size) : uint32_t(m_n % Coder::block_size);
+        const uint32_t cur_base = (block ? u32_at(m_block_maxs, block - 1) : uint32_t(-1)) + 1;
+        const uint32_t cur_max = u32_at(m_block_maxs, block);
+        m_freqs_block_data = Coder::decode(*m_docs_dict, block_data, m_end, m_docs_buf.data(),
+                                           cur_max - cur_base - (m_cur_block_size - 1), m_cur_block_size);
+        m_docs_buf[0] += cur_base;
+        m_cur_block = block;
+        m_pos_in_block = 0;
+        m_cur_docid = m_docs_buf[0];
+        m_freqs_decoded = false;
+    }
+    void decode_freqs_block() {
+        Coder::decode(*m_freqs_dict, m_freqs_block_data, m_end, m_freqs_buf.data(), uint32_t(-1), m_cur_block_size);
+        m_freqs_decoded = true;
+    }
+
+    uint32_t m_n = 0;
+    uint8_t const* m_base;
+    uint8_t const* m_end;
+    uint64_t m_blocks;
+    uint8_t const* m_block_maxs;
+    uint8_t const* m_block_endpoints;
+    uint8_t const* m_blocks_data;
+    Dictionary const* m_docs_dict;
+    Dictionary const* m_freqs_dict;
+    uint64_t m_cur_block = 0;
+    uint32_t m_pos_in_block = 0, m_cur_block_size = 0;
+    uint64_t m_cur_docid = 0;
+    uint8_t const* m_freqs_block_data = nullptr;
+    bool m_freqs_decoded = false;
+    std::vector<uint32_t> m_docs_buf, m_freqs_buf;
+};
+
+template <typename Dictionary, typename Coder>
+int run(char** argv) {
+    auto docs_file = slurp<uint8_t>(argv[2]), freqs_file = slurp<uint8_t>(argv[3]), list = slurp<uint8_t>(argv[4]);
+    auto want_docs = slurp<uint32_t>(argv[5]), want_freqs = slurp<uint32_t>(argv[6]);
+    static_assert(Coder::block_size == 256 && Coder::overflow == 256, "the reference's statics");
+    typename Dictionary::builder db, fb;
+    db.load(docs_file);
+    fb.load(freqs_file);
+    Dictionary docs_dict, freqs_dict;
+    db.build(docs_dict);
+    fb.build(freqs_dict);
+    list.resize(list.size() + 16, 0);
+    enumerator<Dictionary, Coder> e(&docs_dict, &freqs_dict, list.data(), list.data() + list.size());
+    if (e.size() != want_docs.size()) {
+        std::cerr << "list holds " << e.size() << " postings, expected " << want_docs.size() << "\n";
+        return 1;
+    }
+    for (size_t i = 0; i != want_docs.size(); ++i) {
+        if (e.docid() != want_docs[i] || e.freq() != want_freqs[i]) {
+            std::cerr << "posting " << i << ": (" << e.docid() << ", " << e.freq() << ") expected (" << want_docs[i] << ", "
+                      << want_freqs[i] << ")\n";
+            return 1;
+        }
+        if (!e.poisoned()) {
+            std::cerr << "posting " << i << ": the decoder wrote past the block\n";
+            return 1;
+        }
+        const bool more = e.next();
+        if (more != (i + 1 != want_docs.size())) {
+            std::cerr << "next() at posting " << i << " returned " << more << "\n";
+            return 1;
+        }
+    }
+    std::cout << "ok\n";
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc != 7) return 2;
+    try {
+        switch (std::atoi(argv[1])) {
+            case 1: return run<dint::single_dictionary_packed_type, dint::opt_dint_single_dict_block_device>(argv);
+            case 2: return run<dint::multi_dictionary_packed_type, dint::opt_dint_multi_dict_block_device>(argv);
+        }
+    } catch (std::exception const& ex) {
+        std::cerr << "exception: " << ex.what() << "\n";
+        return 1;
+    }
+    return 2;
+}

@@ -50,3 +50,75 @@ def test_decode_cli_reports_the_reference_keys(small_corpus, tmp_path, kind):
     assert int(line["num_integers"]) == small_corpus.coll.num_postings
     assert int(line["num_sequences"]) == np.count_nonzero(small_corpus.coll.lens)
     assert line["type"] == TYPES[kind] and int(line["ints_x_sec"]) > 0
+
+
+@pytest.fixture(scope="module")
+def walker_binary(tmp_path_factory):
+    exe = tmp_path_factory.mktemp("cpp") / "block_walker"
+    subprocess.run(["g++", "-O2", "-std=c++17", f"-I{ROOT}/include", f"-I{ROOT}/dint_amd/csrc/host",
+                    os.path.join(ROOT, "tests", "cpp", "block_walker.cpp"), "-o", str(exe),
+                    f"-L{ROOT}/dint_amd", "-ldint_hip", f"-Wl,-rpath,{ROOT}/dint_amd"], check=True)
+    return str(exe)
+
+
+@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
+def test_block_coder_under_a_posting_list_walker(walker_binary, small_corpus, tmp_path, kind):
+    """The device block Coders instantiate under a dict_posting_list-shaped enumerator (tests/cpp/block_walker.cpp):
+    full blocks and an interpolative tail, docs with their sum_of_values hint, freqs with -1; every posting equals
+    the oracle's document_enumerator walk and the builder's input."""
+    import oracle
+    from test_index_cpu import get_index
+
+    ix = get_index(small_corpus, kind)
+    od, of = oracle.OracleDict(kind, ix.docs_dict), oracle.OracleDict(kind, ix.freqs_dict)
+    # lists with several full blocks and a tail, a pure tail (< 256), and an exact multiple of 256 if there is one
+    lens = np.asarray(ix.lens)
+    picks = [int(np.flatnonzero((lens > 600) & (lens % 256 != 0))[0]), int(np.flatnonzero((lens > 3) & (lens < 256))[0])]
+    exact = np.flatnonzero((lens >= 256) & (lens % 256 == 0))
+    if len(exact):
+        picks.append(int(exact[0]))
+    (tmp_path / "docs.dict").write_bytes(ix.docs_dict)
+    (tmp_path / "freqs.dict").write_bytes(ix.freqs_dict)
+    for i in picks:
+        lo, hi = int(ix.offsets[i]), int(ix.offsets[i + 1])
+        d, f = oracle.posting_list_decode(od, of, ix.bytes, lo)
+        a, b = int(ix.bounds[i]), int(ix.bounds[i + 1])
+        assert np.array_equal(d, ix.docids[a:b]) and np.array_equal(f, ix.freqs[a:b])
+        ix.bytes[lo:hi].tofile(tmp_path / "list.bin")
+        d.astype(np.uint32).tofile(tmp_path / "docids.bin")
+        f.astype(np.uint32).tofile(tmp_path / "freqs.bin")
+        r = subprocess.run([walker_binary, str(kind), str(tmp_path / "docs.dict"), str(tmp_path / "freqs.dict"),
+                            str(tmp_path / "list.bin"), str(tmp_path / "docids.bin"), str(tmp_path / "freqs.bin")],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and r.stdout.strip() == "ok", f"list {i} (n={lens[i]}): " + r.stdout + r.stderr
+
+
+def test_decode_block_host_call_shape(small_corpus):
+    """dint_decode_block_host directly: consumed bytes are the block's bytes, for docs (sum hint) and freqs (-1) parts."""
+    from dint_amd import device
+    from test_index_cpu import get_index
+
+    kind = host.SINGLE_PACKED
+    ix = get_index(small_corpus, kind)
+    blocks, _ = device.index_posting_lists(ix.bytes, ix.offsets)
+    dd, fd = device.Dictionary(kind, ix.docs_dict), device.Dictionary(kind, ix.freqs_dict)
+    padded = np.concatenate([ix.bytes, np.zeros(16, np.uint8)])
+    seen = set()
+    for b in range(len(blocks)):
+        n = int(blocks["n"][b])
+        key = (n == 256, n < 16)
+        if key in seen and len(seen) >= 3:
+            continue
+        seen.add(key)
+        at = int(blocks["in_off"][b])
+        gaps_sum = (int(blocks["max"][b]) - int(blocks["base"][b]) - (n - 1)) & 0xFFFFFFFF
+        docs, used = device.decode_block(dd, padded, at, gaps_sum, n)
+        lo = int(blocks["out_off"][b])
+        want = ix.docids[lo:lo + n].astype(np.int64)
+        gaps = np.diff(np.r_[int(blocks["base"][b]) - 1, want]) - 1
+        assert np.array_equal(docs, gaps.astype(np.uint32))
+        freqs, used_f = device.decode_block(fd, padded, at + used, 0xFFFFFFFF, n)
+        assert np.array_equal(freqs + 1, ix.freqs[lo:lo + n])
+        nxt = int(blocks["in_off"][b + 1]) if b + 1 < len(blocks) and blocks["list"][b + 1] == blocks["list"][b] else None
+        if nxt is not None:
+            assert at + used + used_f == nxt
