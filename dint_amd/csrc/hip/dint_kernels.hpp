@@ -87,7 +87,10 @@ constexpr uint32_t kProfWords = 16;
 constexpr uint32_t kProfWords = 0;
 #endif
 constexpr uint32_t kScratchWords = kFwWords + kDeltaWords + kStageWords + kProfWords;
-constexpr uint32_t kClassTableWords = 328;            // slot classification table: 648 u16 rows, padded
+constexpr uint32_t kClassTableWords = 328 + 24;       // slot classification table: 648 u16 rows, padded; then the (up to 6)
+                                                      // dictionaries' descriptors, 4 words each (a block's selector byte
+                                                      // picks one: an LDS read instead of a trip to L2 per block)
+constexpr uint32_t kDescWordAt = 328;
 constexpr uint32_t kHotImageWords = kLdsWords - kClassTableWords - kWavesPerBlock * kScratchWords;
 constexpr uint32_t kZeroHalves = 256;                 // longest run codeword, in u16
 // metadata word of a codeword: (size - 1) << 24 | kMetaCold | kMetaSlow | cells << 20 | LDS byte offset
@@ -217,19 +220,19 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// kSPL consecutive W-bit slots of one lane (W = 16: 8 bytes, W = 8: 4 bytes) from an
+// kSPL consecutive slots of one lane (16-bit slots: 8 bytes; `narrow`, 8-bit slots: 4 bytes) from an
 // arbitrary byte address. `tile_byte` is the (wave-uniform) offset of the tile's
 // first slot: when the whole tile lies inside the buffer — every tile but the stream's last —
 // this is one plain load whose result nothing touches until the tile is unpacked, two tiles
 // later. Otherwise it never reads past the buffer: the tail lanes load the final bytes and
 // shift (bytes past the end read as zero), which waits for the data on the spot.
-template <int W>
-__device__ __forceinline__ uint64_t load_lane_slots(const uint8_t* enc, uint64_t tile_byte, uint32_t lane,
+// (`narrow` is a compile-time constant in the single-dictionary kernel and wave-uniform in the multi one.)
+__device__ __forceinline__ uint64_t load_lane_slots(bool narrow, const uint8_t* enc, uint64_t tile_byte, uint32_t lane,
                                                     uint64_t enc_bytes) {
-    constexpr uint32_t kBytes = kSPL * W / 8;
+    const uint32_t kBytes = narrow ? 4u : 8u;
     const uint64_t byte_off = tile_byte + uint64_t(kBytes) * lane;
     if (tile_byte <= enc_bytes && enc_bytes - tile_byte >= uint64_t(kBytes) * kWave) {  // wave-uniform
-        if (W == 16) {
+        if (!narrow) {
             const u32x2 r = reinterpret_cast<const u32x2_a1*>(enc + byte_off)->v;
             return (uint64_t(r.y) << 32) | r.x;
         }
@@ -239,7 +242,7 @@ __device__ __forceinline__ uint64_t load_lane_slots(const uint8_t* enc, uint64_t
     const uint64_t o = byte_off < last_valid ? byte_off : last_valid;
     const uint64_t over = byte_off - o;  // 0 for all but the tail lanes
     uint64_t q;
-    if (W == 16) {
+    if (!narrow) {
         const u32x2 r = reinterpret_cast<const u32x2_a1*>(enc + o)->v;
         q = (uint64_t(r.y) << 32) | r.x;
     } else {
@@ -259,10 +262,14 @@ struct head_regs {     // per cold slot: the 16-byte head of its dictionary entr
     u32x4 q[kSPL];     // (later in the tile: the next 8 integers of the entries that have them)
 };
 
-template <int W>
-__device__ __forceinline__ void unpack_slots(uint64_t raw, tile_regs& t) {
+__device__ __forceinline__ void unpack_slots(bool narrow, uint64_t raw, tile_regs& t) {
+    if (!narrow) {
 #pragma unroll
-    for (uint32_t k = 0; k != kSPL; ++k) t.s[k] = uint32_t(raw >> (W * k)) & ((1u << W) - 1u);
+        for (uint32_t k = 0; k != kSPL; ++k) t.s[k] = uint32_t(raw >> (16 * k)) & 0xFFFFu;
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k != kSPL; ++k) t.s[k] = uint32_t(raw >> (8 * k)) & 0xFFu;
+    }
 }
 
 // Slot classification table. Whether a slot is a codeword header or an exception
@@ -321,6 +328,7 @@ struct prof_t {};
 struct wave_ctx {
     const uint32_t* lds;           // the workgroup's LDS (the dictionary image first)
     const uint16_t* cls;           // slot classification table
+    const uint32_t* descs;         // the dictionaries' descriptors in LDS: {meta_base, hot_base, hot_k, pad} each
     uint32_t* scratch;             // this wave's {flag pairs | delta table | staging cells}
     uint32_t lane;
     __amdgpu_buffer_rsrc_t rs_dict;  // gmeta | rows | gtable: one descriptor, hardware bounds
@@ -384,9 +392,8 @@ __device__ __forceinline__ void chain_request(const uint8_t* enc, uint64_t selec
 }
 
 // slots of tile t (0 or 1) of a chained segment, in the lane layout load_lane_slots produces
-template <int W>
-__device__ __forceinline__ uint64_t chain_tile(const u32x4& d, uint32_t t, uint32_t lane) {
-    if (W == 16) {  // lane l: bytes [512 t + 8 l, + 8) = half (l & 1) of lane 32 t + l / 2
+__device__ __forceinline__ uint64_t chain_tile(bool narrow, const u32x4& d, uint32_t t, uint32_t lane) {
+    if (!narrow) {  // lane l: bytes [512 t + 8 l, + 8) = half (l & 1) of lane 32 t + l / 2
         const int src = int(32 * t + (lane >> 1));
         const uint32_t x = __shfl(d.x, src), y = __shfl(d.y, src), z = __shfl(d.z, src), w = __shfl(d.w, src);
         const bool hi = (lane & 1u) != 0;
@@ -621,10 +628,9 @@ __device__ __forceinline__ void expand_tile(const tile_slots& t, bool plain, boo
 // stores (which put zeros there): dictionary entries that hold a value of 65536 or more, and whatever found
 // no staging cell (more than 256 cells in one tile: no real stream, but a legal one) — looked up again here:
 // rare enough not to ride through the expansion in registers. `slowb` bit k: slot k; `pos0` = the tile's first
-// output inside the segment of `seg_n` integers; `slot_addr` = this lane's first slot in the stream, W bits
-// per slot.
-template <int W>
-__device__ __forceinline__ void slow_stores(const wave_ctx& c, const tile_slots& t, uint32_t slowb, uint32_t plus_one, uint32_t pos0,
+// output inside the segment of `seg_n` integers; `slot_addr` = this lane's first slot in the stream (8 bits per
+// slot if `narrow`, else 16).
+__device__ __forceinline__ void slow_stores(bool narrow, const wave_ctx& c, const tile_slots& t, uint32_t slowb, uint32_t plus_one, uint32_t pos0,
                                             uint32_t seg_n, const uint8_t* slot_addr, uint32_t hot_base, uint32_t hot_k,
                                             uint32_t meta_base, const __amdgpu_buffer_rsrc_t rs_out) {
     // the zeros must be in memory first: two stores of one wave to one address are only ordered by the wait
@@ -633,10 +639,10 @@ __device__ __forceinline__ void slow_stores(const wave_ctx& c, const tile_slots&
     for (uint32_t k = 0; k != kSPL; ++k) {
         if ((slowb >> k) & 1u) {
             const uint32_t pos = pos0 + t.obase + t.off[k];
-            const uint8_t* const sp = slot_addr + (W / 8) * k;
-            const uint32_t sv = W == 16 ? uint32_t(sp[0]) | (uint32_t(sp[1]) << 8) : uint32_t(sp[0]);
+            const uint8_t* const sp = slot_addr + (narrow ? 1u : 2u) * k;
+            const uint32_t sv = !narrow ? uint32_t(sp[0]) | (uint32_t(sp[1]) << 8) : uint32_t(sp[0]);
             if (sv < 2) {  // an exception whose literal found no staging cell: from the stream again
-                const uint8_t* const lp = sp + W / 8;
+                const uint8_t* const lp = sp + (narrow ? 1 : 2);
                 uint32_t v = uint32_t(lp[0]) | (uint32_t(lp[1]) << 8);
                 if (sv == 1) v |= (uint32_t(lp[2]) << 16) | (uint32_t(lp[3]) << 24);
                 __builtin_amdgcn_raw_buffer_store_b32(v + plus_one, rs_out, 4 * pos, 0, DINT_STORE_AUX);
@@ -657,13 +663,19 @@ __device__ __forceinline__ void slow_stores(const wave_ctx& c, const tile_slots&
 
 // ROUNDS x GROUPS x 256 = outputs per expansion batch: 2 x 4 for the long single-dictionary
 // segments; a multi-dictionary segment is one block of at most 256 integers, 1 x 1.
-template <int W, uint32_t ROUNDS, uint32_t GROUPS, bool CHAINED>
+// W = 16 / 8: the slot width; 0: `narrow_rt` says (wave-uniform). CHAINED = 1 / 0, or -1: `chained_rt` says.
+// (The multi-dictionary kernel has ONE instantiation for both widths, chained or not: with four, inlined side by
+// side, the register allocator spilled 127 registers to scratch.)
+template <int W, uint32_t ROUNDS, uint32_t GROUPS, int CHAINED_T>
 __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const wave_ctx& c, const dict_desc& dd, uint64_t in_off,
-                                                   uint32_t n, uint32_t* const out, chain_io& ch, prof_t& pf) {
+                                                   uint32_t n, uint32_t* const out, chain_io& ch, prof_t& pf,
+                                                   bool narrow_rt = false, bool chained_rt = false) {
     SECTION(pf, 11, "segment_prologue");
-    constexpr uint32_t kSlotBytes = W / 8;
-    constexpr uint32_t kTileBytes = kTileSlots * kSlotBytes;
-    const uint16_t* const rows = c.cls + (W == 16 ? 0 : kRows16);
+    const bool narrow = W == 0 ? narrow_rt : W == 8;
+    const bool CHAINED = CHAINED_T < 0 ? chained_rt : CHAINED_T != 0;
+    const uint32_t kSlotBytes = narrow ? 1u : 2u;
+    const uint32_t kTileBytes = kTileSlots * kSlotBytes;
+    const uint16_t* const rows = c.cls + (!narrow ? 0 : kRows16);
     const uint32_t lane = c.lane;
     const uint32_t hot_k = dd.hot_k;
     // hardware bounds: nothing past this segment's n integers can be written
@@ -682,22 +694,22 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const w
     head_regs hr;  // (deliberately uninitialised: each register is written and read under the same lane predicate)
     uint64_t raw1, raw2 = 0;
     if (CHAINED) {  // tiles 0 and 1 arrived with the previous block (or were requested by the caller)
-        unpack_slots<W>(chain_tile<W>(ch.data, 0, lane), cur);
-        raw1 = chain_tile<W>(ch.data, 1, lane);
+        unpack_slots(narrow, chain_tile(narrow, ch.data, 0, lane), cur);
+        raw1 = chain_tile(narrow, ch.data, 1, lane);
         slot_byte += kTileBytes;  // the pipeline is one tile shorter: tile t+2's slots are requested in tile t
     } else {
-        unpack_slots<W>(load_lane_slots<W>(a.enc, slot_byte, lane, a.enc_bytes), cur);
+        unpack_slots(narrow, load_lane_slots(narrow, a.enc, slot_byte, lane, a.enc_bytes), cur);
         slot_byte += kTileBytes;
-        raw1 = load_lane_slots<W>(a.enc, slot_byte, lane, a.enc_bytes);
+        raw1 = load_lane_slots(narrow, a.enc, slot_byte, lane, a.enc_bytes);
         slot_byte += kTileBytes;
-        raw2 = load_lane_slots<W>(a.enc, slot_byte, lane, a.enc_bytes);
+        raw2 = load_lane_slots(narrow, a.enc, slot_byte, lane, a.enc_bytes);
     }
     ch.valid = false;
     request_metas(c, dd.hot_base, hot_k, dd.meta_base, cur, mr, hr);
     // Everything loaded so far has landed before the loop is entered: inside it, a wait may only
     // ever sit before a tile's stores (see the notes below), never right after them.
     asm volatile("" : "+v"(raw1), "+v"(raw2));
-    unpack_slots<W>(raw1, nxt);
+    unpack_slots(narrow, raw1, nxt);
 
     uint32_t produced = 0;
     uint32_t carry = 0;            // payload slots an exception of the previous tile still owns
@@ -711,7 +723,7 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const w
         // front end. (Requested at the wait point instead, as the youngest load in flight there, it would have
         // a whole tile; measured: no gain — the kernel waits for the vector-memory front end, not for HBM.)
         slot_byte += kTileBytes;
-        const uint64_t raw3 = load_lane_slots<W>(a.enc, slot_byte, lane, a.enc_bytes);
+        const uint64_t raw3 = load_lane_slots(narrow, a.enc, slot_byte, lane, a.enc_bytes);
 
         SECTION(pf, 1, "1_classify");
         // this tile's metadata: requested before the previous tile's stores (so this is no wait for them)
@@ -763,9 +775,12 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const w
             }
             if (tile_exc) {
                 // slot values after this lane's: the next lane's first ones (lane 63: next tile's)
-                if (W == 16) {
+                // (what lane 0 of the next tile holds is read with every lane enabled: a cross-lane read of a
+                // value computed under `lane == 63` would find lane 0's register untouched)
+                if (!narrow) {
+                    const uint32_t next0 = readlane((nxt.s[1] << 16) | nxt.s[0], 0);
                     uint32_t nlo = from_lane_above((cur.s[1] << 16) | cur.s[0]);
-                    if (lane == 63) nlo = readlane((nxt.s[1] << 16) | nxt.s[0], 0);
+                    if (lane == 63) nlo = next0;
                     uint32_t v[kSPL + 2];
 #pragma unroll
                     for (uint32_t k = 0; k != kSPL; ++k) v[k] = cur.s[k];
@@ -775,8 +790,9 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const w
                     for (uint32_t k = 0; k != kSPL; ++k)
                         excval[k] = v[k] == 0 ? v[k + 1] : (v[k + 1] | (v[k + 2] << 16));
                 } else {
+                    const uint32_t next0 = readlane(nxt.s[0] | (nxt.s[1] << 8) | (nxt.s[2] << 16) | (nxt.s[3] << 24), 0);
                     uint32_t nlo = from_lane_above(cur.s[0] | (cur.s[1] << 8) | (cur.s[2] << 16) | (cur.s[3] << 24));
-                    if (lane == 63) nlo = readlane(nxt.s[0] | (nxt.s[1] << 8) | (nxt.s[2] << 16) | (nxt.s[3] << 24), 0);
+                    if (lane == 63) nlo = next0;
                     uint32_t v[kSPL + 4];
 #pragma unroll
                     for (uint32_t k = 0; k != kSPL; ++k) v[k] = cur.s[k];
@@ -825,7 +841,7 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const w
                     const bool act = ((t.liveb >> k) & 1u) != 0 && pos < remaining;
                     if (act) {
                         const bool exc = ((row >> (4 + k)) & 1u) != 0;
-                        cand = kSPL * lane + k + 1 + (exc ? (W == 16 ? cur.s[k] + 1 : 2 * cur.s[k] + 2) : 0u);
+                        cand = kSPL * lane + k + 1 + (exc ? (!narrow ? cur.s[k] + 1 : 2 * cur.s[k] + 2) : 0u);
                         ++t.nlive;
                         lb |= 1u << k;
                     } else {
@@ -925,7 +941,7 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const w
 
         SECTION(pf, 10, "10_tail");
         if (tile_slow)
-            slow_stores<W>(c, t, slowb, a.plus_one, produced, n, a.enc + tile_base + uint64_t(kSPL * kSlotBytes) * lane, dd.hot_base,
+            slow_stores(narrow, c, t, slowb, a.plus_one, produced, n, a.enc + tile_base + uint64_t(kSPL * kSlotBytes) * lane, dd.hot_base,
                            hot_k, dd.meta_base, rs_out);
         SECTION(pf, 5, "10_rotate");
         produced += t.total;
@@ -934,7 +950,7 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const w
 
         // ---- rotate the pipeline ---------------------------------------------------
         cur = nxt;
-        unpack_slots<W>(CHAINED ? raw3w : raw2, nxt);
+        unpack_slots(narrow, CHAINED ? raw3w : raw2, nxt);
         raw2 = raw3w;
     }
     SECTION(pf, 13, "epilogue");
@@ -952,7 +968,7 @@ __device__ __forceinline__ void decode_unit_single(const decode_args& a, const w
     if (n == 0 || n > kMaxUnitInts || out_off > a.out_capacity || a.out_capacity - out_off < n || (a.only_full && n != 256)) return;
     const uint64_t in_off = uniform64(up->in_off);
     chain_io ch{};
-    const uint64_t end = decode_segment<16, kRounds, kGroups, false>(a, c, a.dict.first, in_off, n, a.out + out_off, ch, pf);
+    const uint64_t end = decode_segment<16, kRounds, kGroups, 0>(a, c, a.dict.first, in_off, n, a.out + out_off, ch, pf);
     if (a.end_off && c.lane == 0) a.end_off[unit_index] = end;
 }
 
@@ -1107,10 +1123,10 @@ __device__ __forceinline__ void decode_bundle(const decode_args& a, const wave_c
     if (MULTI) {
         const uint32_t sel = has ? uint32_t(a.enc[my_in]) : 0u;
         my_narrow = sel >= 6 ? 1u : 0u;
-        const dict_desc* dp = a.dict.descs + (my_narrow ? sel - 6 : sel) % 6;
-        my_hot_base = dp->hot_base;
-        my_hot_k = dp->hot_k;
-        my_meta_base = dp->meta_base;
+        const uint32_t* dp = c.descs + 4 * ((my_narrow ? sel - 6 : sel) % 6);
+        my_meta_base = dp[0];
+        my_hot_base = dp[1];
+        my_hot_k = dp[2];
         const uint32_t stride = my_narrow ? 4u : 8u;
         my_lanes = has ? uint32_t((nxt_in - my_in - 1 + stride - 1) / stride) : 0u;
     }
@@ -1155,7 +1171,7 @@ __device__ __forceinline__ void decode_bundle(const decode_args& a, const wave_c
             raw = (uint64_t(r.y) << 32) | r.x;
         }
         raw_lo = uint32_t(raw);
-        unpack_slots<16>(raw, cur);
+        unpack_slots(false, raw, cur);
         if (MULTI && narrow) {
 #pragma unroll
             for (uint32_t k = 0; k != kSPL; ++k) cur.s[k] = (raw_lo >> (8 * k)) & 0xFFu;
@@ -1331,8 +1347,7 @@ __device__ __forceinline__ void decode_bundle(const decode_args& a, const wave_c
     if (tile_slow) {
         // (positions in slow_stores are relative to the bundle; a unit's clamp is what `room` must be)
         const uint8_t* const my_slots = a.enc + slot0 + stride * (lane - seg_lane0);
-        if (MULTI && narrow) slow_stores<8>(c, t, slowb, a.plus_one, 0u, seg_out0 + seg_n, my_slots, hot_base, hot_k, meta_base, rs_out);
-        else slow_stores<16>(c, t, slowb, a.plus_one, 0u, seg_out0 + seg_n, my_slots, hot_base, hot_k, meta_base, rs_out);
+        slow_stores(MULTI && narrow, c, t, slowb, a.plus_one, 0u, seg_out0 + seg_n, my_slots, hot_base, hot_k, meta_base, rs_out);
     }
     SECTION(pf, 13, "epilogue");
 }
@@ -1365,19 +1380,13 @@ __device__ __forceinline__ void decode_unit_multi(const decode_args& a, const wa
         const bool narrow = sel >= 6;
         const uint32_t d = (narrow ? sel - 6 : sel) % 6;
         dict_desc dd;
-        dd.meta_base = uniform(a.dict.descs[d].meta_base);
-        dd.hot_base = uniform(a.dict.descs[d].hot_base);
-        dd.hot_k = uniform(a.dict.descs[d].hot_k);
+        dd.meta_base = uniform(c.descs[4 * d]);
+        dd.hot_base = uniform(c.descs[4 * d + 1]);
+        dd.hot_k = uniform(c.descs[4 * d + 2]);
         dd.pad = 0;
         uint32_t* const out = a.out + out_off + done;
         ch.more = done + bsize < n;
-        if (chained) {
-            if (narrow) pos = decode_segment<8, 1, 1, true>(a, c, dd, pos + 1, bsize, out, ch, pf);
-            else pos = decode_segment<16, 1, 1, true>(a, c, dd, pos + 1, bsize, out, ch, pf);
-        } else {
-            if (narrow) pos = decode_segment<8, 1, 1, false>(a, c, dd, pos + 1, bsize, out, ch, pf);
-            else pos = decode_segment<16, 1, 1, false>(a, c, dd, pos + 1, bsize, out, ch, pf);
-        }
+        pos = decode_segment<0, 1, 1, -1>(a, c, dd, pos + 1, bsize, out, ch, pf, narrow, chained);
         done += bsize;
     }
     if (a.end_off && lane == 0) a.end_off[unit_index] = pos;
@@ -1409,6 +1418,8 @@ __device__ __forceinline__ void decode_kernel_body(const decode_args& kernarg) {
     for (uint32_t i = threadIdx.x; i < a.dict.hot_words; i += kBlockThreads) lds[i] = a.dict.lds_image[i];
     uint16_t* const cls = reinterpret_cast<uint16_t*>(lds + a.dict.hot_words);
     build_class_table(cls);
+    uint32_t* const descs = lds + a.dict.hot_words + kDescWordAt;
+    if (threadIdx.x < 24) descs[threadIdx.x] = MULTI ? reinterpret_cast<const uint32_t*>(a.dict.descs)[threadIdx.x] : 0u;
     const uint32_t lane = lane_id();
     const uint32_t wave = uniform(threadIdx.x / kWave);
     uint32_t* const scratch = lds + a.dict.hot_words + kClassTableWords + wave * kScratchWords;
@@ -1417,6 +1428,7 @@ __device__ __forceinline__ void decode_kernel_body(const decode_args& kernarg) {
     wave_ctx c;
     c.lds = lds;
     c.cls = cls;
+    c.descs = descs;
     c.scratch = scratch;
     c.lane = lane;
     c.rs_dict = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.dict.tables), 0, int(a.dict.tables_bytes), 0x00020000);

@@ -12,6 +12,14 @@ import os
 
 import numpy as np
 
+try:
+    # torch ships its own HIP runtime under the same soname as the system one. Whichever is loaded first serves
+    # the whole process; with the system's loaded first (by libdint_hip.so), torch later finds "No HIP GPUs".
+    # So torch — which owns device memory and streams in this layer anyway — is imported before the library.
+    import torch  # noqa: F401
+except ImportError:  # (the C ABI itself does not need torch)
+    pass
+
 from .host import UNIT_DTYPE, KIND_BY_TYPE, RECTANGULAR, SINGLE_PACKED, MULTI_PACKED  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
