@@ -169,10 +169,6 @@ struct dint_dict {
     bool slot_used[kQueueSlots] = {};
     std::atomic<uint32_t> next_slot{0};
     std::mutex launch_mutex;
-    // workspace of dint_decode_posting_blocks (grow-only; one call at a time per dictionary)
-    void* pl_ws = nullptr;
-    size_t pl_ws_bytes = 0;
-    std::mutex pl_mutex;
 };
 
 namespace {
@@ -518,7 +514,6 @@ void dint_dict_destroy(dint_dict* dd) {
     if (dd->d_queues) (void)hipFree(dd->d_queues);
     for (auto p : dd->d_sched)
         if (p) (void)hipFree(p);
-    if (dd->pl_ws) (void)hipFree(dd->pl_ws);
     for (auto e : dd->slot_done)
         if (e) (void)hipEventDestroy(e);
     delete dd;
@@ -633,9 +628,17 @@ int dint_index_stream(const dint_dict* dd, const uint8_t* enc, size_t enc_bytes,
     return DINT_OK;
 }
 
+// A bundle schedule kept by its owner (a prepared block table: the same units launch after launch) instead of
+// being rebuilt, three small kernels, before every launch.
+struct sched_cache {
+    void* d_mem = nullptr;  // [items u32 x n][block counts/offsets u32 x blocks][n_items u32][sched u8 x n][item counts u8 x n]
+    bool valid = false;
+};
+
 static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_bytes, const dint_unit* d_units,
                          size_t n_units, uint32_t* d_out, size_t out_capacity, uint64_t* d_end_off, void* stream,
-                         uint32_t only_full, const uint32_t* d_spans = nullptr, uint32_t plus_one = 0) {
+                         uint32_t only_full, const uint32_t* d_spans = nullptr, uint32_t plus_one = 0,
+                         const uint32_t* d_unit_base = nullptr, uint8_t* d_gaps_left = nullptr, sched_cache* cache = nullptr) {
     if (!dd) return DINT_ERR_ARG;
     if (n_units == 0) return DINT_OK;
     if (!d_enc || !d_units || !d_out || enc_bytes < 8) return DINT_ERR_ARG;  // slots are fetched 8 bytes at a time
@@ -651,6 +654,8 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
     a.end_off = d_end_off;
     a.only_full = only_full;
     a.plus_one = plus_one;
+    a.unit_base = d_unit_base;
+    a.gaps_left = d_gaps_left;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint64_t blocks_needed = (uint64_t(n_units) + kWavesPerBlock - 1) / kWavesPerBlock;
     const uint32_t grid = uint32_t(std::min<uint64_t>(blocks_needed, std::max<uint32_t>(1, dd->compute_units) * kBlocksPerCU));
@@ -674,7 +679,8 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
         // workspace of the slot: [items u32 x n][block counts/offsets u32 x blocks][n_items u32][sched u8 x n][item counts u8 x n]
         const size_t n_blocks = (n_units + 255) / 256;
         const size_t need = 4 * n_units + 4 * n_blocks + 4 + 2 * n_units;
-        if (mut->sched_cap[slot] < need) {
+        if (cache && !cache->d_mem) HIP_TRY(hipMalloc(&cache->d_mem, need));
+        if (!cache && mut->sched_cap[slot] < need) {
             if (mut->d_sched[slot]) HIP_TRY(hipFree(mut->d_sched[slot]));
             mut->d_sched[slot] = nullptr;
             mut->sched_cap[slot] = 0;
@@ -682,17 +688,20 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
             HIP_TRY(hipMalloc(&mut->d_sched[slot], want));
             mut->sched_cap[slot] = want;
         }
-        uint32_t* const d_items = reinterpret_cast<uint32_t*>(mut->d_sched[slot]);
+        uint32_t* const d_items = reinterpret_cast<uint32_t*>(cache ? cache->d_mem : mut->d_sched[slot]);
         uint32_t* const d_block = d_items + n_units;
         uint32_t* const d_n_items = d_block + n_blocks;
         uint8_t* const d_sch = reinterpret_cast<uint8_t*>(d_n_items + 1);
         uint8_t* const d_item_cnt = d_sch + n_units;
-        hipLaunchKernelGGL(bundle_schedule_kernel, dim3(uint32_t(n_blocks)), dim3(256), 0, s, d_units, d_spans, uint64_t(n_units),
-                           d_enc, uint64_t(enc_bytes), uint64_t(out_capacity), only_full,
-                           uint32_t(dd->kind == DINT_DICT_MULTI_PACKED), d_sch, d_block);
-        hipLaunchKernelGGL(bundle_offsets_kernel, dim3(1), dim3(1024), 0, s, d_block, uint32_t(n_blocks), d_n_items);
-        hipLaunchKernelGGL(bundle_items_kernel, dim3(uint32_t(n_blocks)), dim3(256), 0, s, d_sch, uint64_t(n_units), d_block,
-                           d_items, d_item_cnt);
+        if (!cache || !cache->valid) {
+            hipLaunchKernelGGL(bundle_schedule_kernel, dim3(uint32_t(n_blocks)), dim3(256), 0, s, d_units, d_spans, uint64_t(n_units),
+                               d_enc, uint64_t(enc_bytes), uint64_t(out_capacity), only_full,
+                               uint32_t(dd->kind == DINT_DICT_MULTI_PACKED), d_sch, d_block);
+            hipLaunchKernelGGL(bundle_offsets_kernel, dim3(1), dim3(1024), 0, s, d_block, uint32_t(n_blocks), d_n_items);
+            hipLaunchKernelGGL(bundle_items_kernel, dim3(uint32_t(n_blocks)), dim3(256), 0, s, d_sch, uint64_t(n_units), d_block,
+                               d_items, d_item_cnt);
+            if (cache) cache->valid = true;
+        }
         a.sched = d_sch;
         a.items = d_items;
         a.n_items = d_n_items;
@@ -761,72 +770,173 @@ int dint_index_posting_lists(const uint8_t* index, size_t index_bytes, const uin
     return DINT_OK;
 }
 
+// A block table prepared for decoding: what depends on the table alone is computed once — the docs parts' unit
+// table, byte spans and docID bases, the list of short (interpolative) blocks — and the per-call workspace (where
+// the docs parts end, the freqs parts' units) lives here too, so that a decode is a sequence of launches and
+// nothing else.
+struct dint_block_table {
+    int device = 0;
+    size_t n_blocks = 0, n_tails = 0;
+    bool owns_blocks = false;
+    const dint_block_ref* d_blocks = nullptr;
+    void* d_ws = nullptr;  // one allocation: everything below
+    dint_unit* d_units = nullptr;       // docs parts
+    uint32_t* d_spans = nullptr;
+    uint32_t* d_bases = nullptr;
+    uint32_t* d_tails = nullptr;        // indices of the short blocks, then their number
+    uint64_t* d_ends = nullptr;         // per call: where each docs part ended = where the freqs part begins
+    dint_unit* d_funits = nullptr;      // per call: freqs parts
+    uint32_t* d_fspans = nullptr;
+    uint8_t* d_gaps_left = nullptr;     // per call: blocks the decode kernels left as gaps
+    bool spans_exact = false;           // the docs parts' byte spans have been cut down to their ends (after the first decode)
+    // From the third decode on nothing but the decode kernels, the interpolative decoder and the clean-up run:
+    // the first decode learns where the docs parts end (exact spans, the freqs parts' units), the second builds
+    // the two bundle schedules from them, and both are a property of the index, not of the call.
+    uint32_t decodes = 0;
+    sched_cache docs_sched, freqs_sched;
+    bool freqs_units_ready = false;
+};
+
+namespace {
+int block_table_prepare(dint_block_table& t, const dint_block_ref* d_blocks, size_t n_blocks, size_t index_bytes, hipStream_t s) {
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t b_units = up(n_blocks * sizeof(dint_unit)), b_u32 = up((n_blocks + 1) * 4), b_u64 = up(n_blocks * 8),
+                 b_u8 = up(n_blocks);
+    HIP_TRY(hipMalloc(&t.d_ws, 2 * b_units + 4 * b_u32 + b_u64 + b_u8));
+    uint8_t* p = static_cast<uint8_t*>(t.d_ws);
+    t.d_units = reinterpret_cast<dint_unit*>(p), p += b_units;
+    t.d_funits = reinterpret_cast<dint_unit*>(p), p += b_units;
+    t.d_ends = reinterpret_cast<uint64_t*>(p), p += b_u64;
+    t.d_spans = reinterpret_cast<uint32_t*>(p), p += b_u32;
+    t.d_fspans = reinterpret_cast<uint32_t*>(p), p += b_u32;
+    t.d_bases = reinterpret_cast<uint32_t*>(p), p += b_u32;
+    t.d_tails = reinterpret_cast<uint32_t*>(p), p += b_u32;
+    t.d_gaps_left = p;
+    t.d_blocks = d_blocks;
+    t.n_blocks = n_blocks;
+    const uint32_t tb = 256, grid = uint32_t((n_blocks + tb - 1) / tb);
+    HIP_TRY(hipMemsetAsync(t.d_tails + n_blocks, 0, 4, s));
+    hipLaunchKernelGGL(collect_tails_kernel, dim3(grid), dim3(tb), 0, s, d_blocks, uint64_t(n_blocks), t.d_tails, t.d_tails + n_blocks);
+    hipLaunchKernelGGL(blocks_to_units_kernel, dim3(grid), dim3(tb), 0, s, d_blocks, static_cast<const uint64_t*>(nullptr),
+                       uint64_t(n_blocks), uint64_t(index_bytes), t.d_units, t.d_spans, t.d_bases);
+    HIP_TRY(hipGetLastError());
+    uint32_t n_tails = 0;
+    HIP_TRY(hipMemcpyAsync(&n_tails, t.d_tails + n_blocks, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    t.n_tails = n_tails;
+    return DINT_OK;
+}
+
+// docs parts -> docIDs, freqs parts -> freqs: launches only, nothing waited for
+int block_table_decode(const dint_dict* docs_dict, const dint_dict* freqs_dict, const uint8_t* d_index, size_t index_bytes,
+                       const dint_block_table& t, uint32_t* d_docids, uint32_t* d_freqs, size_t out_capacity, hipStream_t s) {
+    const size_t n_blocks = t.n_blocks;
+    const uint32_t tb = 256, grid = uint32_t((n_blocks + tb - 1) / tb);
+    const uint32_t tgrid = uint32_t((t.n_tails + kTailLanes - 1) / kTailLanes);  // one wave per kTailLanes short blocks
+    HIP_TRY(hipMemsetAsync(t.d_gaps_left, 0, n_blocks, s));
+    // docs parts of the full blocks through the DINT kernel (docIDs formed in the expansion); then, where they end,
+    // their freqs parts; the short blocks — both parts of a block in one lane — through the interpolative decoder
+    dint_block_table& mt = const_cast<dint_block_table&>(t);
+    const bool keep = t.owns_blocks && t.decodes >= 1;  // (a one-shot table never reaches its second decode)
+    int st = launch_decode(docs_dict, d_index, index_bytes, t.d_units, n_blocks, d_docids, out_capacity, t.d_ends, s, 1, t.d_spans, 0,
+                           t.d_bases, t.d_gaps_left, keep ? &mt.docs_sched : nullptr);
+    if (st != DINT_OK) return st;
+    if (!t.spans_exact) {  // (stream-ordered: the next decode on this table finds the exact spans)
+        hipLaunchKernelGGL(exact_spans_kernel, dim3(grid), dim3(tb), 0, s, t.d_units, t.d_ends, uint64_t(n_blocks), t.d_spans);
+        mt.spans_exact = true;
+    }
+    if (d_freqs) {
+        if (!t.freqs_units_ready) {
+            hipLaunchKernelGGL(blocks_to_units_kernel, dim3(grid), dim3(tb), 0, s, t.d_blocks, t.d_ends, uint64_t(n_blocks),
+                               uint64_t(index_bytes), t.d_funits, t.d_fspans, static_cast<uint32_t*>(nullptr));
+            mt.freqs_units_ready = t.owns_blocks;
+        }
+        // (freq = decoded value + 1, dict_posting_list.hpp:164-169: added where the values are stored)
+        st = launch_decode(freqs_dict, d_index, index_bytes, t.d_funits, n_blocks, d_freqs, out_capacity, nullptr, s, 1, t.d_fspans, 1,
+                           nullptr, nullptr, keep ? &mt.freqs_sched : nullptr);
+        if (st != DINT_OK) return st;
+    }
+    if (tgrid)
+        hipLaunchKernelGGL(interpolative_tails_kernel, dim3(tgrid), dim3(64), kTailLdsBytes, s, d_index, uint64_t(index_bytes), t.d_blocks,
+                           static_cast<const uint64_t*>(nullptr), t.d_tails, t.d_tails + n_blocks, d_docids, uint64_t(out_capacity),
+                           static_cast<uint64_t*>(nullptr), 0u, 1u, d_freqs);
+    // the blocks that had to stay gaps (a slow codeword, a block of more than 256 slots): next to none
+    hipLaunchKernelGGL(finalize_flagged_kernel, dim3(uint32_t((n_blocks + 63) / 64)), dim3(64), 0, s, t.d_blocks, uint64_t(n_blocks),
+                       d_docids, uint64_t(out_capacity), t.d_gaps_left);
+    HIP_TRY(hipGetLastError());
+    mt.decodes += 1;
+    return DINT_OK;
+}
+}  // namespace
+
+int dint_block_table_create(const dint_dict* docs_dict, const dint_block_ref* blocks, size_t n_blocks, size_t index_bytes,
+                            dint_block_table** out) {
+    if (!docs_dict || !out || (!blocks && n_blocks)) return DINT_ERR_ARG;
+    *out = nullptr;
+    if (n_blocks >= 0xFFFFFFFFull) return DINT_ERR_ARG;
+    for (size_t b = 0; b != n_blocks; ++b)
+        if (blocks[b].n == 0 || blocks[b].n > kBlock || blocks[b].in_off > index_bytes) return DINT_ERR_FORMAT;
+    auto* t = new (std::nothrow) dint_block_table();
+    if (!t) return DINT_ERR_NOMEM;
+    t->device = docs_dict->device;
+    if (n_blocks == 0) {
+        *out = t;
+        return DINT_OK;
+    }
+    dint_block_ref* d_blocks = nullptr;
+    int st = DINT_ERR_HIP;
+    if (hip_ok(hipSetDevice(t->device), "hipSetDevice") && hip_ok(hipMalloc(&d_blocks, n_blocks * sizeof(dint_block_ref)), "hipMalloc(blocks)") &&
+        hip_ok(hipMemcpy(d_blocks, blocks, n_blocks * sizeof(dint_block_ref), hipMemcpyHostToDevice), "hipMemcpy(blocks)")) {
+        t->owns_blocks = true;
+        st = block_table_prepare(*t, d_blocks, n_blocks, index_bytes, nullptr);
+    }
+    if (st != DINT_OK) {
+        if (d_blocks && !t->d_blocks) (void)hipFree(d_blocks);
+        dint_block_table_destroy(t);
+        return st;
+    }
+    *out = t;
+    return DINT_OK;
+}
+
+void dint_block_table_destroy(dint_block_table* t) {
+    if (!t) return;
+    (void)hipSetDevice(t->device);
+    if (t->d_ws) (void)hipFree(t->d_ws);
+    if (t->docs_sched.d_mem) (void)hipFree(t->docs_sched.d_mem);
+    if (t->freqs_sched.d_mem) (void)hipFree(t->freqs_sched.d_mem);
+    if (t->owns_blocks && t->d_blocks) (void)hipFree(const_cast<dint_block_ref*>(t->d_blocks));
+    delete t;
+}
+
+int dint_decode_block_table(const dint_dict* docs_dict, const dint_dict* freqs_dict, const uint8_t* d_index, size_t index_bytes,
+                            dint_block_table* table, uint32_t* d_docids, uint32_t* d_freqs, size_t out_capacity, void* stream) {
+    if (!docs_dict || !table || (d_freqs && !freqs_dict)) return DINT_ERR_ARG;
+    if (table->n_blocks == 0) return DINT_OK;
+    if (!d_index || !d_docids || index_bytes < 8 || table->device != docs_dict->device) return DINT_ERR_ARG;
+    if (freqs_dict && (freqs_dict->device != docs_dict->device || freqs_dict->kind != docs_dict->kind)) return DINT_ERR_ARG;
+    HIP_TRY(hipSetDevice(docs_dict->device));
+    return block_table_decode(docs_dict, freqs_dict, d_index, index_bytes, *table, d_docids, d_freqs, out_capacity,
+                              static_cast<hipStream_t>(stream));
+}
+
 int dint_decode_posting_blocks(const dint_dict* docs_dict, const dint_dict* freqs_dict, const uint8_t* d_index,
                                size_t index_bytes, const dint_block_ref* d_blocks, size_t n_blocks,
                                uint32_t* d_docids, uint32_t* d_freqs, size_t out_capacity, void* stream) {
     if (!docs_dict || (d_freqs && !freqs_dict)) return DINT_ERR_ARG;
     if (n_blocks == 0) return DINT_OK;
-    if (!d_index || !d_blocks || !d_docids || index_bytes < 8) return DINT_ERR_ARG;
+    if (!d_index || !d_blocks || !d_docids || index_bytes < 8 || n_blocks >= 0xFFFFFFFFull) return DINT_ERR_ARG;
     if (freqs_dict && (freqs_dict->device != docs_dict->device || freqs_dict->kind != docs_dict->kind))
         return DINT_ERR_ARG;
     HIP_TRY(hipSetDevice(docs_dict->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // workspace: [units][docs ends][spans][short blocks + their number], kept with the docs dictionary
-    dint_dict* owner = const_cast<dint_dict*>(docs_dict);
-    std::lock_guard<std::mutex> ws_lock(owner->pl_mutex);
-    const size_t need = n_blocks * (sizeof(dint_unit) + sizeof(uint64_t) + 2 * sizeof(uint32_t)) + 64;
-    if (owner->pl_ws_bytes < need) {
-        if (owner->pl_ws) HIP_TRY(hipFree(owner->pl_ws));
-        owner->pl_ws = nullptr;
-        owner->pl_ws_bytes = 0;
-        const size_t want = need + need / 4;
-        HIP_TRY(hipMalloc(&owner->pl_ws, want));
-        owner->pl_ws_bytes = want;
-    }
-    dint_unit* const d_units = static_cast<dint_unit*>(owner->pl_ws);
-    uint64_t* const d_ends = reinterpret_cast<uint64_t*>(d_units + n_blocks);
-    uint32_t* const d_spans = reinterpret_cast<uint32_t*>(d_ends + n_blocks);
-    uint32_t* const d_tails = d_spans + n_blocks;  // [n_blocks] indices of the short blocks, [n_blocks]: their number
-    int st = DINT_OK;
-    auto cleanup = [&] { (void)hipStreamSynchronize(s); };
-#define TRY_OR_CLEAN(call)            \
-    do {                              \
-        if (!hip_ok((call), #call)) { \
-            cleanup();                \
-            return DINT_ERR_HIP;      \
-        }                             \
-    } while (0)
-    TRY_OR_CLEAN(hipMemsetAsync(d_tails + n_blocks, 0, 4, s));
-    const uint32_t tb = 256;
-    const uint32_t grid = uint32_t((n_blocks + tb - 1) / tb);
-    const uint32_t tgrid = uint32_t((n_blocks + 63) / 64);  // one wave per 64 short blocks (most exit at once)
-    hipLaunchKernelGGL(collect_tails_kernel, dim3(grid), dim3(tb), 0, s, d_blocks, uint64_t(n_blocks), d_tails, d_tails + n_blocks);
-    // docs parts: full blocks through the DINT kernel, short ones through the interpolative decoder
-    hipLaunchKernelGGL(blocks_to_units_kernel, dim3(grid), dim3(tb), 0, s, d_blocks, nullptr, uint64_t(n_blocks),
-                       uint64_t(index_bytes), d_units, d_spans);
-    st = launch_decode(docs_dict, d_index, index_bytes, d_units, n_blocks, d_docids, out_capacity, d_ends, s, 1, d_spans);
-    if (st == DINT_OK) {
-        hipLaunchKernelGGL(interpolative_tails_kernel, dim3(tgrid), dim3(64), kTailLdsBytes, s, d_index, uint64_t(index_bytes),
-                           d_blocks, nullptr, d_tails, d_tails + n_blocks, d_docids, uint64_t(out_capacity), d_ends, 0u);
-        if (d_freqs) {  // freqs parts start where the docs parts ended
-            hipLaunchKernelGGL(blocks_to_units_kernel, dim3(grid), dim3(tb), 0, s, d_blocks, d_ends,
-                               uint64_t(n_blocks), uint64_t(index_bytes), d_units, d_spans);
-            // (freq = decoded value + 1, dict_posting_list.hpp:164-169: added where the values are stored)
-            st = launch_decode(freqs_dict, d_index, index_bytes, d_units, n_blocks, d_freqs, out_capacity, nullptr, s, 1, d_spans, 1);
-            if (st == DINT_OK)
-                hipLaunchKernelGGL(interpolative_tails_kernel, dim3(tgrid), dim3(64), kTailLdsBytes, s, d_index,
-                                   uint64_t(index_bytes), d_blocks, d_ends, d_tails, d_tails + n_blocks, d_freqs,
-                                   uint64_t(out_capacity), nullptr, 1u);
-        }
-    }
-    if (st == DINT_OK) {
-        const uint32_t wgrid = uint32_t((n_blocks * kWave + tb - 1) / tb);
-        hipLaunchKernelGGL(finalize_postings_kernel, dim3(wgrid), dim3(tb), 0, s, d_blocks, uint64_t(n_blocks),
-                           d_docids, static_cast<uint32_t*>(nullptr), uint64_t(out_capacity));
-        if (!hip_ok(hipGetLastError(), "in-index kernels")) st = DINT_ERR_HIP;
-    }
-#undef TRY_OR_CLEAN
-    cleanup();
+    // one shot: a prepared table for this call only (dint_block_table_create + dint_decode_block_table keep it)
+    dint_block_table t;
+    t.device = docs_dict->device;
+    int st = block_table_prepare(t, d_blocks, n_blocks, index_bytes, s);
+    if (st == DINT_OK) st = block_table_decode(docs_dict, freqs_dict, d_index, index_bytes, t, d_docids, d_freqs, out_capacity, s);
+    (void)hipStreamSynchronize(s);  // the workspace goes away with the call
+    if (t.d_ws) (void)hipFree(t.d_ws);
     return st;
 }
 
@@ -915,7 +1025,7 @@ static int decode_doc_pages(dint_query_index* qi, size_t n_pages, uint32_t* d_ou
     HIP_TRY(hipMemsetAsync(qi->tails.p + n_pages, 0, 4, s));
     hipLaunchKernelGGL(collect_tails_kernel, dim3(grid), dim3(tb), 0, s, qi->sub.p, uint64_t(n_pages), qi->tails.p,
                        qi->tails.p + n_pages);
-    hipLaunchKernelGGL(interpolative_tails_kernel, dim3(uint32_t((n_pages + 63) / 64)), dim3(64), kTailLdsBytes, s, qi->d_index,
+    hipLaunchKernelGGL(interpolative_tails_kernel, dim3(uint32_t((n_pages + kTailLanes - 1) / kTailLanes)), dim3(64), kTailLdsBytes, s, qi->d_index,
                        uint64_t(qi->index_bytes), qi->sub.p, nullptr, qi->tails.p, qi->tails.p + n_pages, d_out, cap, nullptr, 0u);
     const uint32_t wgrid = uint32_t((n_pages * kWave + tb - 1) / tb);
     hipLaunchKernelGGL(finalize_postings_kernel, dim3(wgrid), dim3(tb), 0, s, qi->sub.p, uint64_t(n_pages), d_out,

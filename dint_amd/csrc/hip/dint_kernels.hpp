@@ -143,6 +143,11 @@ struct decode_args {
     const uint8_t* item_cnt;  // with sched: sched[items[w]] per work item
     const uint32_t* spans; // nullable; per unit an upper bound of its stream bytes (else: up to the next unit's start)
     uint32_t plus_one;     // in-index freqs parts: every decoded integer + 1 (dict_posting_list.hpp:164-169)
+    // in-index docs parts (units = 256-posting blocks): the gaps leave the kernel as docIDs — docid_i = base +
+    // sum_{j<=i} (gap_j + 1) - 1 (dict_posting_list.hpp:111-124, :304), one wave scan per block in the expansion.
+    const uint32_t* unit_base;  // nullable; per unit: the block's docID base
+    uint8_t* gaps_left;         // with unit_base; per unit, zero at launch: set where a block had to be left as gaps (it
+                                // held a slow codeword) for finalize_postings_kernel
 };
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -508,7 +513,7 @@ __device__ __forceinline__ void tables_general(const tile_slots& t, uint8_t* fw,
 template <uint32_t ROUNDS, uint32_t GROUPS, bool WIDE>
 __device__ __forceinline__ void expand_batch(uint32_t bt, uint32_t out_int, const uint8_t* lds_bytes, const uint8_t* fw,
                                              const uint8_t* delta, const __amdgpu_buffer_rsrc_t rs_out, uint32_t lane,
-                                             uint32_t plus_one) {
+                                             uint32_t plus_one, const uint32_t* group_base) {
     // lane constants: this lane owns outputs 4*lane .. 4*lane+3 of every group
     const uint32_t sh = (4 * lane) & 31u;                 // bit position of its nibble in its flag word
     const uint32_t pair_byte = (lane >> 3) * 8;           // its {flag, base} pair inside a group's 8 pairs
@@ -556,6 +561,12 @@ __device__ __forceinline__ void expand_batch(uint32_t bt, uint32_t out_int, cons
             for (uint32_t g = 0; g != GROUPS; ++g) {
                 const uint32_t p0 = (rd * GROUPS + g) * 4 * kWave + 4 * lane;
                 if ((rd * GROUPS + g) * 4 * kWave < bt) {  // wave-uniform
+                    if (group_base) {  // wave-uniform: the group is one 256-posting block — gaps to docIDs
+                        const uint32_t base = uniform(group_base[rd * GROUPS + g]);
+                        const uint32_t v0 = x[g][0] + 1u, v1 = v0 + x[g][1] + 1u, v2 = v1 + x[g][2] + 1u, v3 = v2 + x[g][3] + 1u;
+                        const uint32_t before = wave_inclusive_sum(v3) - v3 + base - 1u;
+                        x[g][0] = before + v0, x[g][1] = before + v1, x[g][2] = before + v2, x[g][3] = before + v3;
+                    }
                     if (p0 < bt) {
                         u32x4 xv = {x[g][0], x[g][1], x[g][2], x[g][3]};
                         if (plus_one) xv += 1u;  // wave-uniform branch: nothing on the plain decode path
@@ -575,7 +586,8 @@ __device__ __forceinline__ void expand_batch(uint32_t bt, uint32_t out_int, cons
 // (The one-batch path is straight-line on purpose: inside a loop over batches everything the tables are built
 // from would stay live through the expansion — 55 more registers, measured.)
 template <uint32_t ROUNDS, uint32_t GROUPS, class BeforeGathers>
-__device__ __forceinline__ void expand_tile(const tile_slots& t, bool plain, bool wide, uint32_t plus_one, uint32_t out_int0,
+__device__ __forceinline__ void expand_tile(const tile_slots& t, bool plain, bool wide, uint32_t plus_one,
+                                            const uint32_t* group_base, uint32_t out_int0,
                                             const uint32_t* lds, uint32_t* scratch, const __amdgpu_buffer_rsrc_t rs_out,
                                             uint32_t lane, prof_t& pf, BeforeGathers&& before_gathers) {
     (void)pf;
@@ -594,8 +606,10 @@ __device__ __forceinline__ void expand_tile(const tile_slots& t, bool plain, boo
         SECTION(pf, 7, "7_rows2");
         before_gathers();
         SECTION(pf, 9, "9_expand");
-        if (__builtin_expect(wide, 0)) expand_batch<ROUNDS, GROUPS, true>(total, out_int0, lds_bytes, fw, delta, rs_out, lane, plus_one);
-        else expand_batch<ROUNDS, GROUPS, false>(total, out_int0, lds_bytes, fw, delta, rs_out, lane, plus_one);
+        if (__builtin_expect(wide, 0))
+            expand_batch<ROUNDS, GROUPS, true>(total, out_int0, lds_bytes, fw, delta, rs_out, lane, plus_one, group_base);
+        else
+            expand_batch<ROUNDS, GROUPS, false>(total, out_int0, lds_bytes, fw, delta, rs_out, lane, plus_one, group_base);
         // the flag words go back to zero for the next batch (this wave's LDS operations execute in order)
         *reinterpret_cast<uint32_t*>(fw + 8 * lane) = 0;
         wave_lds_fence();
@@ -616,7 +630,8 @@ __device__ __forceinline__ void expand_tile(const tile_slots& t, bool plain, boo
         tables_general(t, fw, delta, inb, done, rdone);
         wave_lds_fence();
         if (done == 0) before_gathers();
-        expand_batch<ROUNDS, GROUPS, true>(bend - done, out_int0 + done, lds_bytes, fw, delta, rs_out, lane, plus_one);
+        // (batches of lanes do not end on block boundaries: no docIDs here — the caller leaves such a tile as gaps)
+        expand_batch<ROUNDS, GROUPS, true>(bend - done, out_int0 + done, lds_bytes, fw, delta, rs_out, lane, plus_one, nullptr);
         *reinterpret_cast<uint32_t*>(fw + 8 * lane) = 0;
         wave_lds_fence();
         done = bend;
@@ -669,7 +684,8 @@ __device__ __forceinline__ void slow_stores(bool narrow, const wave_ctx& c, cons
 template <int W, uint32_t ROUNDS, uint32_t GROUPS, int CHAINED_T>
 __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const wave_ctx& c, const dict_desc& dd, uint64_t in_off,
                                                    uint32_t n, uint32_t* const out, chain_io& ch, prof_t& pf,
-                                                   bool narrow_rt = false, bool chained_rt = false) {
+                                                   bool narrow_rt = false, bool chained_rt = false,
+                                                   const uint32_t* block_base = nullptr, uint8_t* gaps_left = nullptr) {
     SECTION(pf, 11, "segment_prologue");
     const bool narrow = W == 0 ? narrow_rt : W == 8;
     const bool CHAINED = CHAINED_T < 0 ? chained_rt : CHAINED_T != 0;
@@ -920,7 +936,12 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const w
                 if (t.need[k] > 2u) t3[k] = __builtin_amdgcn_raw_buffer_load_b32(c.rs_dict, tail + 16, 0, 0);
             }
         }
-        expand_tile<ROUNDS, GROUPS>(t, plain, tile_wide, a.plus_one, produced, c.lds, c.scratch, rs_out, lane, pf, [&]() {
+        // (in-index docs part: the segment is one 256-posting block = one group of one tile; with a slow codeword in
+        // it, or spread over two tiles — more than 256 slots: a block full of exceptions — it stays gaps and
+        // finalize_postings_kernel is told)
+        const bool as_docids = block_base != nullptr && !tile_slow && produced == 0 && last_tile && t.total <= ROUNDS * GROUPS * 256;
+        if (block_base != nullptr && !as_docids && lane == 0) *gaps_left = 1;
+        expand_tile<ROUNDS, GROUPS>(t, plain, tile_wide, a.plus_one, as_docids ? block_base : nullptr, produced, c.lds, c.scratch, rs_out, lane, pf, [&]() {
 #pragma unroll
             for (uint32_t k = 0; k != kSPL; ++k) asm volatile("" : "+v"(hr.q[k]), "+v"(t3[k]));
             if (tile_big) {
@@ -968,7 +989,9 @@ __device__ __forceinline__ void decode_unit_single(const decode_args& a, const w
     if (n == 0 || n > kMaxUnitInts || out_off > a.out_capacity || a.out_capacity - out_off < n || (a.only_full && n != 256)) return;
     const uint64_t in_off = uniform64(up->in_off);
     chain_io ch{};
-    const uint64_t end = decode_segment<16, kRounds, kGroups, 0>(a, c, a.dict.first, in_off, n, a.out + out_off, ch, pf);
+    const uint64_t end = decode_segment<16, kRounds, kGroups, 0>(a, c, a.dict.first, in_off, n, a.out + out_off, ch, pf, false, false,
+                                                                 a.unit_base ? a.unit_base + unit_index : nullptr,
+                                                                 a.unit_base ? a.gaps_left + unit_index : nullptr);
     if (a.end_off && c.lane == 0) a.end_off[unit_index] = end;
 }
 
@@ -1028,7 +1051,8 @@ __global__ __launch_bounds__(256) void bundle_schedule_kernel(const dint_unit* u
 #pragma unroll 16
         for (uint32_t j = tid; j != tid + 64; ++j) {
             const uint32_t l = lanes[j];
-            const bool cont = l != 0 && prev_l != 0 && pre[j] != 0 && in_use + l <= kWave - 1 && members < kWave;
+            // (in-index launches: at most 8 blocks = 2048 postings to a bundle, one expansion batch, groups = blocks)
+            const bool cont = l != 0 && prev_l != 0 && pre[j] != 0 && in_use + l <= kWave - 1 && members < (only_full ? 8u : kWave);
             start[j] = cont ? 0 : 1;
             in_use = cont ? in_use + l : l;
             members = cont ? members + 1 : 1;
@@ -1332,7 +1356,11 @@ __device__ __forceinline__ void decode_bundle(const decode_args& a, const wave_c
             if (t.need[k] > 2u) t3[k] = __builtin_amdgcn_raw_buffer_load_b32(c.rs_dict, tail + 16, 0, 0);
         }
     }
-    expand_tile<kRounds, kGroups>(t, false, tile_wide, a.plus_one, 0u, lds, scratch, rs_out, lane, pf, [&]() {
+    // (in-index docs parts: every unit of the bundle is a 256-posting block, so group g of the expansion is unit
+    // u0 + g; a slow codeword anywhere leaves the whole bundle as gaps for finalize_postings_kernel)
+    const bool as_docids = a.unit_base != nullptr && !tile_slow && total <= kRounds * kGroups * 256;
+    if (a.unit_base != nullptr && !as_docids && has) a.gaps_left[u0 + lane] = 1;
+    expand_tile<kRounds, kGroups>(t, false, tile_wide, a.plus_one, as_docids ? a.unit_base + u0 : nullptr, 0u, lds, scratch, rs_out, lane, pf, [&]() {
 #pragma unroll
         for (uint32_t k = 0; k != kSPL; ++k) asm volatile("" : "+v"(hr.q[k]), "+v"(t3[k]));
         if (tile_big) {
@@ -1386,7 +1414,9 @@ __device__ __forceinline__ void decode_unit_multi(const decode_args& a, const wa
         dd.pad = 0;
         uint32_t* const out = a.out + out_off + done;
         ch.more = done + bsize < n;
-        pos = decode_segment<0, 1, 1, -1>(a, c, dd, pos + 1, bsize, out, ch, pf, narrow, chained);
+        pos = decode_segment<0, 1, 1, -1>(a, c, dd, pos + 1, bsize, out, ch, pf, narrow, chained,
+                                          a.unit_base ? a.unit_base + unit_index : nullptr,
+                                          a.unit_base ? a.gaps_left + unit_index : nullptr);
         done += bsize;
     }
     if (a.end_off && lane == 0) a.end_off[unit_index] = pos;
@@ -1407,7 +1437,8 @@ __device__ __forceinline__ decode_args own_scalars(const decode_args& k) {
                  "+s"(a.dict.first.meta_base), "+s"(a.dict.first.hot_base), "+s"(a.dict.first.hot_k));
     asm volatile("" : "+s"(a.enc), "+s"(a.enc_bytes), "+s"(a.units), "+s"(a.n_units), "+s"(a.out),
                  "+s"(a.out_capacity), "+s"(a.end_off), "+s"(a.queue), "+s"(a.n_shards), "+s"(a.only_full));
-    asm volatile("" : "+s"(a.sched), "+s"(a.items), "+s"(a.n_items), "+s"(a.item_cnt), "+s"(a.spans), "+s"(a.plus_one));
+    asm volatile("" : "+s"(a.sched), "+s"(a.items), "+s"(a.n_items), "+s"(a.item_cnt), "+s"(a.spans), "+s"(a.plus_one),
+                 "+s"(a.unit_base), "+s"(a.gaps_left));
     return a;
 }
 
@@ -1517,7 +1548,7 @@ __global__ __launch_bounds__(kBlockThreads, DINT_MIN_WAVES) void decode_multi_ke
 // unit table for the docs parts (in_off from the block table) or for the freqs parts (in_off =
 // where the docs part ended)
 __global__ void blocks_to_units_kernel(const dint_block_ref* blocks, const uint64_t* docs_end, uint64_t n_blocks,
-                                       uint64_t index_bytes, dint_unit* units, uint32_t* spans) {
+                                       uint64_t index_bytes, dint_unit* units, uint32_t* spans, uint32_t* bases = nullptr) {
     const uint64_t b = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (b >= n_blocks) return;
     dint_unit u;
@@ -1531,6 +1562,15 @@ __global__ void blocks_to_units_kernel(const dint_block_ref* blocks, const uint6
     u.n = blocks[b].n;
     u.list = blocks[b].list;
     units[b] = u;
+    if (bases) bases[b] = blocks[b].base;
+}
+
+// After a table's first decode the docs parts' ends are known: their byte spans become exact (they were "up to
+// the next block", freqs bytes included), and later launches pack four to six docs parts to a tile instead of two.
+__global__ void exact_spans_kernel(const dint_unit* units, const uint64_t* ends, uint64_t n_blocks, uint32_t* spans) {
+    const uint64_t b = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    if (units[b].n == 256 && ends[b] > units[b].in_off && ends[b] - units[b].in_off < spans[b]) spans[b] = uint32_t(ends[b] - units[b].in_off);
 }
 
 // Binary interpolative decode of the blocks shorter than 256 (include/ds2i/interpolative_coding.hpp:
@@ -1574,6 +1614,34 @@ struct tail_bits {
     }
 };
 
+// One block of n < 256 integers in binary interpolative code at p -> its prefix sums in o[0 .. n) (o[n - 1] = sum);
+// returns the bytes consumed. The reference recurses node - left subtree - right subtree
+// (interpolative_coding.hpp:128-146); here an explicit stack (frames of 4 words in LDS) is walked in that order.
+// (A variant with the bit reader one word ahead and the left child taken without a trip through the stack was
+// measured: a third slower — the kernel lives on how many of these lanes are in flight, not on their length.)
+__device__ __forceinline__ uint64_t interpolative_prefix_sums(const uint8_t* p, uint64_t limit, uint32_t n, uint32_t sum, uint32_t* o,
+                                                            uint32_t* stack) {
+    o[n - 1] = sum;
+    if (n <= 1) return 0;
+    tail_bits br{p, limit, 0, 0, 0, 0};
+    uint32_t top = 0;
+    auto push = [&](uint32_t off, uint32_t cnt, uint32_t low, uint32_t high) {
+        uint32_t* f = stack + 4 * top++;
+        f[0] = off, f[1] = cnt, f[2] = low, f[3] = high;
+    };
+    push(0, n - 1, 0, sum);
+    while (top) {
+        const uint32_t* f = stack + 4 * --top;
+        const uint32_t f_off = f[0], f_n = f[1], f_low = f[2], f_high = f[3];
+        const uint32_t h = f_n / 2;
+        const uint32_t val = f_low + br.read_int(f_high - f_low + 1);
+        o[f_off + h] = val;
+        if (f_n - h - 1) push(f_off + h + 1, f_n - h - 1, val, f_high);
+        if (h) push(f_off, h, f_low, val);
+    }
+    return (br.pos + 7) / 8;
+}
+
 // The short blocks are one in fifteen of a block table; collected first, so that the bit-serial decoder
 // below runs with full wavefronts (scattered over the table, four active lanes per wave made every
 // wave last as long as its slowest decode).
@@ -1584,86 +1652,95 @@ __global__ void collect_tails_kernel(const dint_block_ref* blocks, uint64_t n_bl
     if (n != 0 && n < 256) tails[atomicAdd(n_tails, 1u)] = uint32_t(b);
 }
 
-// One wavefront per 64 short blocks, one block per lane. The decoder's values and its explicit stack
+// One wavefront per kTailLanes short blocks, one block per lane. The decoder's values and its explicit stack
 // live in LDS (rows of odd stride: lane-private and conflict-free); the block is differenced there and
 // the wave then copies the rows out together, coalesced — no pass over global memory but that one.
-constexpr uint32_t kTailRow = 257;     // words per lane: up to 255 values
+// (8 blocks to a wave, not 64: the decoder is bit-serial and a wave lasts as long as its longest block, so what
+// counts is how many waves the chip has to overlap — one short block in fifteen leaves it far from full.)
+// What a launch decodes: the docs parts (docs_end null; as_docids: written as docIDs — the code IS the prefix
+// sums), or the freqs parts (docs_end = where each block's docs part ended; sum_of_values = -1: a vbyte of the sum
+// first), or — freqs_out set — both, the freqs part right behind its docs part in the same lane.
+#ifndef DINT_TAIL_LANES
+#define DINT_TAIL_LANES 8
+#endif
+constexpr uint32_t kTailLanes = DINT_TAIL_LANES;
+constexpr uint32_t kTailRow = 257;     // words per lane and row: up to 255 values
 constexpr uint32_t kTailStack = 41;    // words per lane: 10 frames of 4 (depth <= log2(256) + 1)
-constexpr uint32_t kTailLdsBytes = 64 * (kTailRow + kTailStack) * 4;
+constexpr uint32_t kTailLdsBytes = kTailLanes * (kTailRow + kTailStack) * 4;
 
 __global__ __launch_bounds__(64) void interpolative_tails_kernel(const uint8_t* index, uint64_t index_bytes,
                                                                  const dint_block_ref* blocks, const uint64_t* docs_end,
                                                                  const uint32_t* tails, const uint32_t* n_tails, uint32_t* out,
-                                                                 uint64_t out_capacity, uint64_t* end_off, uint32_t plus_one) {
+                                                                 uint64_t out_capacity, uint64_t* end_off, uint32_t plus_one,
+                                                                 uint32_t as_docids = 0, uint32_t* freqs_out = nullptr) {
     extern __shared__ __attribute__((aligned(16))) uint32_t tail_lds[];
-    __shared__ uint32_t row_n[64];
-    __shared__ uint64_t row_out[64];
+    __shared__ uint32_t row_n[kTailLanes], row_base[kTailLanes];
+    __shared__ uint64_t row_out[kTailLanes];
     const uint32_t lane = threadIdx.x;
-    if (uint64_t(blockIdx.x) * 64 >= *n_tails) return;  // (the grid is sized for the worst case)
-    const uint64_t t = uint64_t(blockIdx.x) * 64 + lane;
-    uint32_t* const o = tail_lds + lane * kTailRow;
-    uint32_t* const stack = tail_lds + 64 * kTailRow + lane * kTailStack;
+    if (uint64_t(blockIdx.x) * kTailLanes >= *n_tails) return;  // (the grid may be sized for the worst case)
+    const uint64_t t = uint64_t(blockIdx.x) * kTailLanes + lane;
+    uint32_t* const o = tail_lds + (lane % kTailLanes) * kTailRow;
+    uint32_t* const stack = tail_lds + kTailLanes * kTailRow + (lane % kTailLanes) * kTailStack;
     uint32_t n = 0;
     uint64_t b = 0;
-    if (t < *n_tails) {
+    if (lane < kTailLanes && t < *n_tails) {
         b = tails[t];
         n = blocks[b].n;
         if (n >= 256 || blocks[b].out_off + n > out_capacity) n = 0;
     }
-    row_n[lane] = n;
-    row_out[lane] = n ? blocks[b].out_off : 0;
+    if (lane < kTailLanes) {
+        row_n[lane] = n;
+        row_out[lane] = n ? blocks[b].out_off : 0;
+        row_base[lane] = n ? blocks[b].base : 0;
+    }
+    auto vbyte_sum = [&](uint64_t& at) {  // sum_of_values = -1 -> TightVariableByte sum first
+        uint32_t sum = 0;
+        for (uint32_t shift = 0; at < index_bytes; shift += 7) {
+            const uint8_t c = index[at++];
+            sum += uint32_t(c & 127) << (shift & 31);
+            if (c & 128) break;
+        }
+        return sum;
+    };
+    uint64_t pos = 0;
     if (n != 0) {
-        uint64_t pos = docs_end ? docs_end[b] : blocks[b].in_off;
-        uint32_t sum;
-        if (docs_end) {  // freqs: sum_of_values = -1 -> TightVariableByte sum first
-            sum = 0;
-            for (uint32_t shift = 0; pos < index_bytes; shift += 7) {
-                const uint8_t c = index[pos++];
-                sum += uint32_t(c & 127) << (shift & 31);
-                if (c & 128) break;
-            }
-        } else {
-            sum = blocks[b].max - blocks[b].base - (n - 1);
-        }
-        o[n - 1] = sum;
-        uint64_t used = 0;
-        if (n > 1) {
-            tail_bits br{index + pos, index_bytes - pos, 0, 0, 0, 0};
-            uint32_t top = 0;
-            auto push = [&](uint32_t off, uint32_t cnt, uint32_t low, uint32_t high) {
-                uint32_t* f = stack + 4 * top++;
-                f[0] = off, f[1] = cnt, f[2] = low, f[3] = high;
-            };
-            push(0, n - 1, 0, sum);
-            while (top) {
-                const uint32_t* f = stack + 4 * --top;
-                const uint32_t f_off = f[0], f_n = f[1], f_low = f[2], f_high = f[3];
-                const uint32_t h = f_n / 2;
-                const uint32_t val = f_low + br.read_int(f_high - f_low + 1);
-                o[f_off + h] = val;
-                if (f_n - h - 1) push(f_off + h + 1, f_n - h - 1, val, f_high);
-                if (h) push(f_off, h, f_low, val);
-            }
+        pos = docs_end ? docs_end[b] : blocks[b].in_off;
+        const uint32_t sum = docs_end ? vbyte_sum(pos) : blocks[b].max - blocks[b].base - (n - 1);
+        pos += interpolative_prefix_sums(index + pos, index_bytes - pos, n, sum, o, stack);
+        // (the code stores prefix sums: docID i of the block is base + prefix_i + i — no differencing then)
+        if (!as_docids)
             for (uint32_t i = n - 1; i > 0; --i) o[i] -= o[i - 1];
-            used = (br.pos + 7) / 8;
-        }
-        if (end_off) end_off[b] = pos + used;
+        if (end_off) end_off[b] = pos;
     }
     __syncthreads();
-    for (uint32_t j = 0; j != 64; ++j) {  // rows out, the whole wave on one row at a time
+    for (uint32_t j = 0; j != kTailLanes; ++j) {  // rows out, the whole wave on one row at a time
         const uint32_t nj = row_n[j];
         uint32_t* const dst = out + row_out[j];
-        for (uint32_t i = lane; i < nj; i += 64) dst[i] = tail_lds[j * kTailRow + i] + plus_one;
+        const uint32_t add = as_docids ? row_base[j] : plus_one;
+        for (uint32_t i = lane; i < nj; i += 64) dst[i] = tail_lds[j * kTailRow + i] + add + (as_docids ? i : 0u);
+    }
+    if (!freqs_out) return;
+    __syncthreads();  // the rows are free again: the freqs parts, right behind the docs parts
+    if (n != 0) {
+        const uint32_t fsum = vbyte_sum(pos);
+        interpolative_prefix_sums(index + pos, index_bytes - pos, n, fsum, o, stack);
+        for (uint32_t i = n - 1; i > 0; --i) o[i] -= o[i - 1];
+    }
+    __syncthreads();
+    for (uint32_t j = 0; j != kTailLanes; ++j) {
+        const uint32_t nj = row_n[j];
+        for (uint32_t i = lane; i < nj; i += 64) freqs_out[row_out[j] + i] = tail_lds[j * kTailRow + i] + 1u;
     }
 }
 
 // gaps -> docIDs (docid_i = base + sum_{j<=i} gap_j + i, dict_posting_list.hpp:111-124) and
 // freq - 1 -> freq; one wave per block, 4 consecutive postings per lane.
 __global__ void finalize_postings_kernel(const dint_block_ref* blocks, uint64_t n_blocks, uint32_t* docids,
-                                         uint32_t* freqs, uint64_t out_capacity) {
+                                         uint32_t* freqs, uint64_t out_capacity, const uint8_t* todo = nullptr) {
     const uint32_t lane = lane_id();
     const uint64_t b = (uint64_t(blockIdx.x) * blockDim.x + threadIdx.x) / kWave;
     if (b >= n_blocks) return;
+    if (todo && !todo[b]) return;  // (the decode kernels left docIDs already)
     const uint32_t n = blocks[b].n;
     const uint64_t at = blocks[b].out_off;
     if (n == 0 || n > 256 || at + n > out_capacity) return;
@@ -1682,6 +1759,36 @@ __global__ void finalize_postings_kernel(const dint_block_ref* blocks, uint64_t 
         if (i < n) {
             docids[at + i] = run;
             if (freqs) freqs[at + i] += 1;
+        }
+    }
+}
+
+// The same for the few blocks the decode kernels had to leave as gaps (flags in `todo`): one wave per 64 blocks,
+// every lane looks at one flag; the rare block that has it set is summed by the whole wave.
+__global__ __launch_bounds__(64) void finalize_flagged_kernel(const dint_block_ref* blocks, uint64_t n_blocks, uint32_t* docids,
+                                                              uint64_t out_capacity, const uint8_t* todo) {
+    const uint32_t lane = threadIdx.x;
+    const uint64_t b0 = uint64_t(blockIdx.x) * 64;
+    uint64_t flagged = __ballot(b0 + lane < n_blocks && todo[b0 + lane] != 0);
+    while (flagged) {  // wave-uniform
+        const uint64_t b = b0 + uint32_t(__builtin_ctzll(flagged));
+        flagged &= flagged - 1;
+        const uint32_t n = blocks[b].n;
+        const uint64_t at = blocks[b].out_off;
+        if (n == 0 || n > 256 || at + n > out_capacity) continue;
+        uint32_t g[4], local = 0;
+#pragma unroll
+        for (uint32_t k = 0; k != 4; ++k) {
+            const uint32_t i = 4 * lane + k;
+            g[k] = i < n ? docids[at + i] + 1 : 0;
+            local += g[k];
+        }
+        uint32_t run = blocks[b].base + wave_inclusive_sum(local) - local - 1;
+#pragma unroll
+        for (uint32_t k = 0; k != 4; ++k) {
+            const uint32_t i = 4 * lane + k;
+            run += g[k];
+            if (i < n) docids[at + i] = run;
         }
     }
 }

@@ -32,6 +32,7 @@ ABI_SYMBOLS = (
     "dint_decode_units", "dint_decode_list_host", "dint_last_kernel_ms", "dint_recent_kernel_ms",
     "dint_stream_stats_get",
     "dint_decode_block_host", "dint_index_posting_lists", "dint_decode_posting_blocks",
+    "dint_block_table_create", "dint_block_table_destroy", "dint_decode_block_table",
     "dint_query_index_create", "dint_query_index_destroy", "dint_and_queries",
 )
 
@@ -84,6 +85,10 @@ def _load():
     lib.dint_decode_block_host.argtypes = [vp, vp, sz, vp, u32, sz, C.POINTER(sz)]
     lib.dint_index_posting_lists.argtypes = [vp, sz, vp, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(u64)]
     lib.dint_decode_posting_blocks.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, sz, vp]
+    lib.dint_block_table_create.argtypes = [vp, vp, sz, sz, C.POINTER(vp)]
+    lib.dint_block_table_destroy.restype = None
+    lib.dint_block_table_destroy.argtypes = [vp]
+    lib.dint_decode_block_table.argtypes = [vp, vp, vp, sz, vp, vp, vp, sz, vp]
     lib.dint_query_index_create.argtypes = [vp, vp, sz, vp, sz, sz, C.POINTER(vp)]
     lib.dint_query_index_destroy.restype = None
     lib.dint_query_index_destroy.argtypes = [vp]
@@ -254,6 +259,34 @@ def decode_posting_lists(docs_dict: "Dictionary", freqs_dict, index: np.ndarray,
     docids = docids_dev.cpu().numpy().view(np.uint32)[:total]
     freqs = freqs_dev.cpu().numpy().view(np.uint32)[:total] if freqs_dev is not None else None
     return docids, freqs
+
+
+class BlockTable:
+    """A block table prepared once for asynchronous in-index decodes (dint_block_table)."""
+
+    def __init__(self, docs_dict: "Dictionary", blocks: np.ndarray, index_bytes: int):
+        self._h = C.c_void_p()
+        self._blocks = np.ascontiguousarray(blocks)
+        _check(_lib.dint_block_table_create(docs_dict._h, self._blocks.ctypes.data, len(self._blocks), index_bytes,
+                                            C.byref(self._h)), "dint_block_table_create")
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.dint_block_table_destroy(h)
+
+    __del__ = close
+
+    def decode(self, docs_dict, freqs_dict, index_dev, index_bytes, docids_dev, freqs_dev, stream=None):
+        """Enqueue the decode of every block (asynchronous); tensors are CUDA tensors on the dictionaries' device."""
+        import torch
+
+        if stream is None:
+            stream = torch.cuda.current_stream(index_dev.device).cuda_stream
+        _check(_lib.dint_decode_block_table(
+            docs_dict._h, freqs_dict._h if freqs_dict is not None else None, index_dev.data_ptr(), index_bytes, self._h,
+            docids_dev.data_ptr(), freqs_dev.data_ptr() if freqs_dev is not None else None, docids_dev.numel(), stream),
+            "dint_decode_block_table")
 
 
 class QueryIndex:

@@ -165,12 +165,28 @@ int dint_index_posting_lists(const uint8_t* index, size_t index_bytes, const uin
                              size_t n_lists, dint_block_ref** blocks, size_t* n_blocks,
                              uint64_t* total_postings);
 
-/* Device: decode every block of the table to docIDs (and, if d_freqs is not NULL, term
- * frequencies): full blocks through the DINT kernels, blocks shorter than 256 through the
- * binary-interpolative decoder, then gap -> docID prefix sums. d_index / d_blocks / outputs are
- * device pointers on the dictionaries' device; both dictionaries must be of the same kind and
- * live on the same device. The call enqueues on `stream` and returns after synchronising it
- * (its workspace is kept with docs_dict: one call at a time per docs dictionary).
+/* A block table prepared for decoding. What depends on the table alone — the docs parts' unit table and
+ * docID bases, the list of short (interpolative) blocks — is computed once, here; the workspace of a
+ * decode lives in the handle too. `blocks` is the HOST table (dint_index_posting_lists); the handle keeps a
+ * device copy. One decode at a time per handle (calls on one stream are ordered anyway). */
+typedef struct dint_block_table dint_block_table;
+int dint_block_table_create(const dint_dict* docs_dict, const dint_block_ref* blocks, size_t n_blocks,
+                            size_t index_bytes, dint_block_table** out);
+void dint_block_table_destroy(dint_block_table* table);
+
+/* Device: decode every block of the prepared table to docIDs (and, if d_freqs is not NULL, term
+ * frequencies). ASYNCHRONOUS: enqueues on `stream` and returns. Full blocks go through the DINT kernels —
+ * the docID prefix sums are formed in the expansion, one wave scan per block, the gaps never reach memory;
+ * freq = value + 1 is added where the values are stored — blocks shorter than 256 through the
+ * binary-interpolative decoder (whose code is the prefix sums already).
+ * Replaces: see dint_decode_posting_blocks. */
+int dint_decode_block_table(const dint_dict* docs_dict, const dint_dict* freqs_dict, const uint8_t* d_index,
+                            size_t index_bytes, dint_block_table* table, uint32_t* d_docids, uint32_t* d_freqs,
+                            size_t out_capacity, void* stream);
+
+/* One-shot form of the two calls above over a DEVICE block table: prepares, decodes, synchronises
+ * `stream`, releases. d_index / d_blocks / outputs are device pointers on the dictionaries' device;
+ * both dictionaries must be of the same kind and live on the same device.
  * Replaces: document_enumerator::decode_docs_block / decode_freqs_block + the docid
  * accumulation of next() (dict_posting_list.hpp:111-124, 284-318), i.e. dint_block::decode /
  * opt_dint_multi_dict_block::decode (include/dint/dint_codecs.hpp:13-49, 460-510) and

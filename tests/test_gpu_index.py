@@ -62,3 +62,35 @@ def test_block_table_matches_the_list_directories(device, small_corpus):
     # bases chain: base = previous max + 1 inside a list
     same = ~first
     assert np.array_equal(blocks["base"][same], blocks["max"][np.flatnonzero(same) - 1] + 1)
+
+
+@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
+def test_prepared_block_table_decodes_asynchronously(device, small_corpus, kind):
+    """dint_block_table_create + dint_decode_block_table: prepared once, decoded twice on a side stream without a
+    host synchronisation in between; docIDs come straight out of the decode kernels (fused prefix sums)."""
+    import torch
+
+    ix = get_index(small_corpus, kind)
+    blocks, total = device.index_posting_lists(ix.bytes, ix.offsets)
+    dd, fd = device.Dictionary(kind, ix.docs_dict), device.Dictionary(kind, ix.freqs_dict)
+    dev = torch.device("cuda", 0)
+    padded = np.concatenate([ix.bytes, np.zeros(16, np.uint8)])
+    index_dev = torch.from_numpy(padded).to(dev)
+    table = device.BlockTable(dd, blocks, padded.size)
+    side = torch.cuda.Stream(dev)
+    outs = []
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            docids_dev = torch.full((total,), -1, dtype=torch.int32, device=dev)
+            freqs_dev = torch.full((total,), -1, dtype=torch.int32, device=dev)
+            table.decode(dd, fd, index_dev, padded.size, docids_dev, freqs_dev, stream=side.cuda_stream)
+            outs.append((docids_dev, freqs_dev))
+    side.synchronize()
+    for docids_dev, freqs_dev in outs:
+        assert np.array_equal(docids_dev.cpu().numpy().view(np.uint32), ix.docids)
+        assert np.array_equal(freqs_dev.cpu().numpy().view(np.uint32), ix.freqs)
+    # docs only
+    docids_dev = torch.empty(total, dtype=torch.int32, device=dev)
+    table.decode(dd, None, index_dev, padded.size, docids_dev, None)
+    torch.cuda.synchronize()
+    assert np.array_equal(docids_dev.cpu().numpy().view(np.uint32), ix.docids)

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""In-index decode: every posting of an index in the dict_posting_list layout
+-> docIDs and freqs on the device, through a prepared block table (dint_block_table), timed with HIP events
+around the enqueued launches. usage: tools/inindex_bench.py [postings] [out.json]"""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT]
+import numpy as np, torch
+from dint_amd import host, device
+
+postings = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100_000_000
+out_path = sys.argv[2] if len(sys.argv) > 2 else None
+dev = torch.device("cuda:0")
+sub = host.synth_collection(postings, universe=25_000_000, seed=777)
+docids = host.gaps_to_docids(sub); freqs = host.synth_freqs(sub.num_postings, 5)
+res = {"postings": int(sub.num_postings), "lists": int(np.count_nonzero(sub.lens))}
+for typ in ("single_packed_dint", "multi_packed_dint"):
+    kind = host.KIND_BY_TYPE[typ]
+    dd = host.build_dictionary(kind, sub, max_sample_ints=20_000_000)
+    fd = host.build_dictionary(kind, host.Collection(freqs - 1, sub.lens), max_sample_ints=20_000_000)
+    idx, offs = host.build_index(kind, dd, fd, docids, freqs, sub.lens)
+    blocks, total = device.index_posting_lists(idx, offs)
+    D, F = device.Dictionary(kind, dd), device.Dictionary(kind, fd)
+    padded = np.concatenate([idx, np.zeros(16, dtype=np.uint8)])
+    index_dev = torch.from_numpy(padded).to(dev)
+    docs_dev = torch.empty(total, dtype=torch.int32, device=dev); freqs_dev = torch.empty(total, dtype=torch.int32, device=dev)
+    table = device.BlockTable(D, blocks, padded.size)
+    r = {"bits_per_posting": round(idx.size * 8 / total, 3), "blocks": int(len(blocks)), "short_blocks": int((blocks["n"] < 256).sum())}
+    for label, fdev in (("docs_and_freqs", freqs_dev), ("docs_only", None)):
+        ms = []
+        for i in range(8):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            table.decode(D, F if fdev is not None else None, index_dev, padded.size, docs_dev, fdev)
+            e1.record(); torch.cuda.synchronize()
+            ms.append(e0.elapsed_time(e1))
+        m = float(np.median(ms[2:]))
+        algo = total * (8 if fdev is not None else 4) + idx.size * (1.0 if fdev is not None else 0.5)
+        r[label] = {"ms": round(m, 4), "ms_all": [round(x, 4) for x in ms], "G_postings_per_s": round(total / m / 1e6, 1),
+                    "algorithmic_GBps": round(algo / m / 1e6, 1), "frac_of_8TBps": round(algo / m / 1e6 / 8000, 4)}
+    r["bit_exact"] = bool(np.array_equal(docs_dev.cpu().numpy().view(np.uint32), docids)) and \
+        bool(np.array_equal(freqs_dev.cpu().numpy().view(np.uint32), freqs))
+    res[typ] = r
+    print(typ, json.dumps(r), flush=True)
+    del table
+if out_path:
+    json.dump(res, open(out_path, "w"), indent=1)
