@@ -415,10 +415,12 @@ struct dint_query_index {
     uint32_t* d_rank = nullptr;     // n_blocks
     uint32_t* d_touched = nullptr;  // n_blocks
     uint32_t* d_n_touched = nullptr;
-    device_buffer<uint32_t> page_block, page_query, term_first, term_blocks, cand, target, probe, tails;
+    device_buffer<uint32_t> page_block, page_query, term_first, term_blocks, cand, target, probe, fprobe, tails, spans, bases;
     device_buffer<dint_block_ref> sub;
     device_buffer<dint_unit> units;
-    device_buffer<unsigned long long> counts;
+    device_buffer<uint64_t> ends;
+    device_buffer<uint8_t> gaps_left;
+    device_buffer<unsigned long long> counts, freq_sums;
     std::mutex mutex;
 };
 
@@ -957,6 +959,12 @@ void dint_query_index_destroy(dint_query_index* qi) {
     qi->target.release();
     qi->probe.release();
     qi->tails.release();
+    qi->fprobe.release();
+    qi->spans.release();
+    qi->bases.release();
+    qi->ends.release();
+    qi->gaps_left.release();
+    qi->freq_sums.release();
     qi->sub.release();
     qi->units.release();
     qi->counts.release();
@@ -1011,32 +1019,60 @@ int dint_query_index_create(const dint_dict* docs_dict, const uint8_t* d_index, 
     return DINT_OK;
 }
 
-// docs parts of the pages of `sub` -> docIDs, 256 slots per page (no freqs, no sync)
-static int decode_doc_pages(dint_query_index* qi, size_t n_pages, uint32_t* d_out, hipStream_t s) {
-    if (!qi->units.ensure(n_pages)) return DINT_ERR_HIP;
+// The pages of `sub` decoded, 256 slots per page, no sync: docs parts -> docIDs in d_docs (formed in the decode
+// kernels' expansion, like dint_decode_block_table) and, with a freqs dictionary, freqs parts -> d_freqs.
+static int decode_pages(dint_query_index* qi, size_t n_pages, uint32_t* d_docs, const dint_dict* freqs_dict, uint32_t* d_freqs,
+                        hipStream_t s) {
+    if (!qi->units.ensure(n_pages) || !qi->spans.ensure(n_pages) || !qi->bases.ensure(n_pages) || !qi->ends.ensure(n_pages) ||
+        !qi->gaps_left.ensure(n_pages) || !qi->tails.ensure(n_pages + 1))
+        return DINT_ERR_HIP;
     const uint32_t tb = 256;
     const uint32_t grid = uint32_t((n_pages + tb - 1) / tb);
     const uint64_t cap = uint64_t(n_pages) * kPageSlots;
-    hipLaunchKernelGGL(blocks_to_units_kernel, dim3(grid), dim3(tb), 0, s, qi->sub.p, nullptr, uint64_t(n_pages),
-                       uint64_t(qi->index_bytes), qi->units.p, static_cast<uint32_t*>(nullptr));
-    const int st = launch_decode(qi->docs, qi->d_index, qi->index_bytes, qi->units.p, n_pages, d_out, cap, nullptr, s, 1);
-    if (st != DINT_OK) return st;
-    if (!qi->tails.ensure(n_pages + 1)) return DINT_ERR_HIP;
+    HIP_TRY(hipMemsetAsync(qi->gaps_left.p, 0, n_pages, s));
     HIP_TRY(hipMemsetAsync(qi->tails.p + n_pages, 0, 4, s));
+    hipLaunchKernelGGL(blocks_to_units_kernel, dim3(grid), dim3(tb), 0, s, qi->sub.p, static_cast<const uint64_t*>(nullptr),
+                       uint64_t(n_pages), uint64_t(qi->index_bytes), qi->units.p, qi->spans.p, qi->bases.p);
     hipLaunchKernelGGL(collect_tails_kernel, dim3(grid), dim3(tb), 0, s, qi->sub.p, uint64_t(n_pages), qi->tails.p,
                        qi->tails.p + n_pages);
-    hipLaunchKernelGGL(interpolative_tails_kernel, dim3(uint32_t((n_pages + kTailLanes - 1) / kTailLanes)), dim3(64), kTailLdsBytes, s, qi->d_index,
-                       uint64_t(qi->index_bytes), qi->sub.p, nullptr, qi->tails.p, qi->tails.p + n_pages, d_out, cap, nullptr, 0u);
-    const uint32_t wgrid = uint32_t((n_pages * kWave + tb - 1) / tb);
-    hipLaunchKernelGGL(finalize_postings_kernel, dim3(wgrid), dim3(tb), 0, s, qi->sub.p, uint64_t(n_pages), d_out,
-                       nullptr, cap);
+    int st = launch_decode(qi->docs, qi->d_index, qi->index_bytes, qi->units.p, n_pages, d_docs, cap, qi->ends.p, s, 1, qi->spans.p, 0,
+                           qi->bases.p, qi->gaps_left.p);
+    if (st != DINT_OK) return st;
+    if (freqs_dict) {  // freqs parts of the full blocks: from where their docs parts ended
+        hipLaunchKernelGGL(blocks_to_units_kernel, dim3(grid), dim3(tb), 0, s, qi->sub.p, qi->ends.p, uint64_t(n_pages),
+                           uint64_t(qi->index_bytes), qi->units.p, qi->spans.p, static_cast<uint32_t*>(nullptr));
+        st = launch_decode(freqs_dict, qi->d_index, qi->index_bytes, qi->units.p, n_pages, d_freqs, cap, nullptr, s, 1, qi->spans.p, 1);
+        if (st != DINT_OK) return st;
+    }
+    // (the grid is sized for "every page is a short block"; the waves past the list's end leave at once)
+    hipLaunchKernelGGL(interpolative_tails_kernel, dim3(uint32_t((n_pages + kTailLanes - 1) / kTailLanes)), dim3(64), kTailLdsBytes, s,
+                       qi->d_index, uint64_t(qi->index_bytes), qi->sub.p, static_cast<const uint64_t*>(nullptr), qi->tails.p,
+                       qi->tails.p + n_pages, d_docs, cap, static_cast<uint64_t*>(nullptr), 0u, 1u, freqs_dict ? d_freqs : nullptr);
+    hipLaunchKernelGGL(finalize_flagged_kernel, dim3(uint32_t((n_pages + 63) / 64)), dim3(64), 0, s, qi->sub.p, uint64_t(n_pages), d_docs,
+                       cap, qi->gaps_left.p);
     HIP_TRY(hipGetLastError());
     return DINT_OK;
 }
 
+static int and_queries_impl(dint_query_index* qi, const dint_dict* freqs_dict, const uint32_t* terms, const uint64_t* query_offsets,
+                            size_t n_queries, uint64_t* counts, uint64_t* freq_sums, uint64_t* freq_blocks, void* stream);
+
 int dint_and_queries(dint_query_index* qi, const uint32_t* terms, const uint64_t* query_offsets, size_t n_queries,
                      uint64_t* counts, void* stream) {
+    return and_queries_impl(qi, nullptr, terms, query_offsets, n_queries, counts, nullptr, nullptr, stream);
+}
+
+int dint_and_queries_freqs(dint_query_index* qi, const dint_dict* freqs_dict, const uint32_t* terms, const uint64_t* query_offsets,
+                           size_t n_queries, uint64_t* counts, uint64_t* freq_sums, uint64_t* freq_blocks_decoded, void* stream) {
+    if (!freqs_dict || !freq_sums) return DINT_ERR_ARG;
+    if (qi && (freqs_dict->device != qi->docs->device || freqs_dict->kind != qi->docs->kind)) return DINT_ERR_ARG;
+    return and_queries_impl(qi, freqs_dict, terms, query_offsets, n_queries, counts, freq_sums, freq_blocks_decoded, stream);
+}
+
+static int and_queries_impl(dint_query_index* qi, const dint_dict* freqs_dict, const uint32_t* terms, const uint64_t* query_offsets,
+                            size_t n_queries, uint64_t* counts, uint64_t* freq_sums, uint64_t* freq_blocks, void* stream) {
     if (!qi || (n_queries && (!query_offsets || !counts))) return DINT_ERR_ARG;
+    if (freq_blocks) *freq_blocks = 0;
     if (n_queries == 0) return DINT_OK;
     if (n_queries >= 0xFFFFFFFFull) return DINT_ERR_ARG;
     const size_t n_lists = qi->list_len.size();
@@ -1054,6 +1090,7 @@ int dint_and_queries(dint_query_index* qi, const uint32_t* terms, const uint64_t
         t.erase(std::unique(t.begin(), t.end()), t.end());
         std::stable_sort(t.begin(), t.end(), [&](uint32_t a, uint32_t b) { return qi->list_len[a] < qi->list_len[b]; });
         counts[q] = 0;
+        if (freq_sums) freq_sums[q] = 0;
         if (t.empty()) continue;
         rounds = std::max(rounds, t.size() - 1);
         for (uint32_t b = qi->list_first[t[0]]; b != qi->list_first[t[0] + 1]; ++b) {
@@ -1091,7 +1128,9 @@ int dint_and_queries(dint_query_index* qi, const uint32_t* terms, const uint64_t
     // candidates: the rarest list of every query
     hipLaunchKernelGGL(gather_pages_kernel, dim3(page_grid), dim3(tb), 0, s, qi->d_blocks, qi->page_block.p,
                        uint64_t(n_pages), qi->sub.p);
-    int st = decode_doc_pages(qi, n_pages, qi->cand.p, s);
+    // (a failure between and_search_kernel and and_release_kernel would leave claim flags behind: start clean)
+    HIP_TRY(hipMemsetAsync(qi->d_needed, 0, std::max<size_t>(1, qi->n_blocks) * 4, s));
+    int st = decode_pages(qi, n_pages, qi->cand.p, nullptr, nullptr, s);
     if (st != DINT_OK) {
         (void)hipStreamSynchronize(s);
         return st;
@@ -1116,7 +1155,7 @@ int dint_and_queries(dint_query_index* qi, const uint32_t* terms, const uint64_t
         const uint32_t tgrid = (n_touched + tb - 1) / tb;
         hipLaunchKernelGGL(gather_pages_kernel, dim3(tgrid), dim3(tb), 0, s, qi->d_blocks, qi->d_touched,
                            uint64_t(n_touched), qi->sub.p);
-        st = decode_doc_pages(qi, n_touched, qi->probe.p, s);
+        st = decode_pages(qi, n_touched, qi->probe.p, nullptr, nullptr, s);
         if (st != DINT_OK) {
             (void)hipStreamSynchronize(s);
             return st;
@@ -1128,10 +1167,53 @@ int dint_and_queries(dint_query_index* qi, const uint32_t* terms, const uint64_t
     hipLaunchKernelGGL(and_count_kernel, dim3(slot_grid), dim3(tb), 0, s, qi->cand.p, n_slots, qi->page_query.p,
                        qi->counts.p);
     HIP_TRY(hipGetLastError());
+    // ---- and_query<true> (queries.hpp:72-76): the freq of every term at every match. Lazily, like the reference's
+    // freq(): a freqs part is decoded only for the blocks that hold a match — term by term, the blocks the
+    // matches fall into (for the rarest term: the candidate pages themselves), their docs and freqs parts, then
+    // every match reads its freq at the position of its docID.
+    std::vector<unsigned long long> h_sums;
+    if (freqs_dict) {
+        if (!qi->freq_sums.ensure(n_queries)) return DINT_ERR_HIP;
+        HIP_TRY(hipMemsetAsync(qi->freq_sums.p, 0, n_queries * sizeof(unsigned long long), s));
+        for (size_t r = 0; r != rounds + 1; ++r) {  // r = 0: the rarest term; r >= 1: the term of round r - 1
+            const uint32_t* first = r ? qi->term_first.p + (r - 1) * n_queries : nullptr;
+            const uint32_t* nblk = r ? qi->term_blocks.p + (r - 1) * n_queries : nullptr;
+            HIP_TRY(hipMemsetAsync(qi->d_n_touched, 0, 4, s));
+            hipLaunchKernelGGL(and_freq_search_kernel, dim3(slot_grid), dim3(tb), 0, s, qi->cand.p, n_slots, qi->page_query.p,
+                               qi->page_block.p, first, nblk, qi->d_block_max, qi->target.p, qi->d_needed, qi->d_rank,
+                               qi->d_touched, qi->d_n_touched);
+            uint32_t n_touched = 0;
+            HIP_TRY(hipMemcpyAsync(&n_touched, qi->d_n_touched, 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (n_touched == 0) continue;
+            if (freq_blocks) *freq_blocks += n_touched;
+            if (!qi->sub.ensure(std::max<size_t>(n_pages, n_touched)) || !qi->probe.ensure(uint64_t(n_touched) * kPageSlots) ||
+                !qi->fprobe.ensure(uint64_t(n_touched) * kPageSlots)) {
+                (void)hipStreamSynchronize(s);
+                return DINT_ERR_HIP;
+            }
+            const uint32_t tgrid = (n_touched + tb - 1) / tb;
+            hipLaunchKernelGGL(gather_pages_kernel, dim3(tgrid), dim3(tb), 0, s, qi->d_blocks, qi->d_touched, uint64_t(n_touched),
+                               qi->sub.p);
+            st = decode_pages(qi, n_touched, qi->probe.p, freqs_dict, qi->fprobe.p, s);
+            if (st != DINT_OK) {
+                (void)hipStreamSynchronize(s);
+                return st;
+            }
+            hipLaunchKernelGGL(and_freq_gather_kernel, dim3(slot_grid), dim3(tb), 0, s, qi->cand.p, n_slots, qi->page_query.p, nblk,
+                               qi->d_blocks, qi->target.p, qi->d_rank, qi->probe.p, qi->fprobe.p, qi->freq_sums.p);
+            hipLaunchKernelGGL(and_release_kernel, dim3(tgrid), dim3(tb), 0, s, qi->d_touched, n_touched, qi->d_needed);
+        }
+        HIP_TRY(hipGetLastError());
+        h_sums.resize(n_queries);
+        HIP_TRY(hipMemcpyAsync(h_sums.data(), qi->freq_sums.p, n_queries * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    }
     std::vector<unsigned long long> h_counts(n_queries);
     HIP_TRY(hipMemcpyAsync(h_counts.data(), qi->counts.p, n_queries * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     for (size_t q = 0; q != n_queries; ++q) counts[q] = h_counts[q];
+    if (freqs_dict)
+        for (size_t q = 0; q != n_queries; ++q) freq_sums[q] = h_sums[q];
     return DINT_OK;
 }
 

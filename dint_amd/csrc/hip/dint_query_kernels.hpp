@@ -102,6 +102,53 @@ __global__ void and_probe_kernel(uint32_t* cand, uint64_t n_slots, const uint32_
     if (pos == n || page[pos] != c) cand[i] = kDeadCandidate;
 }
 
+// and_query<true>, step A per term: the block each match (surviving candidate) falls into — for the rarest term
+// (first == nullptr) the candidate page's own block — claimed once, as in and_search_kernel.
+__global__ void and_freq_search_kernel(const uint32_t* cand, uint64_t n_slots, const uint32_t* page_query, const uint32_t* page_block,
+                                       const uint32_t* term_first, const uint32_t* term_blocks, const uint32_t* block_max,
+                                       uint32_t* target, uint32_t* needed, uint32_t* rank, uint32_t* touched, uint32_t* n_touched) {
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    uint32_t gb = kDeadCandidate;
+    if (i < n_slots) {
+        const uint32_t c = cand[i];
+        if (c != kDeadCandidate) {
+            if (!term_first) {
+                gb = page_block[i / kPageSlots];
+            } else {
+                const uint32_t q = page_query[i / kPageSlots];
+                const uint32_t nb = term_blocks[q];
+                if (nb) gb = term_first[q] + lower_bound_u32(block_max + term_first[q], nb, c);  // (a match: always found)
+            }
+            target[i] = gb;
+        }
+    }
+    const uint32_t prev = __shfl_up(gb, 1);
+    const bool lead = gb != kDeadCandidate && ((threadIdx.x & 63u) == 0 || prev != gb);
+    if (lead && atomicExch(&needed[gb], 1u) == 0u) {
+        const uint32_t k = atomicAdd(n_touched, 1u);
+        touched[k] = gb;
+        rank[gb] = k;
+    }
+}
+
+// ... step B: every match finds its docID in its block's decoded page and adds the freq at that position to its query's
+// sum (document_enumerator::freq(), dict_posting_list.hpp:164-169; queries.hpp:72-76 reads one per term and match).
+__global__ void and_freq_gather_kernel(const uint32_t* cand, uint64_t n_slots, const uint32_t* page_query, const uint32_t* term_blocks,
+                                       const dint_block_ref* blocks, const uint32_t* target, const uint32_t* rank,
+                                       const uint32_t* probe, const uint32_t* fprobe, unsigned long long* freq_sums) {
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n_slots) return;
+    const uint32_t c = cand[i];
+    if (c == kDeadCandidate) return;
+    const uint32_t q = page_query[i / kPageSlots];
+    if (term_blocks && term_blocks[q] == 0) return;  // the query has no such term
+    const uint32_t gb = target[i];
+    const uint32_t n = blocks[gb].n;
+    const uint64_t page = uint64_t(rank[gb]) * kPageSlots;
+    const uint32_t pos = lower_bound_u32(probe + page, n, c);
+    if (pos < n && probe[page + pos] == c) atomicAdd(&freq_sums[q], (unsigned long long)fprobe[page + pos]);
+}
+
 __global__ void and_release_kernel(const uint32_t* touched, uint32_t n_touched, uint32_t* needed) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n_touched) needed[touched[k]] = 0;

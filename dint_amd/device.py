@@ -33,7 +33,7 @@ ABI_SYMBOLS = (
     "dint_stream_stats_get",
     "dint_decode_block_host", "dint_index_posting_lists", "dint_decode_posting_blocks",
     "dint_block_table_create", "dint_block_table_destroy", "dint_decode_block_table",
-    "dint_query_index_create", "dint_query_index_destroy", "dint_and_queries",
+    "dint_query_index_create", "dint_query_index_destroy", "dint_and_queries", "dint_and_queries_freqs",
 )
 
 #: dint_block_ref (include/dint_hip.h)
@@ -93,6 +93,7 @@ def _load():
     lib.dint_query_index_destroy.restype = None
     lib.dint_query_index_destroy.argtypes = [vp]
     lib.dint_and_queries.argtypes = [vp, vp, vp, sz, vp, vp]
+    lib.dint_and_queries_freqs.argtypes = [vp, vp, vp, vp, sz, vp, vp, C.POINTER(u64), vp]
     lib.dint_debug_wave_scan.argtypes = [vp, vp]
     return lib
 
@@ -328,6 +329,33 @@ class QueryIndex:
         _check(_lib.dint_and_queries(self._h, terms.ctypes.data, offs.ctypes.data, len(queries),
                                      counts.ctypes.data, stream), "dint_and_queries")
         return counts
+
+    def and_queries_with_freqs(self, freqs_dict: "Dictionary", queries):
+        """`and_query<true>` for a batch -> (counts, sums of the freqs read at the matches, freqs blocks decoded)."""
+        return and_queries_with_freqs(self, freqs_dict, queries)
+
+
+def _pack_queries(queries):
+    lens = np.fromiter((len(q) for q in queries), dtype=np.uint64, count=len(queries))
+    offs = np.zeros(len(queries) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=offs[1:])
+    terms = np.ascontiguousarray(np.concatenate([np.asarray(q, dtype=np.uint32) for q in queries])
+                                 if len(queries) else np.zeros(0, np.uint32), dtype=np.uint32)
+    return terms, offs
+
+
+def and_queries_with_freqs(qi: "QueryIndex", freqs_dict: "Dictionary", queries):
+    """and_query<true> for a batch: -> (counts u64[], freq sums u64[], freqs blocks decoded)."""
+    import torch
+
+    terms, offs = _pack_queries(queries)
+    counts = np.zeros(len(queries), dtype=np.uint64)
+    sums = np.zeros(len(queries), dtype=np.uint64)
+    nblocks = C.c_uint64()
+    stream = torch.cuda.current_stream(torch.device("cuda", qi.docs_dict.device)).cuda_stream
+    _check(_lib.dint_and_queries_freqs(qi._h, freqs_dict._h, terms.ctypes.data, offs.ctypes.data, len(queries),
+                                       counts.ctypes.data, sums.ctypes.data, C.byref(nblocks), stream), "dint_and_queries_freqs")
+    return counts, sums, nblocks.value
 
 
 def units_to_device(units: np.ndarray, device):

@@ -217,6 +217,14 @@ void dint_query_index_destroy(dint_query_index* qi);
 int dint_and_queries(dint_query_index* qi, const uint32_t* terms, const uint64_t* query_offsets,
                      size_t n_queries, uint64_t* counts, void* stream);
 
+/* and_query<true> (queries.hpp:72-76): the same counts, and freq_sums[q] = the sum, over the matches of query q and
+ * over its (distinct) terms, of the term's frequency in the matching document — what the reference reads through
+ * document_enumerator::freq() at every match. Lazy like the reference (dict_posting_list.hpp:164-169, :311-318): a
+ * freqs part is decoded only for the blocks that hold a match; *freq_blocks_decoded (nullable) = how many that were. */
+int dint_and_queries_freqs(dint_query_index* qi, const dint_dict* freqs_dict, const uint32_t* terms,
+                           const uint64_t* query_offsets, size_t n_queries, uint64_t* counts, uint64_t* freq_sums,
+                           uint64_t* freq_blocks_decoded, void* stream);
+
 /* Device time (ms) between the two events the library records around the decode kernel of the most
  * recent dint_decode_units on this dictionary (one event pair per in-flight launch: launches on
  * different streams do not disturb each other's); synchronises that launch. */

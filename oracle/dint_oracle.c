@@ -446,6 +446,12 @@ typedef struct {
     uint64_t universe;
     uint32_t cur_block, pos_in_block, cur_block_max, cur_block_size, cur_docid;
     uint32_t docs_buf[BLOCK + 256];
+    /* freqs side (:164-169, :311-318): decoded lazily, once per block, on the first freq() */
+    const oracle_dict* freqs_dict;
+    const uint8_t* freqs_block_data;
+    int freqs_decoded;
+    uint64_t freqs_blocks_decoded;
+    uint32_t freqs_buf[BLOCK + 256];
 } oracle_enum;
 
 static uint32_t en_block_max(const oracle_enum* e, uint32_t b) { return ld32(e->block_maxs + 4 * (size_t)b); }
@@ -457,16 +463,29 @@ static void en_decode_docs_block(oracle_enum* e, uint32_t block) { /* :284-309 *
     uint32_t cur_base = (block ? en_block_max(e, block - 1) : (uint32_t)-1) + 1;
     e->cur_block_max = en_block_max(e, block);
     memset(e->docs_buf, 0, sizeof e->docs_buf);
-    oracle_block_decode(e->dict, block_data, e->docs_buf, e->cur_block_max - cur_base - (e->cur_block_size - 1),
-                        e->cur_block_size);
+    e->freqs_block_data = oracle_block_decode(e->dict, block_data, e->docs_buf,
+                                              e->cur_block_max - cur_base - (e->cur_block_size - 1), e->cur_block_size);
+    e->freqs_decoded = 0;
     e->docs_buf[0] += cur_base;
     e->cur_block = block;
     e->pos_in_block = 0;
     e->cur_docid = e->docs_buf[0];
 }
 
+static uint32_t en_freq(oracle_enum* e) { /* freq(), :164-169; decode_freqs_block, :311-318 */
+    if (!e->freqs_decoded) {
+        memset(e->freqs_buf, 0, sizeof e->freqs_buf);
+        oracle_block_decode(e->freqs_dict, e->freqs_block_data, e->freqs_buf, (uint32_t)-1, e->cur_block_size);
+        e->freqs_decoded = 1;
+        e->freqs_blocks_decoded += 1;
+    }
+    return e->freqs_buf[e->pos_in_block] + 1;
+}
+
 static void en_init(oracle_enum* e, const oracle_dict* d, const uint8_t* data, uint64_t universe) { /* :90-109 */
     e->dict = d;
+    e->freqs_dict = NULL;
+    e->freqs_blocks_decoded = 0;
     const uint8_t* base = oracle_vbyte_read(data, &e->n);
     e->blocks = (e->n + BLOCK - 1) / BLOCK;
     e->block_maxs = base;
@@ -512,9 +531,14 @@ static int cmp_enum_size(const void* a, const void* b) {
     return x->n < y->n ? -1 : x->n > y->n;
 }
 
-/* and_query<false>, include/ds2i/queries.hpp:34-84 */
-uint64_t oracle_and_query(const oracle_dict* docs_dict, const uint8_t* index, const uint64_t* list_offsets,
-                          uint64_t num_docs, const uint32_t* terms_in, size_t n_terms) {
+/* and_query<with_freqs>, include/ds2i/queries.hpp:34-84. freqs_dict != NULL: with_freqs = true — at every match the
+ * freq() of every enumerator is read (:72-76); the reference throws the values away (do_not_optimize_away), here
+ * their sum goes to *freq_sum and the number of freqs blocks that had to be decoded to *freqs_blocks. */
+static uint64_t and_query_impl(const oracle_dict* docs_dict, const oracle_dict* freqs_dict, const uint8_t* index,
+                               const uint64_t* list_offsets, uint64_t num_docs, const uint32_t* terms_in, size_t n_terms,
+                               uint64_t* freq_sum, uint64_t* freqs_blocks) {
+    if (freq_sum) *freq_sum = 0;
+    if (freqs_blocks) *freqs_blocks = 0;
     if (!n_terms) return 0;
     uint32_t* terms = (uint32_t*)malloc(n_terms * 4);
     memcpy(terms, terms_in, n_terms * 4);
@@ -526,6 +550,7 @@ uint64_t oracle_and_query(const oracle_dict* docs_dict, const uint8_t* index, co
     oracle_enum** enums = (oracle_enum**)malloc(m * sizeof(oracle_enum*));
     for (size_t i = 0; i != m; ++i) {
         en_init(&store[i], docs_dict, index + list_offsets[terms[i]], num_docs);
+        store[i].freqs_dict = freqs_dict;
         enums[i] = &store[i];
     }
     qsort(enums, m, sizeof(oracle_enum*), cmp_enum_size); /* sort by increasing frequency, :49-52 */
@@ -543,13 +568,31 @@ uint64_t oracle_and_query(const oracle_dict* docs_dict, const uint8_t* index, co
         }
         if (i == m) {
             results += 1;
+            if (freqs_dict) {
+                for (i = 0; i < m; ++i) *freq_sum += en_freq(enums[i]);
+            }
             en_next(enums[0]);
             candidate = enums[0]->cur_docid;
             i = 1;
         }
     }
+    if (freqs_blocks)
+        for (size_t k = 0; k != m; ++k) *freqs_blocks += store[k].freqs_blocks_decoded;
     free(terms);
     free(store);
     free(enums);
     return results;
+}
+
+uint64_t oracle_and_query(const oracle_dict* docs_dict, const uint8_t* index, const uint64_t* list_offsets,
+                          uint64_t num_docs, const uint32_t* terms_in, size_t n_terms) {
+    return and_query_impl(docs_dict, NULL, index, list_offsets, num_docs, terms_in, n_terms, NULL, NULL);
+}
+
+uint64_t oracle_and_query_freqs(const oracle_dict* docs_dict, const oracle_dict* freqs_dict, const uint8_t* index,
+                                const uint64_t* list_offsets, uint64_t num_docs, const uint32_t* terms_in, size_t n_terms,
+                                uint64_t* freq_sum, uint64_t* freqs_blocks) {
+    uint64_t dummy;
+    return and_query_impl(docs_dict, freqs_dict, index, list_offsets, num_docs, terms_in, n_terms, freq_sum ? freq_sum : &dummy,
+                          freqs_blocks);
 }

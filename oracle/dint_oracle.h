@@ -96,6 +96,13 @@ uint32_t oracle_posting_list_decode(const oracle_dict* docs_dict, const oracle_d
 uint64_t oracle_and_query(const oracle_dict* docs_dict, const uint8_t* index, const uint64_t* list_offsets,
                           uint64_t num_docs, const uint32_t* terms, size_t n_terms);
 
+/* and_query<true>::operator() (queries.hpp:34-84 with :72-76 live): the same count; *freq_sum = sum over the matches and
+ * over the query's enumerators of freq() (document_enumerator::freq, dict_posting_list.hpp:164-169, which decodes the
+ * block's freqs part on first use, :311-318); *freqs_blocks = how many freqs parts were decoded. */
+uint64_t oracle_and_query_freqs(const oracle_dict* docs_dict, const oracle_dict* freqs_dict, const uint8_t* index,
+                                const uint64_t* list_offsets, uint64_t num_docs, const uint32_t* terms_in, size_t n_terms,
+                                uint64_t* freq_sum, uint64_t* freqs_blocks);
+
 #ifdef __cplusplus
 }
 #endif

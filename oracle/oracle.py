@@ -46,6 +46,8 @@ def _load():
     lib.oracle_posting_list_decode.argtypes = [vp, vp, vp, vp, vp]
     lib.oracle_and_query.restype = C.c_uint64
     lib.oracle_and_query.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_size_t]
+    lib.oracle_and_query_freqs.restype = C.c_uint64
+    lib.oracle_and_query_freqs.argtypes = [vp, vp, vp, vp, C.c_uint64, vp, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.oracle_time_stream.restype = C.c_double
     lib.oracle_time_stream.argtypes = [vp, vp, C.c_size_t, C.c_uint64, C.c_double,
                                        C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -158,3 +160,11 @@ class OracleIndex:
         t = np.ascontiguousarray(terms, dtype=np.uint32)
         return int(_lib.oracle_and_query(self.docs_dict._h, self._padded.ctypes.data, self._offs.ctypes.data,
                                          self.num_docs, t.ctypes.data, t.size))
+
+    def and_query_freqs(self, freqs_dict: OracleDict, terms):
+        """and_query<true> -> (matches, sum of the freq() of every term at every match, freqs blocks decoded)."""
+        t = np.ascontiguousarray(terms, dtype=np.uint32)
+        fsum, fblocks = C.c_uint64(), C.c_uint64()
+        n = _lib.oracle_and_query_freqs(self.docs_dict._h, freqs_dict._h, self._padded.ctypes.data, self._offs.ctypes.data,
+                                        self.num_docs, t.ctypes.data, t.size, C.byref(fsum), C.byref(fblocks))
+        return int(n), int(fsum.value), int(fblocks.value)

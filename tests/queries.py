@@ -41,3 +41,19 @@ def intersect(docids: np.ndarray, bounds: np.ndarray, terms) -> int:
     for t in terms[1:]:
         cur = np.intersect1d(cur, docids[int(bounds[t]):int(bounds[t + 1])], assume_unique=True)
     return int(cur.size)
+
+
+def intersect_freqs(docids: np.ndarray, freqs: np.ndarray, bounds: np.ndarray, terms):
+    """-> (matches, sum over matches and over the distinct terms of the term's freq in the document)."""
+    terms = np.unique(np.asarray(terms))
+    if terms.size == 0:
+        return 0, 0
+    cur = docids[int(bounds[terms[0]]):int(bounds[terms[0] + 1])]
+    for t in terms[1:]:
+        cur = np.intersect1d(cur, docids[int(bounds[t]):int(bounds[t + 1])], assume_unique=True)
+    total = 0
+    for t in terms:
+        lo, hi = int(bounds[t]), int(bounds[t + 1])
+        pos = np.searchsorted(docids[lo:hi], cur)
+        total += int(freqs[lo:hi][pos].astype(np.uint64).sum())
+    return int(cur.size), total

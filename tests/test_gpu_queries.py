@@ -5,7 +5,7 @@ import pytest
 
 import oracle
 from dint_amd import host
-from queries import heavy_queries, intersect, reference_queries
+from queries import heavy_queries, intersect, intersect_freqs, reference_queries
 from test_index_cpu import get_index
 
 pytestmark = pytest.mark.gpu
@@ -93,3 +93,52 @@ def test_disjoint_and_identical_lists(device):
     qi = device.QueryIndex(device.Dictionary(kind, dd), idx, offs)
     got = qi.and_queries([[0, 1], [1, 0], [2, 3], [2, 4], [3, 4, 2], [0, 4], [0, 2], [1, 3, 4]])
     assert list(got) == [0, 0, 0, len(ev), 0, len(a), 1500, 2000]
+
+
+@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.RECTANGULAR, host.MULTI_PACKED])
+@pytest.mark.parametrize("corpus_name", ["small_corpus", "dense_corpus"])
+def test_with_freqs_matches_oracle(device, request, kind, corpus_name):
+    """and_query<true> (queries.hpp:72-76): the freqs of every term at every match, freqs parts decoded lazily."""
+    corpus = request.getfixturevalue(corpus_name)
+    ix = get_index(corpus, kind)
+    dd = device.Dictionary(kind, ix.docs_dict)
+    fd = device.Dictionary(kind, ix.freqs_dict)
+    qi = device.QueryIndex(dd, ix.bytes, ix.offsets)
+    qs = reference_queries(len(ix.lens))[:150] + heavy_queries(ix.lens, 120, seed=11)
+    counts, sums, nblocks = qi.and_queries_with_freqs(fd, qs)
+    want = [intersect_freqs(ix.docids, ix.freqs, ix.bounds, q) for q in qs]
+    assert np.array_equal(counts, np.array([w[0] for w in want], dtype=np.uint64))
+    assert np.array_equal(sums, np.array([w[1] for w in want], dtype=np.uint64))
+    assert np.array_equal(counts, qi.and_queries(qs))
+    assert int(sums.sum()) > int(counts.sum()) > 1000
+    # one query at a time: the same freqs blocks as the reference's lazy freq() decodes
+    oi = oracle.OracleIndex(oracle.OracleDict(kind, ix.docs_dict), ix.bytes, ix.offsets, int(ix.docids.max()) + 1)
+    ofd = oracle.OracleDict(kind, ix.freqs_dict)
+    total_blocks = len(qi.blocks)
+    lazy = 0
+    for i in range(0, len(qs), 9):
+        c1, s1, b1 = qi.and_queries_with_freqs(fd, [qs[i]])
+        assert (int(c1[0]), int(s1[0]), b1) == oi.and_query_freqs(ofd, qs[i])
+        n_terms = np.unique(qs[i]).size
+        lazy += b1 < sum(int(np.ceil(ix.lens[t] / 256)) for t in np.unique(qs[i]))
+    assert lazy > 0 and total_blocks > 0  # fewer freqs parts than the lists hold, for some queries at least
+    qi.close()
+
+
+def test_with_freqs_edges(device, dense_corpus):
+    kind = host.SINGLE_PACKED
+    ix = get_index(dense_corpus, kind)
+    dd = device.Dictionary(kind, ix.docs_dict)
+    fd = device.Dictionary(kind, ix.freqs_dict)
+    qi = device.QueryIndex(dd, ix.bytes, ix.offsets)
+    c, s, b = qi.and_queries_with_freqs(fd, [])
+    assert c.size == 0 and s.size == 0 and b == 0
+    big = int(np.argmax(ix.lens))
+    c, s, b = qi.and_queries_with_freqs(fd, [[big], [big, big], []])
+    lo, hi = int(ix.bounds[big]), int(ix.bounds[big + 1])
+    assert list(c) == [hi - lo, hi - lo, 0]
+    assert list(s) == [int(ix.freqs[lo:hi].astype(np.uint64).sum())] * 2 + [0]
+    wrong = device.Dictionary(host.RECTANGULAR, get_index(dense_corpus, host.RECTANGULAR).freqs_dict)
+    with pytest.raises(device.DintError):
+        qi.and_queries_with_freqs(wrong, [[big]])
+    qi.close()

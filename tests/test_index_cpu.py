@@ -89,3 +89,22 @@ def test_full_blocks_are_vroom_segments(small_corpus):
     hdr = 1 if n < 128 else (2 if n < 16384 else 3)
     start = int(ix.offsets[i]) + hdr + 4 * n_blocks + 4 * (n_blocks - 1)
     assert bytes(ix.bytes[start:start + len(payload)]) == payload
+
+
+@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
+def test_oracle_and_query_with_freqs(small_corpus, kind):
+    """and_query<true> (queries.hpp:72-76) against plain set intersection of the builder's input."""
+    from queries import heavy_queries, intersect_freqs, reference_queries
+
+    ix = get_index(small_corpus, kind)
+    oi = oracle.OracleIndex(oracle.OracleDict(kind, ix.docs_dict), ix.bytes, ix.offsets, int(ix.docids.max()) + 1)
+    ofd = oracle.OracleDict(kind, ix.freqs_dict)
+    qs = reference_queries(len(ix.lens))[:60] + heavy_queries(ix.lens, 40, seed=2)
+    seen = 0
+    for q in qs:
+        n, fsum, blocks = oi.and_query_freqs(ofd, q)
+        assert (n, fsum) == intersect_freqs(ix.docids, ix.freqs, ix.bounds, q)
+        assert n == oi.and_query(q)
+        assert (blocks == 0) == (n == 0)
+        seen += n
+    assert seen > 100
