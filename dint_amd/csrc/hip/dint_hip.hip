@@ -340,7 +340,7 @@ int stage_dictionary(dint_dict& dd, parsed_dict const& pd) {
     HIP_TRY(hipMemcpy(base + b_heads, tails.data(), tails.size() * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(base + b_heads + b_tails, goff.data(), goff.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(base + b_heads + b_tails + b_goff, gtable.data(), gtable.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&dd.d_queues, size_t(dint_dict::kQueueSlots) * kQueueShards * kQueueStride * 4));
+    HIP_TRY(hipMalloc(&dd.d_queues, size_t(dint_dict::kQueueSlots) * (kQueueShards + 1) * kQueueStride * 4));
     for (uint32_t i = 0; i != dint_dict::kQueueSlots; ++i) {
         HIP_TRY(hipEventCreateWithFlags(&dd.slot_done[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreate(&dd.slot_start[i]));
@@ -633,7 +633,7 @@ int dint_index_stream(const dint_dict* dd, const uint8_t* enc, size_t enc_bytes,
 // A bundle schedule kept by its owner (a prepared block table: the same units launch after launch) instead of
 // being rebuilt, three small kernels, before every launch.
 struct sched_cache {
-    void* d_mem = nullptr;  // [items u32 x n][block counts/offsets u32 x blocks][n_items u32][sched u8 x n][item counts u8 x n]
+    void* d_mem = nullptr;  // (the layout launch_decode gives a slot's schedule workspace)
     bool valid = false;
 };
 
@@ -667,20 +667,25 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
     const uint32_t slot = mut->next_slot.fetch_add(1) % dint_dict::kQueueSlots;
     mut->launches += 1;
     if (mut->slot_used[slot]) HIP_TRY(hipEventSynchronize(mut->slot_done[slot]));  // normally long complete
-    a.queue = mut->d_queues + size_t(slot) * kQueueShards * kQueueStride;
+    a.queue = mut->d_queues + size_t(slot) * (kQueueShards + 1) * kQueueStride;
+    a.chunk_queue = a.queue + kQueueShards * kQueueStride;  // (the bundle path's counter: a line of its own behind the shards')
     a.n_shards = std::min<uint32_t>(kQueueShards, grid);
-    HIP_TRY(hipMemsetAsync(a.queue, 0, size_t(kQueueShards) * kQueueStride * 4, s));
+    HIP_TRY(hipMemsetAsync(a.queue, 0, size_t(kQueueShards + 1) * kQueueStride * 4, s));
     // tiny consecutive units are decoded several to a tile: schedule them (single-dictionary streams)
     a.sched = nullptr;
     a.items = nullptr;
     a.n_items = nullptr;
     a.item_cnt = nullptr;
+    a.urec = nullptr;
+    a.cbase = nullptr;
     a.spans = d_spans;
     if (n_units >= 2 && n_units < 0xFFFFFFFFull &&
         !dd->no_bundles) {
-        // workspace of the slot: [items u32 x n][block counts/offsets u32 x blocks][n_items u32][sched u8 x n][item counts u8 x n]
+        // workspace of the slot: [unit records 16 B x n][chunk bases 16 B x chunks][items u32 x n][block counts/offsets u32 x blocks]
+        // [n_items u32][sched u8 x n][item counts u8 x n]
         const size_t n_blocks = (n_units + 255) / 256;
-        const size_t need = 4 * n_units + 4 * n_blocks + 4 + 2 * n_units;
+        const size_t n_chunks = (n_units + kChunkUnits - 1) / kChunkUnits;
+        const size_t need = 16 * n_units + 16 * n_chunks + 4 * n_units + 4 * n_blocks + 4 + 2 * n_units;
         if (cache && !cache->d_mem) HIP_TRY(hipMalloc(&cache->d_mem, need));
         if (!cache && mut->sched_cap[slot] < need) {
             if (mut->d_sched[slot]) HIP_TRY(hipFree(mut->d_sched[slot]));
@@ -690,7 +695,9 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
             HIP_TRY(hipMalloc(&mut->d_sched[slot], want));
             mut->sched_cap[slot] = want;
         }
-        uint32_t* const d_items = reinterpret_cast<uint32_t*>(cache ? cache->d_mem : mut->d_sched[slot]);
+        u32x4* const d_urec = reinterpret_cast<u32x4*>(cache ? cache->d_mem : mut->d_sched[slot]);
+        uint64_t* const d_cbase = reinterpret_cast<uint64_t*>(d_urec + n_units);
+        uint32_t* const d_items = reinterpret_cast<uint32_t*>(d_cbase + 2 * n_chunks);
         uint32_t* const d_block = d_items + n_units;
         uint32_t* const d_n_items = d_block + n_blocks;
         uint8_t* const d_sch = reinterpret_cast<uint8_t*>(d_n_items + 1);
@@ -698,7 +705,7 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
         if (!cache || !cache->valid) {
             hipLaunchKernelGGL(bundle_schedule_kernel, dim3(uint32_t(n_blocks)), dim3(256), 0, s, d_units, d_spans, uint64_t(n_units),
                                d_enc, uint64_t(enc_bytes), uint64_t(out_capacity), only_full,
-                               uint32_t(dd->kind == DINT_DICT_MULTI_PACKED), d_sch, d_block);
+                               uint32_t(dd->kind == DINT_DICT_MULTI_PACKED), d_sch, d_block, d_urec, d_cbase);
             hipLaunchKernelGGL(bundle_offsets_kernel, dim3(1), dim3(1024), 0, s, d_block, uint32_t(n_blocks), d_n_items);
             hipLaunchKernelGGL(bundle_items_kernel, dim3(uint32_t(n_blocks)), dim3(256), 0, s, d_sch, uint64_t(n_units), d_block,
                                d_items, d_item_cnt);
@@ -708,6 +715,8 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
         a.items = d_items;
         a.n_items = d_n_items;
         a.item_cnt = d_item_cnt;
+        a.urec = d_urec;
+        a.cbase = d_cbase;
     }
     HIP_TRY(hipEventRecord(mut->slot_start[slot], s));
     if (dd->kind == DINT_DICT_MULTI_PACKED)
