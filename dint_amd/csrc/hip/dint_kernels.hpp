@@ -1418,10 +1418,13 @@ __device__ __forceinline__ void bundle_process(const decode_args& a, const wave_
     }
     // (in-index docs parts: every unit of the bundle is a 256-posting block, so group g of the expansion is unit
     // u0 + g; a slow codeword anywhere leaves the whole bundle as gaps for finalize_postings_kernel)
-    const bool as_docids = a.unit_base != nullptr && !tile_slow && total <= kRounds * kGroups * 256;
+    const bool as_docids = a.unit_base != nullptr && !tile_slow && total <= kMaxCap;
     if (a.unit_base != nullptr && !as_docids && has) a.gaps_left[u0 + lane] = 1;
     // (a bundle is one batch by construction: the schedule packs at most kMaxCap integers into one)
-    expand_tile<kRounds, kGroups, true>(t, false, tile_wide, a.plus_one, as_docids ? a.unit_base + u0 : nullptr, 0u, lds, scratch, rs_out, lane, pf, [&]() {
+#ifndef DINT_BUNDLE_GROUPS
+#define DINT_BUNDLE_GROUPS DINT_GROUPS
+#endif
+    expand_tile<8 / DINT_BUNDLE_GROUPS, DINT_BUNDLE_GROUPS, true>(t, false, tile_wide, a.plus_one, as_docids ? a.unit_base + u0 : nullptr, 0u, lds, scratch, rs_out, lane, pf, [&]() {
 #pragma unroll
         for (uint32_t k = 0; k != kSPL; ++k) asm volatile("" : "+v"(hr.q[k]), "+v"(t3[k]));
         if (tile_big) {
@@ -1488,59 +1491,43 @@ __device__ __forceinline__ bool decode_bundle_chunks(const decode_args& a, const
         return *reinterpret_cast<const u32x4*>(a.cbase + 2 * uint64_t(chunk));
     };
     auto leaders = [&](const u32x4& r) -> uint64_t { return __ballot(((r.z >> 18) & 127u) != 0 && ((r.z >> 8) & 63u) != 0); };
-    // chunk `ch` (records rc, bases cb, bundle leaders left: lm), the one after it requested (ch_n, rc_n, cb_n), a
-    // ticket beyond that in flight
+    // chunk `ch` (records rc, bases in0 / out0, bundle leaders left: lm); the next chunk's ticket in flight. (The next
+    // chunk's records are NOT requested ahead: eight more registers live through every tile of the chunk cost more
+    // — as spills, each reload a wait for everything in flight — than one exposed round trip per chunk.)
     uint32_t ch = uniform(tk);
     if (ch >= n_chunks) return false;
-    u32x4 rc = records(ch), cb = bases(ch);
+    u32x4 rc = records(ch);
+    uint64_t in0, out0;
+    {
+        const u32x4 cb = bases(ch);
+        in0 = (uint64_t(uniform(cb.y)) << 32) | uniform(cb.x);
+        out0 = (uint64_t(uniform(cb.w)) << 32) | uniform(cb.z);
+    }
     tk = ask();
     --budget;
-    uint32_t ch_n = 0;
-    u32x4 rc_n = {0, 0, 0, 0}, cb_n = {0, 0, 0, 0};
-    bool more = false;
-    if (budget != 0) {
-        const uint32_t t2 = uniform(tk);
-        if (t2 < n_chunks) {
-            ch_n = t2;
-            rc_n = records(ch_n);
-            cb_n = bases(ch_n);
-            tk = ask();
-            more = true;
-            --budget;
-        }
-    }
     uint64_t lm = leaders(rc);
     // -> the next bundle: (chunk registers current, p, cnt); false: nothing left
     uint32_t p = 0, cnt = 0;
     auto advance = [&]() -> bool {
         while (lm == 0) {
-            if (!more) return false;
-            ch = ch_n;
-            rc = rc_n;
-            cb = cb_n;
+            if (budget == 0) return false;
+            const uint32_t t2 = uniform(tk);
+            if (t2 >= n_chunks) return false;
+            ch = t2;
+            rc = records(ch);
+            const u32x4 cb = bases(ch);
+            in0 = (uint64_t(uniform(cb.y)) << 32) | uniform(cb.x);
+            out0 = (uint64_t(uniform(cb.w)) << 32) | uniform(cb.z);
+            tk = ask();
+            --budget;
             lm = leaders(rc);
-            more = false;
-            if (budget != 0) {
-                const uint32_t t2 = uniform(tk);
-                more = t2 < n_chunks;
-                if (more) {
-                    ch_n = t2;
-                    rc_n = records(ch_n);
-                    cb_n = bases(ch_n);
-                    tk = ask();
-                    --budget;
-                }
-            }
         }
         p = uint32_t(__builtin_ctzll(lm));
         lm &= lm - 1;
         cnt = (readlane(rc.z, p) >> 18) & 127u;
         return true;
     };
-    auto map_here = [&](bundle_lane& l, bundle_head& h) {
-        const uint64_t in0 = (uint64_t(uniform(cb.y)) << 32) | uniform(cb.x), out0 = (uint64_t(uniform(cb.w)) << 32) | uniform(cb.z);
-        bundle_map<MULTI>(c, rc, ch, p, cnt, in0, out0, l, h);
-    };
+    auto map_here = [&](bundle_lane& l, bundle_head& h) { bundle_map<MULTI>(c, rc, ch, p, cnt, in0, out0, l, h); };
     if (!advance()) return true;
     bundle_lane bl;
     bundle_head bh;
