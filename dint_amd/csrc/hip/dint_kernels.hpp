@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(256) void bundle_schedule_kernel(const dint_unit* u
         const uint64_t nxt = spans ? in + spans[i] : (i + 1 < n_units ? units[i + 1].in_off : enc_bytes);
         // (in-index launches decode only the full blocks; the other units stay on their own and are skipped)
         if (n >= 1 && n <= kBundleMaxInts && (!only_full || n == 256) && nxt > in && nxt - in <= kBundleMaxBytes &&
-            nxt <= enc_bytes && out + n <= out_capacity && in >= in0 && in - in0 <= 0xFFFFFFFFull && out >= out0 &&
+            nxt <= enc_bytes && out <= out_capacity && out_capacity - out >= n && in >= in0 && in - in0 <= 0xFFFFFFFFull && out >= out0 &&
             out - out0 <= 0xFFFFFFFFull) {
             if (!multi) {
                 const uint32_t l = uint32_t((nxt - in + 7) >> 3);

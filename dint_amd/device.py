@@ -101,6 +101,9 @@ def _load():
 _lib = _load()
 
 
+MAX_UNIT_INTS = 1 << 28  # DINT_MAX_UNIT_INTS (include/dint_hip.h)
+
+
 class DintError(RuntimeError):
     def __init__(self, status: int, where: str):
         self.status = status

@@ -155,6 +155,48 @@ def synth_collection(target_postings: int, threads: int | None = None, **params)
     return Collection(synth_gaps(p, lens, 0, threads), lens)
 
 
+def readme_test_collection(seed: int = 1) -> Collection:
+    """Stand-in for the reference's test collection (test/test_data/test_collection.docs is not in the checkout;
+    README.md:53 gives its shape): 10 000 documents, 113 306 posting lists, 3 327 520 postings; list lengths
+    Zipf-like (a few lists hold every other document, most hold a handful), every list a sorted set of distinct
+    docIDs < 10 000, lists in no particular order. Seeded and exact: the same collection everywhere."""
+    docs, n_lists, postings = 10_000, 113_306, 3_327_520
+    rank = np.arange(1, n_lists + 1, dtype=np.float64)
+
+    def lengths(c):
+        return np.clip(np.rint(c / rank ** 0.93), 1, docs // 2).astype(np.int64)
+
+    lo, hi = 1.0, 1e7
+    for _ in range(80):  # the scale whose lengths sum to just under the target
+        mid = 0.5 * (lo + hi)
+        lo, hi = (mid, hi) if lengths(mid).sum() <= postings else (lo, mid)
+    lens = lengths(lo)
+    short = postings - int(lens.sum())
+    assert 0 <= short < n_lists
+    lens[np.nonzero(lens < docs // 2)[0][:short]] += 1  # the remainder, one posting each, to the longest lists with room
+    assert int(lens.sum()) == postings and int(lens.max()) >= 4096
+    rng = np.random.default_rng(seed)
+    lens = lens[rng.permutation(n_lists)]
+    gaps = np.empty(postings, dtype=np.uint32)
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    for k in np.unique(lens):  # all the lists of one length at a time
+        idx = np.nonzero(lens == k)[0]
+        if k > 64:
+            rows = np.stack([np.sort(rng.permutation(docs)[:k]) for _ in idx])
+        else:
+            rows = np.sort(rng.integers(0, docs, size=(idx.size, k)), axis=1)
+            while True:  # redraw the rows that hold a docID twice
+                dup = np.nonzero((rows[:, 1:] == rows[:, :-1]).any(axis=1))[0] if k > 1 else np.zeros(0, dtype=np.int64)
+                if dup.size == 0:
+                    break
+                rows[dup] = np.sort(rng.integers(0, docs, size=(dup.size, k)), axis=1)
+        g = rows.astype(np.int64)
+        g[:, 1:] = g[:, 1:] - g[:, :-1] - 1
+        pos = (starts[idx][:, None] + np.arange(k)[None, :]).ravel()
+        gaps[pos] = g.ravel().astype(np.uint32)
+    return Collection(gaps, lens.astype(np.uint32))
+
+
 def docids_to_gaps(docids: np.ndarray) -> np.ndarray:
     """gap[i] = doc[i] - doc[i-1] - 1 with doc[-1] = -1 (vroom_env/jobs.hpp:74-84)."""
     d = np.asarray(docids, dtype=np.uint32)

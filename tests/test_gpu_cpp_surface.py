@@ -52,6 +52,33 @@ def test_decode_cli_reports_the_reference_keys(small_corpus, tmp_path, kind):
     assert line["type"] == TYPES[kind] and int(line["ints_x_sec"]) > 0
 
 
+def test_decode_cli_on_the_readme_shaped_collection(tmp_path):
+    """BASELINE config 1: `decode single_rect_dint` on the reference's test collection — whose .docs file is not in the
+    checkout: a seeded stand-in of the shape README.md:53 states (10 000 documents, 113 306 lists,
+    3 327 520 postings), every list encoded, the tool's output checked against the encoder's input."""
+    coll = host.readme_test_collection(seed=1)
+    assert (len(coll.lens), coll.num_postings) == (113_306, 3_327_520)
+    dict_file = host.build_dictionary(host.RECTANGULAR, coll)
+    enc, _ = host.encode_vroom(host.RECTANGULAR, dict_file, coll, unit_ints=8192)
+    (tmp_path / "test_collection.bin").write_bytes(enc.tobytes())
+    (tmp_path / "dict.bin").write_bytes(dict_file)
+    (tmp_path / "gaps.bin").write_bytes(coll.gaps.tobytes())
+    exe = os.path.join(ROOT, "dint_amd", "bin", "dint_decode")
+    r = subprocess.run([exe, "single_rect_dint", str(tmp_path / "test_collection.bin"), "--dict", str(tmp_path / "dict.bin"),
+                        "--check", str(tmp_path / "gaps.bin")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert int(line["num_sequences"]) == 113_306 and int(line["num_integers"]) == 3_327_520
+    assert line["type"] == "single_rect_dint" and line["bit_exact"] == "true"
+    # and the tool notices when the integers are not the expected ones
+    wrong = coll.gaps.copy()
+    wrong[123_456] ^= 1
+    (tmp_path / "gaps.bin").write_bytes(wrong.tobytes())
+    r = subprocess.run([exe, "single_rect_dint", str(tmp_path / "test_collection.bin"), "--dict", str(tmp_path / "dict.bin"),
+                        "--check", str(tmp_path / "gaps.bin")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 2 and json.loads(r.stdout.strip().splitlines()[-1])["bit_exact"] == "false"
+
+
 @pytest.fixture(scope="module")
 def walker_binary(tmp_path_factory):
     exe = tmp_path_factory.mktemp("cpp") / "block_walker"

@@ -135,20 +135,29 @@ def test_any_unit_size_gives_the_same_integers(device, small_corpus, unit_ints):
     assert np.array_equal(out, small_corpus.coll.gaps)
 
 
-def test_full_size_properties(device):
-    """A collection well past the sizes the oracle is used on: bit-exact against the encoder's
-    input, and decode is idempotent (a second pass over the same buffer changes nothing)."""
+@pytest.mark.parametrize("kind,unit_ints", [(host.SINGLE_PACKED, 8192), (host.RECTANGULAR, 8192), (host.MULTI_PACKED, 8192),
+                                            (host.MULTI_PACKED, 256)],
+                         ids=["single_packed", "single_rect", "multi_packed", "multi_packed_block_units"])
+def test_full_size_properties(device, kind, unit_ints):
+    """4e7 postings, well past the sizes the oracle is used on: bit-exact against the encoder's input, the
+    units' end offsets are where the encoder put the next unit, and decode is idempotent (a second pass over
+    the same buffer changes nothing). unit_ints = 256 on a multi-dictionary stream: block-granular units
+    (vroom_env/dint_codecs.hpp:521-619 decodes the blocks one after the other; with the block table they are
+    independent)."""
     import torch
 
     coll = host.synth_collection(40_000_000, universe=25_000_000, seed=2024)
-    dict_file = host.build_dictionary(host.SINGLE_PACKED, coll, max_sample_ints=5_000_000)
-    enc, units = host.encode_vroom(host.SINGLE_PACKED, dict_file, coll, unit_ints=8192)
-    d = device.Dictionary(host.SINGLE_PACKED, dict_file)
+    dict_file = host.build_dictionary(kind, coll, max_sample_ints=5_000_000)
+    enc, units = host.encode_vroom(kind, dict_file, coll, unit_ints=unit_ints)
+    if unit_ints == 256:
+        assert int(units["n"].max()) <= 256 and len(units) > coll.num_postings // 300
+    d = device.Dictionary(kind, dict_file)
     dev = torch.device("cuda", 0)
     enc_dev = torch.from_numpy(enc).to(dev)
     units_dev = device.units_to_device(units, dev)
     out_dev = torch.zeros(coll.num_postings, dtype=torch.int32, device=dev)
-    d.decode_units(enc_dev, units_dev, len(units), out_dev)
+    end_dev = torch.zeros(len(units), dtype=torch.int64, device=dev)
+    d.decode_units(enc_dev, units_dev, len(units), out_dev, end_dev)
     first = out_dev.clone()
     d.decode_units(enc_dev, units_dev, len(units), out_dev)
     torch.cuda.synchronize()
@@ -156,6 +165,85 @@ def test_full_size_properties(device):
     got = out_dev.cpu().numpy().view(np.uint32)
     assert np.array_equal(got, coll.gaps)
     assert int(got.sum(dtype=np.uint64)) == int(coll.gaps.sum(dtype=np.uint64))
+    # a unit ends where the next one of its list begins (lists are separated by their vroom headers)
+    ends = end_dev.cpu().numpy().astype(np.uint64)
+    nxt = units["in_off"][1:].astype(np.uint64)
+    same_list = units["list"][1:] == units["list"][:-1]
+    assert np.array_equal(ends[:-1][same_list], nxt[same_list])
+    assert (ends[:-1][~same_list] <= nxt[~same_list]).all() and int(ends[-1]) <= enc.size
+
+
+def test_malformed_unit_tables_stay_inside_their_own_output(device, small_corpus):
+    """Unit tables come from the caller: entries that point past the stream, claim more integers than the stream
+    holds, or lie outside the output are skipped or decode garbage INSIDE THEIR OWN [out_off, out_off + n) — every
+    other unit is exact, nothing is written elsewhere, nothing faults."""
+    import torch
+
+    kind = host.SINGLE_PACKED
+    d = device.Dictionary(kind, small_corpus.dict_file(kind))
+    enc, units = small_corpus.encoded(kind)
+    total = small_corpus.coll.num_postings
+    units = units.copy()
+    n_units = len(units)
+    assert n_units > 64
+    capacity = total + 1500      # room behind the last unit for one that claims too much
+    canaries = 4096
+    bad = {}
+    bad["in_off_past_end"] = 5
+    units["in_off"][5] = enc.size + 100
+    bad["in_off_near_end"] = 9
+    units["in_off"][9] = enc.size - 3
+    bad["in_off_huge"] = 13
+    units["in_off"][13] = 2**63 + 17
+    bad["n_past_capacity"] = 21
+    units["n"][21] = capacity            # out_off + n > capacity: skipped
+    bad["out_off_past_capacity"] = 33
+    units["out_off"][33] = capacity + 5
+    bad["n_zero"] = 40
+    units["n"][40] = 0
+    bad["out_off_wraps"] = 55
+    units["out_off"][55] = 2**64 - 8     # out_off + n wraps around to a small number
+    bad["n_over_limit"] = 47
+    units["n"][47] = device.MAX_UNIT_INTS + 1
+    last = n_units - 1                   # claims 1000 integers more than its stream holds: garbage, but its own
+    units["n"][last] += 1000
+    dev = torch.device("cuda", 0)
+    enc_dev = torch.from_numpy(enc).to(dev)
+    units_dev = device.units_to_device(units, dev)
+    sentinel = -1412567295  # 0xABCDEF01
+    out_full = torch.full((capacity + canaries,), sentinel, dtype=torch.int32, device=dev)
+    for _ in range(2):
+        d.decode_units(enc_dev, units_dev, n_units, out_full[:capacity])
+    torch.cuda.synchronize()
+    got = out_full.cpu().numpy()
+    assert (got[capacity:] == sentinel).all(), "written past the output's capacity"
+    good = small_corpus.encoded(kind)[1]
+    want = small_corpus.coll.gaps.view(np.int32)
+    touched = set(bad.values()) | {last}
+    for u in range(n_units):
+        lo, n = int(good["out_off"][u]), int(good["n"][u])
+        if u not in touched:
+            assert np.array_equal(got[lo:lo + n], want[lo:lo + n]), f"unit {u} is not exact"
+    for name in ("in_off_past_end", "in_off_huge", "n_past_capacity", "out_off_past_capacity", "n_zero", "n_over_limit", "out_off_wraps"):
+        u = bad[name]
+        lo, n = int(good["out_off"][u]), int(good["n"][u])
+        assert (got[lo:lo + n] == sentinel).all() or name in ("in_off_past_end", "in_off_huge"), name
+    # the last unit: its real integers are exact, the rest of what it claims is its own to fill
+    lo, n = int(good["out_off"][last]), int(good["n"][last])
+    assert np.array_equal(got[lo:lo + n], want[lo:lo + n])
+    assert (got[lo + n + 1000:capacity] == sentinel).all()
+
+
+def test_units_over_the_size_limit_are_rejected(device, small_corpus):
+    kind = host.SINGLE_PACKED
+    d = device.Dictionary(kind, small_corpus.dict_file(kind))
+    enc, _ = small_corpus.encoded(kind)
+    with pytest.raises(device.DintError):
+        d.decode_list(enc, 0, device.MAX_UNIT_INTS + 1)
+    units, total, _ = d.index_stream(enc, 1 << 31)   # asks for units larger than the limit: capped, still exact
+    assert int(units["n"].max()) <= device.MAX_UNIT_INTS
+    out, _, _ = device.decode_stream(d, enc, units, total)
+    assert np.array_equal(out, small_corpus.coll.gaps)
 
 
 @pytest.mark.parametrize("case", cases("multi_cases"), ids=lambda c: c[0])

@@ -110,3 +110,23 @@ def test_list_lengths_around_block_sizes(small_corpus, kind, n):
         got, used = od.decode_list(enc, payload, n)
         assert np.array_equal(got, vals)
         assert payload + used == enc.size
+
+
+def test_readme_shaped_collection_through_the_oracle():
+    """BASELINE config 1 (the reference's own CPU-runnable case: single_rect_dint vroom decode on its test
+    collection) on the seeded stand-in for the missing test_collection.docs: the shape README.md:53 states, every
+    list decoded by the oracle == the encoder's input."""
+    coll = host.readme_test_collection(seed=1)
+    assert (len(coll.lens), coll.num_postings) == (113_306, 3_327_520) and int(coll.lens.min()) >= 1
+    assert int(coll.lens.max()) >= 4096
+    docids = host.gaps_to_docids(coll)
+    b = coll.list_bounds()
+    for i in range(0, len(coll.lens), 1013):
+        d = docids[int(b[i]):int(b[i + 1])].astype(np.int64)
+        assert d.size == 1 or (np.diff(d) > 0).all()
+        assert int(d[-1]) < 10_000
+    dict_file = host.build_dictionary(host.RECTANGULAR, coll)
+    enc, _ = host.encode_vroom(host.RECTANGULAR, dict_file, coll, unit_ints=8192)
+    got, n_lists = oracle.OracleDict(host.RECTANGULAR, dict_file).decode_stream(enc, coll.num_postings)
+    assert n_lists == 113_306
+    assert np.array_equal(got, coll.gaps)

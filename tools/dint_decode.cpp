@@ -42,7 +42,7 @@ static void dint_ok(int st, const char* what) {
 int main(int argc, char** argv) {
     if (argc < 3) {
         std::cerr << "Usage " << argv[0] << ":\n\t<type> <encoded_data_filename> --dict <dictionary_filename>"
-                  << " [--unit-ints N] [--runs R]" << std::endl;
+                  << " [--unit-ints N] [--runs R] [--check <file of the expected integers, u32 little-endian>]" << std::endl;
         return 1;
     }
     try {
@@ -51,11 +51,13 @@ int main(int argc, char** argv) {
         const char* dict_file = nullptr;
         uint32_t unit_ints = 8192;
         int runs = 5;
+        const char* check_file = nullptr;
         for (int i = 3; i < argc; ++i) {
             std::string arg = argv[i];
             if (arg == "--dict" && i + 1 < argc) dict_file = argv[++i];
             else if (arg == "--unit-ints" && i + 1 < argc) unit_ints = uint32_t(std::atoi(argv[++i]));
             else if (arg == "--runs" && i + 1 < argc) runs = std::max(1, std::atoi(argv[++i]));
+            else if (arg == "--check" && i + 1 < argc) check_file = argv[++i];
             else throw std::runtime_error("unknown parameter");
         }
         int kind;
@@ -102,19 +104,28 @@ int main(int argc, char** argv) {
         dint_dict_info info;
         dint_ok(dint_dict_info_get(dict, &info), "dint_dict_info_get");
 
+        // (not in the reference's tool: the decoded integers against a file of the expected ones)
+        int bit_exact = -1;
+        if (check_file) {
+            std::vector<uint8_t> want = read_file(check_file);
+            std::vector<uint32_t> got(total_ints);
+            HIP_OK(hipMemcpy(got.data(), d_out, total_ints * 4, hipMemcpyDeviceToHost));
+            bit_exact = want.size() == total_ints * 4 && std::memcmp(want.data(), got.data(), want.size()) == 0 ? 1 : 0;
+        }
         std::cerr << "elapsed time " << elapsed << " [sec]\n" << ns_x_int << " [ns] x int\n" << ints_x_sec
                   << " ints x [sec]" << std::endl;
         std::cout << "{\"filename\": \"" << encoded << "\", \"num_sequences\": \"" << n_lists
                   << "\", \"num_integers\": \"" << total_ints << "\", \"type\": \"" << type
                   << "\", \"tot_elapsed_time\": \"" << elapsed << "\", \"ns_x_int\": \"" << ns_x_int
                   << "\", \"ints_x_sec\": \"" << ints_x_sec << "\", \"device\": \"gfx950\", \"units\": \"" << n_units
-                  << "\", \"hot_codewords_in_lds\": \"" << info.hot_entries << "\", \"runs\": \"" << runs << "\"}"
-                  << std::endl;
+                  << "\", \"hot_codewords_in_lds\": \"" << info.hot_entries << "\", \"runs\": \"" << runs << "\""
+                  << (bit_exact < 0 ? "" : bit_exact ? ", \"bit_exact\": \"true\"" : ", \"bit_exact\": \"false\"") << "}" << std::endl;
         dint_free(units);
         (void)hipFree(d_enc);
         (void)hipFree(d_units);
         (void)hipFree(d_out);
         dint_dict_destroy(dict);
+        if (bit_exact == 0) return 2;
     } catch (std::exception const& e) {
         std::cerr << "ERROR: " << e.what() << std::endl;
         return 1;
