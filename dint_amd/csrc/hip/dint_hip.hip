@@ -414,13 +414,19 @@ struct dint_query_index {
     uint32_t* d_needed = nullptr;   // n_blocks, zero between rounds
     uint32_t* d_rank = nullptr;     // n_blocks
     uint32_t* d_touched = nullptr;  // n_blocks
-    uint32_t* d_n_touched = nullptr;
-    device_buffer<uint32_t> page_block, page_query, term_first, term_blocks, cand, target, probe, fprobe, tails, spans, bases;
+    uint32_t* d_n_touched = nullptr;  // two counters: {blocks a round touched, short pages of a page decode}
+    bool claims_dirty = false;        // d_needed may hold claim flags of a call that did not run to its end
+    // one call = one host-to-device copy (everything the call's kernels read from the host, staged in pinned memory),
+    // one clear (every counter the call's launches count in), the launches, one copy back
+    void* h_stage = nullptr;
+    size_t h_stage_cap = 0;
+    device_buffer<uint32_t> inputs, ctrl;
+    device_buffer<uint32_t> cand, target, probe, fprobe, tails, spans, bases;
     device_buffer<dint_block_ref> sub;
     device_buffer<dint_unit> units;
     device_buffer<uint64_t> ends;
     device_buffer<uint8_t> gaps_left;
-    device_buffer<unsigned long long> counts, freq_sums;
+    device_buffer<unsigned long long> freq_sums;
     std::mutex mutex;
 };
 
@@ -640,7 +646,8 @@ struct sched_cache {
 static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_bytes, const dint_unit* d_units,
                          size_t n_units, uint32_t* d_out, size_t out_capacity, uint64_t* d_end_off, void* stream,
                          uint32_t only_full, const uint32_t* d_spans = nullptr, uint32_t plus_one = 0,
-                         const uint32_t* d_unit_base = nullptr, uint8_t* d_gaps_left = nullptr, sched_cache* cache = nullptr) {
+                         const uint32_t* d_unit_base = nullptr, uint8_t* d_gaps_left = nullptr, sched_cache* cache = nullptr,
+                         size_t schedule_from = 2, uint32_t* d_zeroed_queue = nullptr) {
     if (!dd) return DINT_ERR_ARG;
     if (n_units == 0) return DINT_OK;
     if (!d_enc || !d_units || !d_out || enc_bytes < 8) return DINT_ERR_ARG;  // slots are fetched 8 bytes at a time
@@ -663,6 +670,26 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
     const uint32_t grid = uint32_t(std::min<uint64_t>(blocks_needed, std::max<uint32_t>(1, dd->compute_units) * kBlocksPerCU));
     const size_t lds_bytes = (size_t(dd->view.hot_words) + kClassTableWords + kWavesPerBlock * kScratchWords) * 4;
     dint_dict* mut = const_cast<dint_dict*>(dd);
+    if (d_zeroed_queue && (n_units < schedule_from || dd->no_bundles)) {
+        // the lean launch: the caller brings the (zeroed) queue counters, nothing is timed, nothing scheduled — one
+        // API call (a query's pages: the host-side cost of a launch sequence is what a single query waits for)
+        a.queue = d_zeroed_queue;
+        a.chunk_queue = a.queue + kQueueShards * kQueueStride;
+        a.n_shards = std::min<uint32_t>(kQueueShards, grid);
+        a.sched = nullptr;
+        a.items = nullptr;
+        a.n_items = nullptr;
+        a.item_cnt = nullptr;
+        a.urec = nullptr;
+        a.cbase = nullptr;
+        a.spans = d_spans;
+        if (dd->kind == DINT_DICT_MULTI_PACKED)
+            hipLaunchKernelGGL(decode_multi_kernel, dim3(grid), dim3(kBlockThreads), lds_bytes, s, a);
+        else
+            hipLaunchKernelGGL(decode_single_kernel, dim3(grid), dim3(kBlockThreads), lds_bytes, s, a);
+        HIP_TRY(hipGetLastError());
+        return DINT_OK;
+    }
     std::lock_guard<std::mutex> lock(mut->launch_mutex);
     const uint32_t slot = mut->next_slot.fetch_add(1) % dint_dict::kQueueSlots;
     mut->launches += 1;
@@ -679,7 +706,9 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
     a.urec = nullptr;
     a.cbase = nullptr;
     a.spans = d_spans;
-    if (n_units >= 2 && n_units < 0xFFFFFFFFull &&
+    // (schedule_from: a caller that decodes a handful of units at a time — a query's pages — does without the three
+    // schedule launches: with fewer units than waves nothing is gained by sharing tiles)
+    if (n_units >= schedule_from && n_units < 0xFFFFFFFFull &&
         !dd->no_bundles) {
         // workspace of the slot: [unit records 16 B x n][chunk bases 16 B x chunks][items u32 x n][block counts/offsets u32 x blocks]
         // [n_items u32][sched u8 x n][item counts u8 x n]
@@ -960,10 +989,9 @@ void dint_query_index_destroy(dint_query_index* qi) {
                     static_cast<void*>(qi->d_needed), static_cast<void*>(qi->d_rank),
                     static_cast<void*>(qi->d_touched), static_cast<void*>(qi->d_n_touched)})
         if (p) (void)hipFree(p);
-    qi->page_block.release();
-    qi->page_query.release();
-    qi->term_first.release();
-    qi->term_blocks.release();
+    if (qi->h_stage) (void)hipHostFree(qi->h_stage);
+    qi->inputs.release();
+    qi->ctrl.release();
     qi->cand.release();
     qi->target.release();
     qi->probe.release();
@@ -976,7 +1004,6 @@ void dint_query_index_destroy(dint_query_index* qi) {
     qi->freq_sums.release();
     qi->sub.release();
     qi->units.release();
-    qi->counts.release();
     delete qi;
 }
 
@@ -1015,7 +1042,7 @@ int dint_query_index_create(const dint_dict* docs_dict, const uint8_t* d_index, 
               hip_ok(hipMalloc(&qi->d_needed, nb * 4), "hipMalloc(needed)") &&
               hip_ok(hipMalloc(&qi->d_rank, nb * 4), "hipMalloc(rank)") &&
               hip_ok(hipMalloc(&qi->d_touched, nb * 4), "hipMalloc(touched)") &&
-              hip_ok(hipMalloc(&qi->d_n_touched, 4), "hipMalloc(n_touched)") &&
+              hip_ok(hipMalloc(&qi->d_n_touched, 8), "hipMalloc(n_touched)") &&  // {touched blocks, short pages} of a round
               hip_ok(hipMemset(qi->d_needed, 0, nb * 4), "hipMemset(needed)");
     if (ok && n_blocks)
         ok = hip_ok(hipMemcpy(qi->d_blocks, blocks, n_blocks * sizeof(dint_block_ref), hipMemcpyHostToDevice), "hipMemcpy(blocks)") &&
@@ -1059,6 +1086,35 @@ static int decode_pages(dint_query_index* qi, size_t n_pages, uint32_t* d_docs, 
                        qi->tails.p + n_pages, d_docs, cap, static_cast<uint64_t*>(nullptr), 0u, 1u, freqs_dict ? d_freqs : nullptr);
     hipLaunchKernelGGL(finalize_flagged_kernel, dim3(uint32_t((n_pages + 63) / 64)), dim3(64), 0, s, qi->sub.p, uint64_t(n_pages), d_docs,
                        cap, qi->gaps_left.p);
+    HIP_TRY(hipGetLastError());
+    return DINT_OK;
+}
+
+// Control words of one page decode (a call has one set for the candidates and one per round, cleared together):
+// [0] blocks the round touched, [1] short pages, [kCtrlQueueAt ...) the decode kernel's queue counters.
+constexpr size_t kCtrlQueueAt = 32;
+constexpr size_t kCtrlWords = kCtrlQueueAt + (kQueueShards + 1) * kQueueStride;
+
+// Pages -> docIDs, three launches on the stream: the pages are the blocks ids[0 .. *count) (count null: ids[0 .. bound)),
+// `bound` >= their number is what the launches are sized for. `ctrl`: this decode's (cleared) control words.
+// retire: the slots past each page's last posting are marked dead (candidate pages).
+static int decode_pages_counted(dint_query_index* qi, const uint32_t* d_ids, const uint32_t* d_count, size_t bound, uint32_t* d_docs,
+                                uint32_t* ctrl, uint32_t retire, hipStream_t s) {
+    if (!qi->sub.ensure(bound) || !qi->units.ensure(bound) || !qi->spans.ensure(bound) || !qi->bases.ensure(bound) ||
+        !qi->ends.ensure(bound) || !qi->gaps_left.ensure(bound) || !qi->tails.ensure(bound + 1))
+        return DINT_ERR_HIP;
+    const uint32_t tb = 256;
+    const uint64_t cap = uint64_t(bound) * kPageSlots;
+    uint32_t* const d_n_tails = ctrl + 1;
+    hipLaunchKernelGGL(prepare_pages_kernel, dim3(uint32_t((bound + tb - 1) / tb)), dim3(tb), 0, s, qi->d_blocks, uint64_t(qi->n_blocks),
+                       uint64_t(qi->index_bytes), d_ids, d_count, uint64_t(bound), qi->sub.p, qi->units.p, qi->spans.p, qi->bases.p,
+                       qi->gaps_left.p, qi->tails.p, d_n_tails);
+    int st = launch_decode(qi->docs, qi->d_index, qi->index_bytes, qi->units.p, bound, d_docs, cap, nullptr, s, 1, qi->spans.p, 0,
+                           qi->bases.p, qi->gaps_left.p, nullptr, 2048, ctrl + kCtrlQueueAt);
+    if (st != DINT_OK) return st;
+    // (the grid is sized for "every page is a short block": the waves with nothing to do leave at once)
+    hipLaunchKernelGGL(fix_pages_kernel, dim3(uint32_t((bound + kTailLanes - 1) / kTailLanes)), dim3(64), kTailLdsBytes, s, qi->d_index,
+                       uint64_t(qi->index_bytes), qi->sub.p, uint64_t(bound), qi->tails.p, d_n_tails, d_docs, cap, qi->gaps_left.p, retire);
     HIP_TRY(hipGetLastError());
     return DINT_OK;
 }
@@ -1121,60 +1177,89 @@ static int and_queries_impl(dint_query_index* qi, const dint_dict* freqs_dict, c
     std::lock_guard<std::mutex> lock(qi->mutex);
     HIP_TRY(hipSetDevice(qi->docs->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (!qi->page_block.ensure(n_pages) || !qi->page_query.ensure(n_pages) || !qi->sub.ensure(n_pages) ||
-        !qi->cand.ensure(n_slots) || !qi->target.ensure(n_slots) || !qi->term_first.ensure(h_first.size()) ||
-        !qi->term_blocks.ensure(h_blocks.size()) || !qi->counts.ensure(n_queries))
+    // inputs: {page -> block, page -> query, per round and query: first block and block count of the round's list}
+    const size_t in_words = 2 * n_pages + h_first.size() + h_blocks.size();
+    const size_t ctrl_words = (rounds + 1) * kCtrlWords + 2 * n_queries;  // ... and the result counters (u64 each) behind them
+    const size_t stage_bytes = std::max(in_words * 4, n_queries * sizeof(unsigned long long));
+    if (qi->h_stage_cap < stage_bytes) {
+        if (qi->h_stage) (void)hipHostFree(qi->h_stage);
+        qi->h_stage = nullptr;
+        qi->h_stage_cap = 0;
+        const size_t want = stage_bytes + stage_bytes / 2 + 4096;
+        HIP_TRY(hipHostMalloc(&qi->h_stage, want, hipHostMallocDefault));
+        qi->h_stage_cap = want;
+    }
+    if (!qi->inputs.ensure(in_words) || !qi->ctrl.ensure(ctrl_words) || !qi->cand.ensure(n_slots) || !qi->target.ensure(n_slots))
         return DINT_ERR_HIP;
-    HIP_TRY(hipMemcpyAsync(qi->page_block.p, h_page_block.data(), n_pages * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(qi->page_query.p, h_page_query.data(), n_pages * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(qi->term_first.p, h_first.data(), h_first.size() * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(qi->term_blocks.p, h_blocks.data(), h_blocks.size() * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemsetAsync(qi->counts.p, 0, n_queries * sizeof(unsigned long long), s));
+    {
+        uint32_t* h = static_cast<uint32_t*>(qi->h_stage);
+        std::memcpy(h, h_page_block.data(), n_pages * 4);
+        std::memcpy(h + n_pages, h_page_query.data(), n_pages * 4);
+        std::memcpy(h + 2 * n_pages, h_first.data(), h_first.size() * 4);
+        std::memcpy(h + 2 * n_pages + h_first.size(), h_blocks.data(), h_blocks.size() * 4);
+    }
+    uint32_t* const d_page_block = qi->inputs.p;
+    uint32_t* const d_page_query = d_page_block + n_pages;
+    uint32_t* const d_term_first = d_page_query + n_pages;
+    uint32_t* const d_term_blocks = d_term_first + h_first.size();
+    unsigned long long* const d_counts = reinterpret_cast<unsigned long long*>(qi->ctrl.p + (rounds + 1) * kCtrlWords);
+    HIP_TRY(hipMemcpyAsync(qi->inputs.p, qi->h_stage, in_words * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(qi->ctrl.p, 0, ctrl_words * 4, s));
 
     const uint32_t tb = 256;
-    const uint32_t page_grid = uint32_t((n_pages + tb - 1) / tb);
     const uint32_t slot_grid = uint32_t(n_pages);  // 256 slots per page = one workgroup
+    if (qi->claims_dirty) {  // (a call that failed between a search and its release left claim flags behind)
+        HIP_TRY(hipMemsetAsync(qi->d_needed, 0, std::max<size_t>(1, qi->n_blocks) * 4, s));
+        qi->claims_dirty = false;
+    }
     // candidates: the rarest list of every query
-    hipLaunchKernelGGL(gather_pages_kernel, dim3(page_grid), dim3(tb), 0, s, qi->d_blocks, qi->page_block.p,
-                       uint64_t(n_pages), qi->sub.p);
-    // (a failure between and_search_kernel and and_release_kernel would leave claim flags behind: start clean)
-    HIP_TRY(hipMemsetAsync(qi->d_needed, 0, std::max<size_t>(1, qi->n_blocks) * 4, s));
-    int st = decode_pages(qi, n_pages, qi->cand.p, nullptr, nullptr, s);
+    int st = decode_pages_counted(qi, d_page_block, nullptr, n_pages, qi->cand.p, qi->ctrl.p, 1u, s);
     if (st != DINT_OK) {
         (void)hipStreamSynchronize(s);
         return st;
     }
-    hipLaunchKernelGGL(retire_page_tails_kernel, dim3(slot_grid), dim3(tb), 0, s, qi->sub.p, uint64_t(n_pages), qi->cand.p);
+    qi->claims_dirty = true;  // until the call has run to its end
 
+    // A round: block-max search -> the touched blocks, without duplicates -> decoded -> every candidate probes its
+    // block. How many blocks a round touches only the device knows; the host knows a bound (the live candidates at
+    // most, and no more blocks than the round's lists have) and sizes the launches for that — nothing on the host
+    // waits for a round: a call is one copy in, one clear, five launches per round, one copy back. (Round 1 read the
+    // count back every round and made fourteen API calls per round: a query at a time, the host's share was most of
+    // the 200 us a query took.) Past kAsyncPages the count is read back after all: launches sized for a bound far
+    // above the truth cost more than the wait.
+    constexpr size_t kAsyncPages = 32768;
     for (size_t r = 0; r != rounds; ++r) {
-        const uint32_t* first = qi->term_first.p + r * n_queries;
-        const uint32_t* nblk = qi->term_blocks.p + r * n_queries;
-        HIP_TRY(hipMemsetAsync(qi->d_n_touched, 0, 4, s));
-        hipLaunchKernelGGL(and_search_kernel, dim3(slot_grid), dim3(tb), 0, s, qi->cand.p, n_slots, qi->page_query.p,
-                           first, nblk, qi->d_block_max, qi->target.p, qi->d_needed, qi->d_rank, qi->d_touched,
-                           qi->d_n_touched);
-        uint32_t n_touched = 0;
-        HIP_TRY(hipMemcpyAsync(&n_touched, qi->d_n_touched, 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        if (n_touched == 0) continue;  // nothing left to probe in this round
-        if (!qi->sub.ensure(std::max<size_t>(n_pages, n_touched)) || !qi->probe.ensure(uint64_t(n_touched) * kPageSlots)) {
+        const uint32_t* first = d_term_first + r * n_queries;
+        const uint32_t* nblk = d_term_blocks + r * n_queries;
+        uint32_t* const ctrl = qi->ctrl.p + (r + 1) * kCtrlWords;
+        uint64_t list_blocks = 0;
+        for (size_t q = 0; q != n_queries; ++q) list_blocks += h_blocks[r * n_queries + q];
+        if (list_blocks == 0) continue;  // no query has a term for this round
+        size_t bound = size_t(std::min<uint64_t>(n_slots, list_blocks));
+        hipLaunchKernelGGL(and_search_kernel, dim3(slot_grid), dim3(tb), 0, s, qi->cand.p, n_slots, d_page_query,
+                           first, nblk, qi->d_block_max, qi->target.p, qi->d_needed, qi->d_rank, qi->d_touched, ctrl);
+        const uint32_t* d_count = ctrl;
+        if (bound > kAsyncPages) {
+            uint32_t n_touched = 0;
+            HIP_TRY(hipMemcpyAsync(&n_touched, ctrl, 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (n_touched == 0) continue;  // nothing left to probe in this round
+            bound = n_touched;
+            d_count = nullptr;
+        }
+        if (!qi->probe.ensure(uint64_t(bound) * kPageSlots)) {
             (void)hipStreamSynchronize(s);
             return DINT_ERR_HIP;
         }
-        const uint32_t tgrid = (n_touched + tb - 1) / tb;
-        hipLaunchKernelGGL(gather_pages_kernel, dim3(tgrid), dim3(tb), 0, s, qi->d_blocks, qi->d_touched,
-                           uint64_t(n_touched), qi->sub.p);
-        st = decode_pages(qi, n_touched, qi->probe.p, nullptr, nullptr, s);
+        st = decode_pages_counted(qi, qi->d_touched, d_count, bound, qi->probe.p, ctrl, 0u, s);
         if (st != DINT_OK) {
             (void)hipStreamSynchronize(s);
             return st;
         }
-        hipLaunchKernelGGL(and_probe_kernel, dim3(slot_grid), dim3(tb), 0, s, qi->cand.p, n_slots, qi->page_query.p,
-                           nblk, qi->d_blocks, qi->target.p, qi->d_rank, qi->probe.p);
-        hipLaunchKernelGGL(and_release_kernel, dim3(tgrid), dim3(tb), 0, s, qi->d_touched, n_touched, qi->d_needed);
+        hipLaunchKernelGGL(and_probe_release_kernel, dim3(slot_grid), dim3(tb), 0, s, qi->cand.p, n_slots, d_page_query, nblk, qi->d_blocks,
+                           qi->target.p, qi->d_rank, qi->probe.p, qi->d_touched, ctrl, qi->d_needed);
     }
-    hipLaunchKernelGGL(and_count_kernel, dim3(slot_grid), dim3(tb), 0, s, qi->cand.p, n_slots, qi->page_query.p,
-                       qi->counts.p);
+    hipLaunchKernelGGL(and_count_kernel, dim3(slot_grid), dim3(tb), 0, s, qi->cand.p, n_slots, d_page_query, d_counts);
     HIP_TRY(hipGetLastError());
     // ---- and_query<true> (queries.hpp:72-76): the freq of every term at every match. Lazily, like the reference's
     // freq(): a freqs part is decoded only for the blocks that hold a match — term by term, the blocks the
@@ -1185,11 +1270,11 @@ static int and_queries_impl(dint_query_index* qi, const dint_dict* freqs_dict, c
         if (!qi->freq_sums.ensure(n_queries)) return DINT_ERR_HIP;
         HIP_TRY(hipMemsetAsync(qi->freq_sums.p, 0, n_queries * sizeof(unsigned long long), s));
         for (size_t r = 0; r != rounds + 1; ++r) {  // r = 0: the rarest term; r >= 1: the term of round r - 1
-            const uint32_t* first = r ? qi->term_first.p + (r - 1) * n_queries : nullptr;
-            const uint32_t* nblk = r ? qi->term_blocks.p + (r - 1) * n_queries : nullptr;
+            const uint32_t* first = r ? d_term_first + (r - 1) * n_queries : nullptr;
+            const uint32_t* nblk = r ? d_term_blocks + (r - 1) * n_queries : nullptr;
             HIP_TRY(hipMemsetAsync(qi->d_n_touched, 0, 4, s));
-            hipLaunchKernelGGL(and_freq_search_kernel, dim3(slot_grid), dim3(tb), 0, s, qi->cand.p, n_slots, qi->page_query.p,
-                               qi->page_block.p, first, nblk, qi->d_block_max, qi->target.p, qi->d_needed, qi->d_rank,
+            hipLaunchKernelGGL(and_freq_search_kernel, dim3(slot_grid), dim3(tb), 0, s, qi->cand.p, n_slots, d_page_query,
+                               d_page_block, first, nblk, qi->d_block_max, qi->target.p, qi->d_needed, qi->d_rank,
                                qi->d_touched, qi->d_n_touched);
             uint32_t n_touched = 0;
             HIP_TRY(hipMemcpyAsync(&n_touched, qi->d_n_touched, 4, hipMemcpyDeviceToHost, s));
@@ -1209,7 +1294,7 @@ static int and_queries_impl(dint_query_index* qi, const dint_dict* freqs_dict, c
                 (void)hipStreamSynchronize(s);
                 return st;
             }
-            hipLaunchKernelGGL(and_freq_gather_kernel, dim3(slot_grid), dim3(tb), 0, s, qi->cand.p, n_slots, qi->page_query.p, nblk,
+            hipLaunchKernelGGL(and_freq_gather_kernel, dim3(slot_grid), dim3(tb), 0, s, qi->cand.p, n_slots, d_page_query, nblk,
                                qi->d_blocks, qi->target.p, qi->d_rank, qi->probe.p, qi->fprobe.p, qi->freq_sums.p);
             hipLaunchKernelGGL(and_release_kernel, dim3(tgrid), dim3(tb), 0, s, qi->d_touched, n_touched, qi->d_needed);
         }
@@ -1217,9 +1302,10 @@ static int and_queries_impl(dint_query_index* qi, const dint_dict* freqs_dict, c
         h_sums.resize(n_queries);
         HIP_TRY(hipMemcpyAsync(h_sums.data(), qi->freq_sums.p, n_queries * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     }
-    std::vector<unsigned long long> h_counts(n_queries);
-    HIP_TRY(hipMemcpyAsync(h_counts.data(), qi->counts.p, n_queries * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    unsigned long long* const h_counts = static_cast<unsigned long long*>(qi->h_stage);  // (the inputs have long been copied)
+    HIP_TRY(hipMemcpyAsync(h_counts, d_counts, n_queries * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    qi->claims_dirty = false;
     for (size_t q = 0; q != n_queries; ++q) counts[q] = h_counts[q];
     if (freqs_dict)
         for (size_t q = 0; q != n_queries; ++q) freq_sums[q] = h_sums[q];

@@ -1844,16 +1844,15 @@ constexpr uint32_t kTailRow = 257;     // words per lane and row: up to 255 valu
 constexpr uint32_t kTailStack = 41;    // words per lane: 10 frames of 4 (depth <= log2(256) + 1)
 constexpr uint32_t kTailLdsBytes = kTailLanes * (kTailRow + kTailStack) * 4;
 
-__global__ __launch_bounds__(64) void interpolative_tails_kernel(const uint8_t* index, uint64_t index_bytes,
-                                                                 const dint_block_ref* blocks, const uint64_t* docs_end,
-                                                                 const uint32_t* tails, const uint32_t* n_tails, uint32_t* out,
-                                                                 uint64_t out_capacity, uint64_t* end_off, uint32_t plus_one,
-                                                                 uint32_t as_docids = 0, uint32_t* freqs_out = nullptr) {
+__device__ __forceinline__ void interpolative_tails_wave(const uint8_t* index, uint64_t index_bytes,
+                                                         const dint_block_ref* blocks, const uint64_t* docs_end,
+                                                         const uint32_t* tails, const uint32_t* n_tails, uint32_t* out,
+                                                         uint64_t out_capacity, uint64_t* end_off, uint32_t plus_one,
+                                                         uint32_t as_docids, uint32_t* freqs_out) {
     extern __shared__ __attribute__((aligned(16))) uint32_t tail_lds[];
     __shared__ uint32_t row_n[kTailLanes], row_base[kTailLanes];
     __shared__ uint64_t row_out[kTailLanes];
     const uint32_t lane = threadIdx.x;
-    if (uint64_t(blockIdx.x) * kTailLanes >= *n_tails) return;  // (the grid may be sized for the worst case)
     const uint64_t t = uint64_t(blockIdx.x) * kTailLanes + lane;
     uint32_t* const o = tail_lds + (lane % kTailLanes) * kTailRow;
     uint32_t* const stack = tail_lds + kTailLanes * kTailRow + (lane % kTailLanes) * kTailStack;
@@ -1907,6 +1906,15 @@ __global__ __launch_bounds__(64) void interpolative_tails_kernel(const uint8_t* 
         const uint32_t nj = row_n[j];
         for (uint32_t i = lane; i < nj; i += 64) freqs_out[row_out[j] + i] = tail_lds[j * kTailRow + i] + 1u;
     }
+}
+
+__global__ __launch_bounds__(64) void interpolative_tails_kernel(const uint8_t* index, uint64_t index_bytes,
+                                                                 const dint_block_ref* blocks, const uint64_t* docs_end,
+                                                                 const uint32_t* tails, const uint32_t* n_tails, uint32_t* out,
+                                                                 uint64_t out_capacity, uint64_t* end_off, uint32_t plus_one,
+                                                                 uint32_t as_docids = 0, uint32_t* freqs_out = nullptr) {
+    if (uint64_t(blockIdx.x) * kTailLanes >= *n_tails) return;  // (the grid may be sized for the worst case)
+    interpolative_tails_wave(index, index_bytes, blocks, docs_end, tails, n_tails, out, out_capacity, end_off, plus_one, as_docids, freqs_out);
 }
 
 // gaps -> docIDs (docid_i = base + sum_{j<=i} gap_j + i, dict_posting_list.hpp:111-124) and
@@ -1966,6 +1974,44 @@ __global__ __launch_bounds__(64) void finalize_flagged_kernel(const dint_block_r
             run += g[k];
             if (i < n) docids[at + i] = run;
         }
+    }
+}
+
+// What is left to do on a query's pages behind the decode kernel, in one launch (wave w: short blocks
+// tails[8w .. 8w+8), pages 8w .. 8w+8): the short blocks' interpolative docs parts (as docIDs), the gaps -> docIDs of
+// the pages the decode kernel flagged, and — `retire` — the slots past every page's last posting marked as holding no
+// candidate (0xFFFFFFFF is no docID).
+__global__ __launch_bounds__(64) void fix_pages_kernel(const uint8_t* index, uint64_t index_bytes, const dint_block_ref* pages,
+                                                       uint64_t n_pages, const uint32_t* tails, const uint32_t* n_tails, uint32_t* docids,
+                                                       uint64_t out_capacity, const uint8_t* todo, uint32_t retire) {
+    if (uint64_t(blockIdx.x) * kTailLanes < *n_tails)
+        interpolative_tails_wave(index, index_bytes, pages, nullptr, tails, n_tails, docids, out_capacity, nullptr, 0u, 1u, nullptr);
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t j = 0; j != kTailLanes; ++j) {
+        const uint64_t b = uint64_t(blockIdx.x) * kTailLanes + j;
+        if (b >= n_pages) break;
+        const uint32_t n = pages[b].n;
+        const uint64_t at = pages[b].out_off;
+        if (at + 256 > out_capacity) continue;
+        if (todo[b] != 0 && n != 0 && n <= 256) {  // wave-uniform
+            uint32_t g[4], local = 0;
+#pragma unroll
+            for (uint32_t k = 0; k != 4; ++k) {
+                const uint32_t i = 4 * lane + k;
+                g[k] = i < n ? docids[at + i] + 1 : 0;
+                local += g[k];
+            }
+            uint32_t run = pages[b].base + wave_inclusive_sum(local) - local - 1;
+#pragma unroll
+            for (uint32_t k = 0; k != 4; ++k) {
+                const uint32_t i = 4 * lane + k;
+                run += g[k];
+                if (i < n) docids[at + i] = run;
+            }
+        }
+        if (retire)
+            for (uint32_t i = lane; i < 256; i += 64)
+                if (i >= n) docids[at + i] = 0xFFFFFFFFu;
     }
 }
 

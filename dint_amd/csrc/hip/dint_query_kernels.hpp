@@ -32,11 +32,38 @@ __global__ void gather_pages_kernel(const dint_block_ref* blocks, const uint32_t
     sub[i] = r;
 }
 
-// the slots past a short block's end hold no candidate
-__global__ void retire_page_tails_kernel(const dint_block_ref* sub, uint64_t n_pages, uint32_t* cand) {
+// Everything a decode of pages needs, in one launch: page i < *count (count null: i < bound) is block ids[i], relocated to
+// page i; the others (bound is what the host knows — the device knows how many pages there are) are empty. -> the pages'
+// block records, their docs parts as units (byte span: up to where the next block of the index begins), their docID
+// bases, the list of the short (interpolative) ones, and cleared "left as gaps" flags.
+__global__ void prepare_pages_kernel(const dint_block_ref* blocks, uint64_t n_blocks_total, uint64_t index_bytes, const uint32_t* ids,
+                                     const uint32_t* count, uint64_t bound, dint_block_ref* sub, dint_unit* units, uint32_t* spans,
+                                     uint32_t* bases, uint8_t* gaps_left, uint32_t* tails, uint32_t* n_tails) {
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n_pages * kPageSlots) return;
-    if (uint32_t(i % kPageSlots) >= sub[i / kPageSlots].n) cand[i] = kDeadCandidate;
+    if (i >= bound) return;
+    const uint64_t n_pages = count ? uint64_t(*count) : bound;
+    dint_block_ref r{};
+    dint_unit u{};
+    uint32_t span = 0;
+    if (i < n_pages) {
+        const uint64_t gb = ids[i];
+        r = blocks[gb];
+        uint64_t nxt = gb + 1 < n_blocks_total ? blocks[gb + 1].in_off : index_bytes;
+        if (nxt <= r.in_off || nxt > index_bytes) nxt = index_bytes;
+        const uint64_t sp = nxt > r.in_off ? nxt - r.in_off : 0;
+        span = sp > 0xFFFFFFFFull ? 0xFFFFFFFFu : uint32_t(sp);
+        if (r.n != 0 && r.n < 256) tails[atomicAdd(n_tails, 1u)] = uint32_t(i);
+    }
+    r.out_off = i * kPageSlots;
+    u.in_off = r.in_off;
+    u.out_off = r.out_off;
+    u.n = r.n;
+    u.list = r.list;
+    sub[i] = r;
+    units[i] = u;
+    spans[i] = span;
+    bases[i] = r.base;
+    gaps_left[i] = 0;
 }
 
 // first index in [0, n) with a[i] >= key (n if none)
@@ -87,11 +114,13 @@ __global__ void and_search_kernel(uint32_t* cand, uint64_t n_slots, const uint32
     }
 }
 
-// Round step B: each live candidate looks itself up in its (now decoded) block.
-__global__ void and_probe_kernel(uint32_t* cand, uint64_t n_slots, const uint32_t* page_query,
-                                 const uint32_t* term_blocks, const dint_block_ref* blocks, const uint32_t* target,
-                                 const uint32_t* rank, const uint32_t* probe) {
+// Round steps B and C in one launch: each live candidate looks itself up in its (now decoded) block, and — thread k, for the k-th touched block — the claim flag cleared for
+// the next round (the probe reads target / rank, not the flags).
+__global__ void and_probe_release_kernel(uint32_t* cand, uint64_t n_slots, const uint32_t* page_query, const uint32_t* term_blocks,
+                                         const dint_block_ref* blocks, const uint32_t* target, const uint32_t* rank,
+                                         const uint32_t* probe, const uint32_t* touched, const uint32_t* n_touched, uint32_t* needed) {
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < *n_touched) needed[touched[i]] = 0;
     if (i >= n_slots) return;
     const uint32_t c = cand[i];
     if (c == kDeadCandidate || term_blocks[page_query[i / kPageSlots]] == 0) return;
@@ -153,7 +182,6 @@ __global__ void and_release_kernel(const uint32_t* touched, uint32_t n_touched, 
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n_touched) needed[touched[k]] = 0;
 }
-
 // results += 1 per surviving candidate (queries.hpp:72-76); a page belongs to one query
 __global__ void and_count_kernel(const uint32_t* cand, uint64_t n_slots, const uint32_t* page_query,
                                  unsigned long long* counts) {
