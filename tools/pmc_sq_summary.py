@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""SQ counters of the decode kernel, per launch and per decoded integer, from the sq1/ sq2/ passes of
+tools/profile_round.sh (a bench step is one launch of the decode kernel).
+usage: tools/pmc_sq_summary.py <out dir> <ints per step>"""
+import collections, csv, glob, json, os, sys
+out, ints_per_step = sys.argv[1], float(sys.argv[2])
+bench = json.load(open(os.path.join(out, "bench.json")))
+ints = ints_per_step
+agg = collections.defaultdict(lambda: [0.0, 0])
+kernel = None
+for f in sorted(glob.glob(os.path.join(out, "sq*", "**", "*counter_collection.csv"), recursive=True)):
+    for row in csv.DictReader(open(f)):
+        if not row["Kernel_Name"].startswith(("dint_dev::decode_single_kernel", "dint_dev::decode_multi_kernel")):
+            continue
+        kernel = row["Kernel_Name"].split("(")[0]
+        a = agg[row["Counter_Name"]]
+        a[0] += float(row["Counter_Value"])
+        a[1] += 1
+print(f"kernel {kernel}: {ints:.4g} integers per launch ({bench['metric']})")
+for k in sorted(agg):
+    v, n = agg[k]
+    print(f"{k:24s} per launch {v / n:14.6g}   per integer {v / n / ints:9.4f}   ({n} launches)")
+g = lambda k: agg[k][0] / max(1, agg[k][1])
+if "SQ_WAVE_CYCLES" in agg:
+    print(f"VALU instructions per integer {g('SQ_INSTS_VALU') / ints:.3f}; SALU {g('SQ_INSTS_SALU') / ints:.3f}; LDS {g('SQ_INSTS_LDS') / ints:.3f}; "
+          f"waves waiting {100 * g('SQ_WAIT_ANY') / g('SQ_WAVE_CYCLES'):.1f} % of their cycles")
