@@ -1622,7 +1622,11 @@ template <bool MULTI>
 __device__ __forceinline__ void decode_kernel_body(const decode_args& kernarg) {
     const decode_args a = own_scalars(kernarg);
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    for (uint32_t i = threadIdx.x; i < a.dict.hot_words; i += kBlockThreads) lds[i] = a.dict.lds_image[i];
+    // the dictionary's hot part, 16 bytes a thread and step (hot_words is a multiple of 4): five steps instead of
+    // eighteen dependent round trips — nothing for a launch that decodes 10^9 integers, a third of one that decodes a
+    // query's handful of pages
+    for (uint32_t i = threadIdx.x; 4 * i < a.dict.hot_words; i += kBlockThreads)
+        reinterpret_cast<u32x4*>(lds)[i] = reinterpret_cast<const u32x4*>(a.dict.lds_image)[i];
     uint16_t* const cls = reinterpret_cast<uint16_t*>(lds + a.dict.hot_words);
     build_class_table(cls);
     uint32_t* const descs = lds + a.dict.hot_words + kDescWordAt;

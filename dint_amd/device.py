@@ -140,7 +140,7 @@ class Dictionary:
 
     def close(self) -> None:
         h, self._h = self._h, C.c_void_p()
-        if h:
+        if h and _lib is not None:  # (None at interpreter shutdown)
             _lib.dint_dict_destroy(h)
 
     def __del__(self):
@@ -276,7 +276,7 @@ class BlockTable:
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and _lib is not None:
             _lib.dint_block_table_destroy(h)
 
     __del__ = close
@@ -313,7 +313,7 @@ class QueryIndex:
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and _lib is not None:  # (None at interpreter shutdown)
             _lib.dint_query_index_destroy(h)
 
     __del__ = close
@@ -332,6 +332,12 @@ class QueryIndex:
         _check(_lib.dint_and_queries(self._h, terms.ctypes.data, offs.ctypes.data, len(queries),
                                      counts.ctypes.data, stream), "dint_and_queries")
         return counts
+
+    def and_queries_packed(self, terms: np.ndarray, offsets: np.ndarray, counts: np.ndarray, stream: int = 0) -> None:
+        """The bare call: queries already packed (`terms` u32, `offsets` u64[n + 1], `counts` u64[n] out) — what a
+        C++ caller hands over; and_queries() packs Python lists first."""
+        _check(_lib.dint_and_queries(self._h, terms.ctypes.data, offsets.ctypes.data, counts.size, counts.ctypes.data, stream),
+               "dint_and_queries")
 
     def and_queries_with_freqs(self, freqs_dict: "Dictionary", queries):
         """`and_query<true>` for a batch -> (counts, sums of the freqs read at the matches, freqs blocks decoded)."""

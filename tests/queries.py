@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def reference_queries(n_lists: int):
+    """n_lists >= 113 243 (the log's largest term id + 1, e.g. host.readme_test_collection): the log as it is."""
     out = []
     with open(os.path.join(_HERE, "golden", "queries.txt")) as f:
         for line in f:
@@ -57,3 +58,25 @@ def intersect_freqs(docids: np.ndarray, freqs: np.ndarray, bounds: np.ndarray, t
         pos = np.searchsorted(docids[lo:hi], cur)
         total += int(freqs[lo:hi][pos].astype(np.uint64).sum())
     return int(cur.size), total
+
+
+class ReadmeIndex:
+    """The README-shaped stand-in for the reference's test collection (host.readme_test_collection) as an index:
+    113 306 lists, so the reference's query log (term ids up to 113 242) addresses it without folding."""
+    _cache = {}
+
+    def __new__(cls, kind):
+        if kind not in cls._cache:
+            from dint_amd import host
+
+            self = object.__new__(cls)
+            coll = host.readme_test_collection(seed=1)
+            self.docids = host.gaps_to_docids(coll)
+            self.freqs = host.synth_freqs(coll.num_postings, 3)
+            self.lens = coll.lens
+            self.bounds = coll.list_bounds()
+            self.docs_dict = host.build_dictionary(kind, coll)
+            self.freqs_dict = host.build_dictionary(kind, host.Collection(self.freqs - 1, coll.lens))
+            self.bytes, self.offsets = host.build_index(kind, self.docs_dict, self.freqs_dict, self.docids, self.freqs, coll.lens)
+            cls._cache[kind] = self
+        return cls._cache[kind]

@@ -59,13 +59,21 @@ def main():
             t0 = time.perf_counter()
             qi.and_queries(qs)
             t_batch.append(time.perf_counter() - t0)
+        # one query per call, the reference's op_perftest shape: the queries are parsed (packed) beforehand, the
+        # timed region is the call
+        packed = []
+        for q in qs:
+            t = np.ascontiguousarray(q, dtype=np.uint32)
+            packed.append((t, np.array([0, t.size], dtype=np.uint64), np.zeros(1, dtype=np.uint64)))
+        stream = torch.cuda.current_stream().cuda_stream
+        for t, o, c in packed:
+            qi.and_queries_packed(t, o, c, stream)
         single = []
-        for q in qs:
-            qi.and_queries([q])
-        for q in qs:
+        for (t, o, c), want in zip(packed, counts):
             t0 = time.perf_counter()
-            qi.and_queries([q])
+            qi.and_queries_packed(t, o, c, stream)
             single.append((time.perf_counter() - t0) * 1e6)
+            assert int(c[0]) == int(want)
         single = np.sort(np.array(single))
         cpu_q = qs[:args.cpu_queries]
         cpu = []

@@ -5,7 +5,7 @@ import pytest
 
 import oracle
 from dint_amd import host
-from queries import heavy_queries, intersect, intersect_freqs, reference_queries
+from queries import ReadmeIndex, heavy_queries, intersect, intersect_freqs, reference_queries
 from test_index_cpu import get_index
 
 pytestmark = pytest.mark.gpu
@@ -141,4 +141,25 @@ def test_with_freqs_edges(device, dense_corpus):
     wrong = device.Dictionary(host.RECTANGULAR, get_index(dense_corpus, host.RECTANGULAR).freqs_dict)
     with pytest.raises(device.DintError):
         qi.and_queries_with_freqs(wrong, [[big]])
+    qi.close()
+
+
+@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
+def test_reference_query_log_on_the_readme_shaped_collection(device, kind):
+    """BASELINE config 5 on config 1's collection: the reference's query log, term ids as they are, over an index of the
+    shape README.md:53 gives (113 306 lists) — batched and one query per call (op_perftest, src/queries.cpp:15-61),
+    with and without freqs, against the oracle and plain set intersection."""
+    ix = ReadmeIndex(kind)
+    qs = reference_queries(len(ix.lens))
+    dd = device.Dictionary(kind, ix.docs_dict)
+    fd = device.Dictionary(kind, ix.freqs_dict)
+    qi = device.QueryIndex(dd, ix.bytes, ix.offsets)
+    want = np.array([intersect(ix.docids, ix.bounds, q) for q in qs], dtype=np.uint64)
+    assert np.array_equal(qi.and_queries(qs), want) and int(want.sum()) > 500
+    counts, sums, _ = qi.and_queries_with_freqs(fd, qs)
+    wf = [intersect_freqs(ix.docids, ix.freqs, ix.bounds, q) for q in qs]
+    assert np.array_equal(counts, want) and np.array_equal(sums, np.array([w[1] for w in wf], dtype=np.uint64))
+    oi = oracle.OracleIndex(oracle.OracleDict(kind, ix.docs_dict), ix.bytes, ix.offsets, 10_000)
+    for i in range(0, len(qs), 11):
+        assert int(qi.and_queries([qs[i]])[0]) == oi.and_query(qs[i]) == int(want[i])
     qi.close()

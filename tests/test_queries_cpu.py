@@ -6,7 +6,7 @@ import pytest
 
 import oracle
 from dint_amd import host
-from queries import heavy_queries, intersect, reference_queries
+from queries import ReadmeIndex, heavy_queries, intersect, intersect_freqs, reference_queries
 from test_index_cpu import get_index
 
 
@@ -46,3 +46,24 @@ def test_oracle_and_query_edges(dense_corpus):
     assert oracle.and_query(od, ix.bytes, ix.offsets, nd, [longest] * 4) == int(ix.lens[longest])  # :28-31
     assert oracle.and_query(od, ix.bytes, ix.offsets, nd, [shortest, longest]) == intersect(
         ix.docids, ix.bounds, [shortest, longest])
+
+
+def test_reference_query_log_on_the_readme_shaped_collection():
+    """the reference's own query log (test/test_data/queries) over an index of the
+    shape its README gives for the test collection — term ids as they are, no folding. and_query<false> and <true> of the
+    oracle against plain set intersection of the builder's input."""
+    kind = host.SINGLE_PACKED
+    ix = ReadmeIndex(kind)
+    qs = reference_queries(len(ix.lens))
+    assert len(ix.lens) == 113_306 and max(int(q.max()) for q in qs) == 113_242
+    oi = oracle.OracleIndex(oracle.OracleDict(kind, ix.docs_dict), ix.bytes, ix.offsets, 10_000)
+    ofd = oracle.OracleDict(kind, ix.freqs_dict)
+    hits = 0
+    for i, q in enumerate(qs):
+        want = intersect(ix.docids, ix.bounds, q)
+        assert oi.and_query(q) == want
+        if i % 5 == 0:
+            n, fsum, _ = oi.and_query_freqs(ofd, q)
+            assert (n, fsum) == intersect_freqs(ix.docids, ix.freqs, ix.bounds, q)
+        hits += want
+    assert hits > 500
