@@ -896,13 +896,15 @@ int block_table_decode(const dint_dict* docs_dict, const dint_dict* freqs_dict, 
                            nullptr, nullptr, keep ? &mt.freqs_sched : nullptr);
         if (st != DINT_OK) return st;
     }
+    // the short blocks' waves also look through the "left as gaps" flags (a slow codeword, a block of more than 256
+    // slots: next to none), one share each; a table without short blocks gets the flags kernel alone
     if (tgrid)
         hipLaunchKernelGGL(interpolative_tails_kernel, dim3(tgrid), dim3(64), kTailLdsBytes, s, d_index, uint64_t(index_bytes), t.d_blocks,
                            static_cast<const uint64_t*>(nullptr), t.d_tails, t.d_tails + n_blocks, d_docids, uint64_t(out_capacity),
-                           static_cast<uint64_t*>(nullptr), 0u, 1u, d_freqs);
-    // the blocks that had to stay gaps (a slow codeword, a block of more than 256 slots): next to none
-    hipLaunchKernelGGL(finalize_flagged_kernel, dim3(uint32_t((n_blocks + 63) / 64)), dim3(64), 0, s, t.d_blocks, uint64_t(n_blocks),
-                       d_docids, uint64_t(out_capacity), t.d_gaps_left);
+                           static_cast<uint64_t*>(nullptr), 0u, 1u, d_freqs, t.d_gaps_left, uint64_t(n_blocks));
+    else
+        hipLaunchKernelGGL(finalize_flagged_kernel, dim3(uint32_t((n_blocks + 63) / 64)), dim3(64), 0, s, t.d_blocks, uint64_t(n_blocks),
+                           d_docids, uint64_t(out_capacity), t.d_gaps_left);
     HIP_TRY(hipGetLastError());
     mt.decodes += 1;
     return DINT_OK;

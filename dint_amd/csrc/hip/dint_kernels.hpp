@@ -1916,9 +1916,39 @@ __global__ __launch_bounds__(64) void interpolative_tails_kernel(const uint8_t* 
                                                                  const dint_block_ref* blocks, const uint64_t* docs_end,
                                                                  const uint32_t* tails, const uint32_t* n_tails, uint32_t* out,
                                                                  uint64_t out_capacity, uint64_t* end_off, uint32_t plus_one,
-                                                                 uint32_t as_docids = 0, uint32_t* freqs_out = nullptr) {
-    if (uint64_t(blockIdx.x) * kTailLanes >= *n_tails) return;  // (the grid may be sized for the worst case)
-    interpolative_tails_wave(index, index_bytes, blocks, docs_end, tails, n_tails, out, out_capacity, end_off, plus_one, as_docids, freqs_out);
+                                                                 uint32_t as_docids = 0, uint32_t* freqs_out = nullptr,
+                                                                 const uint8_t* todo = nullptr, uint64_t n_blocks = 0) {
+    // (the grid may be sized for the worst case)
+    if (uint64_t(blockIdx.x) * kTailLanes < *n_tails)
+        interpolative_tails_wave(index, index_bytes, blocks, docs_end, tails, n_tails, out, out_capacity, end_off, plus_one, as_docids, freqs_out);
+    if (!todo) return;
+    // ... and this wave's share of the blocks the decode kernels flagged as left in gaps (next to none): gaps -> docIDs
+    const uint32_t lane = threadIdx.x;
+    const uint64_t share = ((n_blocks + gridDim.x - 1) / gridDim.x + 63) / 64 * 64;
+    for (uint64_t b0 = share * blockIdx.x; b0 < share * (blockIdx.x + 1) && b0 < n_blocks; b0 += 64) {
+        uint64_t flagged = __ballot(b0 + lane < n_blocks && todo[b0 + lane] != 0);
+        while (flagged) {  // wave-uniform
+            const uint64_t b = b0 + uint32_t(__builtin_ctzll(flagged));
+            flagged &= flagged - 1;
+            const uint32_t n = blocks[b].n;
+            const uint64_t at = blocks[b].out_off;
+            if (n == 0 || n > 256 || at + n > out_capacity) continue;
+            uint32_t g[4], local = 0;
+#pragma unroll
+            for (uint32_t k = 0; k != 4; ++k) {
+                const uint32_t i = 4 * lane + k;
+                g[k] = i < n ? out[at + i] + 1 : 0;
+                local += g[k];
+            }
+            uint32_t run = blocks[b].base + wave_inclusive_sum(local) - local - 1;
+#pragma unroll
+            for (uint32_t k = 0; k != 4; ++k) {
+                const uint32_t i = 4 * lane + k;
+                run += g[k];
+                if (i < n) out[at + i] = run;
+            }
+        }
+    }
 }
 
 // gaps -> docIDs (docid_i = base + sum_{j<=i} gap_j + i, dict_posting_list.hpp:111-124) and
