@@ -17,6 +17,7 @@
 
 #include "dint_kernels.hpp"
 #include "dint_query_kernels.hpp"
+#include "dint_stats_kernels.hpp"
 
 namespace {
 
@@ -1311,6 +1312,146 @@ static int and_queries_impl(dint_query_index* qi, const dint_dict* freqs_dict, c
     for (size_t q = 0; q != n_queries; ++q) counts[q] = h_counts[q];
     if (freqs_dict)
         for (size_t q = 0; q != n_queries; ++q) freq_sums[q] = h_sums[q];
+    return DINT_OK;
+}
+
+// ---- block statistics ------------------------------------------------------------------------------
+
+int dint_count_ngrams(int device, int multi, const uint32_t* d_gaps, uint64_t n_ints, const uint64_t* list_starts,
+                      uint64_t n_lists, uint32_t top_k, dint_ngram** entries, size_t* n_entries, float* kernel_ms) {
+    if (!entries || !n_entries || (n_lists && (!list_starts || !d_gaps))) return DINT_ERR_ARG;
+    *entries = nullptr;
+    *n_entries = 0;
+    if (kernel_ms) *kernel_ms = 0.f;
+    int count = 0;
+    if (!hip_ok(hipGetDeviceCount(&count), "hipGetDeviceCount") || device < 0 || device >= count) return DINT_ERR_NO_DEVICE;
+    // chunks: 256 integers of a list, aligned to the list's start
+    std::vector<uint64_t> h_start;
+    std::vector<uint32_t> h_n;
+    uint64_t ngrams = 0, total_ints = 0;
+    for (uint64_t l = 0; l != n_lists; ++l) {
+        if (list_starts[l + 1] < list_starts[l] || list_starts[l + 1] > n_ints) return DINT_ERR_ARG;
+        const uint64_t n = list_starts[l + 1] - list_starts[l];
+        total_ints += n;
+        for (uint64_t at = 0; at < n; at += kBlock) {
+            const uint32_t c = uint32_t(std::min<uint64_t>(kBlock, n - at));
+            if (multi && c != kBlock) break;
+            h_start.push_back(list_starts[l] + at);
+            h_n.push_back(c);
+            ngrams += c + c / 2 + c / 4 + c / 8 + c / 16;
+        }
+    }
+    if (h_start.empty()) return DINT_OK;
+    HIP_TRY(hipSetDevice(device));
+    // table: at least twice the n-grams (their distinct ones are far fewer), a power of two, 2^31 slots at most
+    uint64_t slots = 1024;
+    while (slots < 2 * ngrams && slots < (1ull << 31)) slots <<= 1;
+    const size_t n_chunks = h_start.size();
+    unsigned long long *d_keys = nullptr, *d_info = nullptr, *d_n_out = nullptr;
+    uint32_t *d_freq = nullptr, *d_chunk_n = nullptr, *d_overflow = nullptr;
+    uint64_t* d_chunk_start = nullptr;
+    dint_ngram* d_out = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&]() {
+        for (void* p : {static_cast<void*>(d_keys), static_cast<void*>(d_info), static_cast<void*>(d_n_out), static_cast<void*>(d_freq),
+                        static_cast<void*>(d_chunk_n), static_cast<void*>(d_overflow), static_cast<void*>(d_chunk_start),
+                        static_cast<void*>(d_out)})
+            if (p) (void)hipFree(p);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    };
+    auto fail = [&](int st) {
+        cleanup();
+        return st;
+    };
+    if (!hip_ok(hipMalloc(&d_keys, slots * 8), "hipMalloc(ngram keys)") || !hip_ok(hipMalloc(&d_info, slots * 8), "hipMalloc(ngram info)") ||
+        !hip_ok(hipMalloc(&d_freq, slots * 4), "hipMalloc(ngram freq)") || !hip_ok(hipMalloc(&d_n_out, 8), "hipMalloc") ||
+        !hip_ok(hipMalloc(&d_overflow, 4), "hipMalloc") || !hip_ok(hipMalloc(&d_chunk_start, n_chunks * 8), "hipMalloc(chunks)") ||
+        !hip_ok(hipMalloc(&d_chunk_n, n_chunks * 4), "hipMalloc(chunks)"))
+        return fail(DINT_ERR_HIP);
+    if (!hip_ok(hipMemset(d_keys, 0, slots * 8), "hipMemset") || !hip_ok(hipMemset(d_info, 0xFF, slots * 8), "hipMemset") ||
+        !hip_ok(hipMemset(d_freq, 0, slots * 4), "hipMemset") || !hip_ok(hipMemset(d_n_out, 0, 8), "hipMemset") ||
+        !hip_ok(hipMemset(d_overflow, 0, 4), "hipMemset") ||
+        !hip_ok(hipMemcpy(d_chunk_start, h_start.data(), n_chunks * 8, hipMemcpyHostToDevice), "hipMemcpy") ||
+        !hip_ok(hipMemcpy(d_chunk_n, h_n.data(), n_chunks * 4, hipMemcpyHostToDevice), "hipMemcpy") ||
+        !hip_ok(hipEventCreate(&e0), "hipEventCreate") || !hip_ok(hipEventCreate(&e1), "hipEventCreate"))
+        return fail(DINT_ERR_HIP);
+    ngram_table t{d_keys, d_info, d_freq, slots - 1, d_overflow};
+    (void)hipEventRecord(e0, nullptr);
+    hipLaunchKernelGGL(count_ngrams_kernel, dim3(uint32_t((n_chunks + kStatsWaves - 1) / kStatsWaves)), dim3(64 * kStatsWaves), 0, nullptr,
+                       d_gaps, d_chunk_start, d_chunk_n, uint64_t(n_chunks), uint32_t(multi != 0), t);
+    (void)hipEventRecord(e1, nullptr);
+    uint32_t overflow = 0;
+    if (!hip_ok(hipGetLastError(), "count_ngrams_kernel") || !hip_ok(hipDeviceSynchronize(), "count_ngrams_kernel") ||
+        !hip_ok(hipMemcpy(&overflow, d_overflow, 4, hipMemcpyDeviceToHost), "hipMemcpy"))
+        return fail(DINT_ERR_HIP);
+    if (overflow) return fail(DINT_ERR_NOMEM);  // more distinct n-grams than the table holds
+    if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, e0, e1);
+    // the occupied slots, compacted (first a count, then the entries)
+    const uint64_t cap = std::min<uint64_t>(ngrams, slots);
+    if (!hip_ok(hipMalloc(&d_out, cap * sizeof(dint_ngram)), "hipMalloc(ngram entries)")) return fail(DINT_ERR_HIP);
+    hipLaunchKernelGGL(collect_ngrams_kernel, dim3(uint32_t((slots + 255) / 256)), dim3(256), 0, nullptr, t, d_out, d_n_out, cap);
+    unsigned long long n_out = 0;
+    if (!hip_ok(hipGetLastError(), "collect_ngrams_kernel") || !hip_ok(hipMemcpy(&n_out, d_n_out, 8, hipMemcpyDeviceToHost), "hipMemcpy"))
+        return fail(DINT_ERR_HIP);
+    if (n_out > cap) return fail(DINT_ERR_HIP);
+    if (top_k != 0 && n_out > top_k) {
+        // per context: the largest count c with at least top_k kept n-grams of count >= c (1 if there are fewer)
+        uint32_t* d_at_least = nullptr;
+        unsigned long long* d_counts = nullptr;
+        dint_ngram* d_sel = nullptr;
+        auto fail2 = [&](int st) {
+            for (void* p : {static_cast<void*>(d_at_least), static_cast<void*>(d_counts), static_cast<void*>(d_sel)})
+                if (p) (void)hipFree(p);
+            return fail(st);
+        };
+        if (!hip_ok(hipMalloc(&d_at_least, 32), "hipMalloc") || !hip_ok(hipMalloc(&d_counts, 64), "hipMalloc")) return fail2(DINT_ERR_HIP);
+        uint32_t lo[8], hi[8], mid[8];
+        for (int c = 0; c != 8; ++c) lo[c] = 1, hi[c] = 0xFFFFFFFFu;  // invariant: count(>= lo) >= top_k or lo == 1
+        const uint32_t grid = uint32_t((n_out + 255) / 256);
+        for (int it = 0; it != 33; ++it) {
+            bool open = false;
+            for (int c = 0; c != 8; ++c) {
+                mid[c] = lo[c] + uint32_t((uint64_t(hi[c]) - lo[c] + 1) / 2);
+                open = open || lo[c] < hi[c];
+            }
+            if (!open) break;
+            unsigned long long h_counts[8];
+            if (!hip_ok(hipMemcpy(d_at_least, mid, 32, hipMemcpyHostToDevice), "hipMemcpy") || !hip_ok(hipMemset(d_counts, 0, 64), "hipMemset"))
+                return fail2(DINT_ERR_HIP);
+            hipLaunchKernelGGL(count_at_least_kernel, dim3(grid), dim3(256), 0, nullptr, d_out, uint64_t(n_out), double(total_ints), d_at_least,
+                               d_counts);
+            if (!hip_ok(hipMemcpy(h_counts, d_counts, 64, hipMemcpyDeviceToHost), "hipMemcpy")) return fail2(DINT_ERR_HIP);
+            for (int c = 0; c != 8; ++c) {
+                if (lo[c] >= hi[c]) continue;
+                if (h_counts[c] >= top_k) lo[c] = mid[c];
+                else hi[c] = mid[c] - 1;
+            }
+        }
+        if (!hip_ok(hipMemcpy(d_at_least, lo, 32, hipMemcpyHostToDevice), "hipMemcpy") || !hip_ok(hipMemset(d_n_out, 0, 8), "hipMemset") ||
+            !hip_ok(hipMalloc(&d_sel, n_out * sizeof(dint_ngram)), "hipMalloc(selected ngrams)"))
+            return fail2(DINT_ERR_HIP);
+        hipLaunchKernelGGL(keep_at_least_kernel, dim3(grid), dim3(256), 0, nullptr, d_out, uint64_t(n_out), d_at_least, d_sel, d_n_out);
+        unsigned long long n_sel = 0;
+        if (!hip_ok(hipGetLastError(), "keep_at_least_kernel") || !hip_ok(hipMemcpy(&n_sel, d_n_out, 8, hipMemcpyDeviceToHost), "hipMemcpy") ||
+            n_sel > n_out)
+            return fail2(DINT_ERR_HIP);
+        (void)hipFree(d_out);
+        d_out = d_sel;
+        d_sel = nullptr;
+        n_out = n_sel;
+        (void)hipFree(d_at_least);
+        (void)hipFree(d_counts);
+    }
+    dint_ngram* mem = static_cast<dint_ngram*>(std::malloc(std::max<size_t>(1, n_out) * sizeof(dint_ngram)));
+    if (!mem) return fail(DINT_ERR_NOMEM);
+    if (n_out && !hip_ok(hipMemcpy(mem, d_out, n_out * sizeof(dint_ngram), hipMemcpyDeviceToHost), "hipMemcpy")) {
+        std::free(mem);
+        return fail(DINT_ERR_HIP);
+    }
+    cleanup();
+    *entries = mem;
+    *n_entries = size_t(n_out);
     return DINT_OK;
 }
 

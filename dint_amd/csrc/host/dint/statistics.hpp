@@ -83,6 +83,15 @@ public:
         }
     }
 
+    // counts made elsewhere (the device): one distinct n-gram of context c, seen freq times
+    void set(uint32_t c, uint32_t const* p, uint32_t len, uint64_t freq) {
+        ngram_stat st;
+        st.freq = freq;
+        st.data.assign(p, p + len);
+        m_maps[c][hash_u32s(p, len)] = std::move(st);
+    }
+    void add_total(uint64_t n) { m_total += n; }
+
     uint64_t total_integers() const { return m_total; }
 
     // selected blocks of context c in dictionary order (most frequent first)

@@ -33,7 +33,7 @@ ABI_SYMBOLS = (
     "dint_stream_stats_get",
     "dint_decode_block_host", "dint_index_posting_lists", "dint_decode_posting_blocks",
     "dint_block_table_create", "dint_block_table_destroy", "dint_decode_block_table",
-    "dint_query_index_create", "dint_query_index_destroy", "dint_and_queries", "dint_and_queries_freqs",
+    "dint_query_index_create", "dint_query_index_destroy", "dint_and_queries", "dint_and_queries_freqs", "dint_count_ngrams",
 )
 
 #: dint_block_ref (include/dint_hip.h)
@@ -94,6 +94,7 @@ def _load():
     lib.dint_query_index_destroy.argtypes = [vp]
     lib.dint_and_queries.argtypes = [vp, vp, vp, sz, vp, vp]
     lib.dint_and_queries_freqs.argtypes = [vp, vp, vp, vp, sz, vp, vp, C.POINTER(u64), vp]
+    lib.dint_count_ngrams.argtypes = [C.c_int, C.c_int, vp, u64, vp, u64, C.c_uint32, C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_float)]
     lib.dint_debug_wave_scan.argtypes = [vp, vp]
     return lib
 
@@ -365,6 +366,48 @@ def and_queries_with_freqs(qi: "QueryIndex", freqs_dict: "Dictionary", queries):
     _check(_lib.dint_and_queries_freqs(qi._h, freqs_dict._h, terms.ctypes.data, offs.ctypes.data, len(queries),
                                        counts.ctypes.data, sums.ctypes.data, C.byref(nblocks), stream), "dint_and_queries_freqs")
     return counts, sums, nblocks.value
+
+
+NGRAM_DTYPE = np.dtype([("pos", "<u8"), ("freq", "<u4"), ("len", "u1"), ("ctx", "u1"), ("pad", "<u2")])  # dint_ngram
+
+
+def count_ngrams(gaps_dev, list_starts: np.ndarray, multi: bool, device: int = 0, top_k: int = 0):
+    """Block statistics on the device (dint_count_ngrams): gaps_dev — a torch CUDA tensor of u32 d-gaps, lists back
+    to back; list_starts — their n + 1 offsets; top_k > 0: only the entries that can make the first top_k of their
+    context. -> (entries NGRAM_DTYPE[], kernel ms)."""
+    starts = np.ascontiguousarray(list_starts, dtype=np.uint64)
+    out, n, ms = C.c_void_p(), C.c_size_t(), C.c_float()
+    _check(_lib.dint_count_ngrams(device, int(bool(multi)), gaps_dev.data_ptr(), gaps_dev.numel(), starts.ctypes.data,
+                                  len(starts) - 1, top_k, C.byref(out), C.byref(n), C.byref(ms)), "dint_count_ngrams")
+    try:
+        arr = np.empty(n.value, dtype=NGRAM_DTYPE)
+        if n.value:
+            C.memmove(arr.ctypes.data, out, arr.nbytes)
+    finally:
+        _lib.dint_free(out)
+    return arr, ms.value
+
+
+def build_dictionary(kind: int, coll, max_sample_ints: int = 0, device: int = 0):
+    """host.build_dictionary with the counting on the device: the sampled lists' n-grams counted by dint_count_ngrams,
+    selected and packed by the host library — byte-identical to the host-only path. -> (dictionary file, kernel ms)."""
+    import torch
+
+    from . import host
+
+    n_lists, ints = 0, 0
+    for n_lists in range(len(coll.lens) + 1):  # the same prefix sample as dinth_build_dictionary
+        if n_lists == len(coll.lens):
+            break
+        if max_sample_ints and n_lists and ints + int(coll.lens[n_lists]) > max_sample_ints:
+            break
+        ints += int(coll.lens[n_lists])
+    starts = np.zeros(n_lists + 1, dtype=np.uint64)
+    np.cumsum(coll.lens[:n_lists], out=starts[1:])
+    gaps = np.ascontiguousarray(coll.gaps[:ints], dtype=np.uint32)
+    gaps_dev = torch.from_numpy(gaps.view(np.int32)).to(torch.device("cuda", device))
+    entries, ms = count_ngrams(gaps_dev, starts, kind == host.MULTI_PACKED, device, top_k=65536)  # DSF-65536-16
+    return host.build_dictionary_from_ngrams(kind, gaps, ints, entries), ms
 
 
 def units_to_device(units: np.ndarray, device):

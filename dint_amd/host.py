@@ -65,6 +65,7 @@ def _load():
     lib.dinth_synth_lengths.argtypes = [C.POINTER(SynthParams), u64, C.POINTER(vp)]
     lib.dinth_synth_gaps.argtypes = [C.POINTER(SynthParams), vp, u64, u64, vp, i32]
     lib.dinth_build_dictionary.argtypes = [i32, vp, vp, u64, u64, i32, C.POINTER(vp)]
+    lib.dinth_build_dictionary_from_ngrams.argtypes = [i32, vp, u64, u64, vp, u64, C.POINTER(vp)]
     lib.dinth_encode_vroom.argtypes = [i32, i32, vp, C.c_size_t, vp, vp, u64, u32, i32,
                                        C.POINTER(vp), C.POINTER(vp)]
     lib.dinth_build_index.argtypes = [i32, vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp, u64, i32,
@@ -214,6 +215,20 @@ def build_dictionary(kind: int, coll: Collection, max_sample_ints: int = 0,
     gaps, lens = _u32(coll.gaps), _u32(coll.lens)
     _check(_lib.dinth_build_dictionary(kind, gaps.ctypes.data, lens.ctypes.data, len(lens),
                                        max_sample_ints, threads or default_threads(), C.byref(h)))
+    return _take_blob(h, np.uint8).tobytes()
+
+
+NGRAM_DTYPE = np.dtype([("pos", "<u8"), ("freq", "<u4"), ("len", "u1"), ("ctx", "u1"), ("pad", "<u2")])  # dinth_ngram
+
+
+def build_dictionary_from_ngrams(kind: int, gaps: np.ndarray, total_ints: int, entries: np.ndarray) -> bytes:
+    """The selection half of build_dictionary (filter, frequency sort, DSF, packing) over n-gram counts made
+    elsewhere — device.count_ngrams — as NGRAM_DTYPE entries pointing into `gaps`."""
+    h = C.c_void_p()
+    gaps = _u32(gaps)
+    entries = np.ascontiguousarray(entries, dtype=NGRAM_DTYPE)
+    _check(_lib.dinth_build_dictionary_from_ngrams(kind, gaps.ctypes.data, gaps.size, total_ints, entries.ctypes.data,
+                                                   entries.size, C.byref(h)))
     return _take_blob(h, np.uint8).tobytes()
 
 

@@ -225,6 +225,30 @@ int dint_and_queries_freqs(dint_query_index* qi, const dint_dict* freqs_dict, co
                            const uint64_t* query_offsets, size_t n_queries, uint64_t* counts, uint64_t* freq_sums,
                            uint64_t* freq_blocks_decoded, void* stream);
 
+/* ---- block statistics on the device (dictionary construction, counting half) ----------------------------
+ * Counts every aligned 16/8/4/2/1-gram of the given lists — multi != 0: of their whole 256-integer blocks, per block
+ * context — keyed by the MurmurHash64A of its integers, as the reference's collectors do.
+ * Replaces: adjusted::collect, include/dint/statistics_collectors.hpp:90-118 (context: :21-40), the per-thread
+ * maps of block_statistics.hpp:82-106. The selection (filter, sort, DSF, packing: dictionary_builders.hpp:40-76) stays
+ * on the host: dinth_build_dictionary_from_ngrams (include/dint_host.h) takes these entries.
+ * d_gaps: device, n_ints u32 (d-gaps minus one, lists back to back); list_starts: host, n_lists + 1 offsets into d_gaps.
+ * *entries (malloc'ed, release with dint_free): one per distinct (context, n-gram) — position of its first
+ * occurrence in d_gaps, length, context, number of occurrences — in no particular order (see top_k below). */
+typedef struct dint_ngram {
+    uint64_t pos;
+    uint32_t freq;
+    uint8_t len;
+    uint8_t ctx;
+    uint16_t pad;
+} dint_ngram;
+int dint_count_ngrams(int device, int multi, const uint32_t* d_gaps, uint64_t n_ints, const uint64_t* list_starts,
+                      uint64_t n_lists, uint32_t top_k, dint_ngram** entries, size_t* n_entries, float* kernel_ms);
+/* top_k = 0: every distinct n-gram. top_k > 0 (65536 for DSF-65536-16): only those that can be among the first top_k
+ * of their context in the selection's order (occurrences first) — per context the entries whose count reaches the
+ * top_k-th largest count among the n-grams the reference's filter keeps (dictionary_builders.hpp:15-38), ties
+ * included: the dictionary built from them is the same, the host sorts tens of thousands of entries instead of
+ * tens of millions. */
+
 /* Device time (ms) between the two events the library records around the decode kernel of the most
  * recent dint_decode_units on this dictionary (one event pair per in-flight launch: launches on
  * different streams do not disturb each other's); synchronises that launch. */

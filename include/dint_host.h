@@ -54,6 +54,20 @@ int dinth_synth_gaps(const dinth_synth_params* p, const uint32_t* lens, uint64_t
 int dinth_build_dictionary(int kind, const uint32_t* gaps, const uint32_t* lens, uint64_t n_lists,
                            uint64_t max_sample_ints, int threads, dinth_blob** dict_file);
 
+/* The selection half of the same construction, from n-gram counts made elsewhere (dint_count_ngrams on the device):
+ * filter, frequency sort, DSF, packing — dictionary_builders.hpp:15-76 — over the entries' n-grams, read from
+ * gaps[pos .. pos + len). total_ints: the integers of the sampled lists (the savings are relative to it,
+ * block_statistics.hpp:250-262). Byte-identical to dinth_build_dictionary over the same lists. */
+typedef struct dinth_ngram {  /* = dint_ngram of include/dint_hip.h */
+    uint64_t pos;
+    uint32_t freq;
+    uint8_t len;
+    uint8_t ctx;
+    uint16_t pad;
+} dinth_ngram;
+int dinth_build_dictionary_from_ngrams(int kind, const uint32_t* gaps, uint64_t n_ints, uint64_t total_ints,
+                                       const dinth_ngram* entries, uint64_t n_entries, dinth_blob** dict_file);
+
 /* Encode lists into one vroom stream (reference vroom_env/encode.cpp:133-191).
  * kind selects the dictionary type of dict_file; greedy != 0 selects
  * single_greedy_dint instead of single_opt_dint (ignored for multi).

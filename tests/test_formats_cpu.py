@@ -112,3 +112,49 @@ def test_kat_dictionaries_parse_with_the_host_loader():
         for i, e in entries.items():
             size, words = host.dict_entry(kind, DICT_FILES[kind], i)
             assert size == len(e) and words[:size].tolist() == e
+
+
+def _python_ngram_entries(coll, multi):
+    """adjusted::collect (statistics_collectors.hpp:90-118) with a dict: aligned 16/8/4/2/1-grams of every list
+    (multi: of every whole 256-block, under the block's context :21-40) -> NGRAM_DTYPE entries."""
+    import math
+
+    seen = {}
+    bounds = coll.list_bounds()
+    for i in range(len(coll.lens)):
+        lo, n = int(bounds[i]), int(coll.lens[i])
+        chunks = [(lo + at, min(256, n - at)) for at in range(0, n, 256)]
+        for start, c in chunks:
+            if multi and c != 256:
+                continue
+            block = coll.gaps[start:start + c]
+            ctx = 0
+            if multi:
+                mx = int(block.max())
+                ctx = 0 if mx <= 1 else math.ceil(math.log2(math.ceil(math.log2(mx + 1))))
+            for ln in (16, 8, 4, 2, 1):
+                for at in range(0, c - ln + 1, ln):
+                    key = (ctx, block[at:at + ln].tobytes())
+                    e = seen.get(key)
+                    if e is None:
+                        seen[key] = [start + at, 1, ln, ctx]
+                    else:
+                        e[1] += 1
+    out = np.zeros(len(seen), dtype=host.NGRAM_DTYPE)
+    for k, (pos, freq, ln, ctx) in enumerate(seen.values()):
+        out[k] = (pos, freq, ln, ctx, 0)
+    return out
+
+
+@pytest.mark.parametrize("kind", [host.RECTANGULAR, host.SINGLE_PACKED, host.MULTI_PACKED])
+def test_dictionary_from_ngram_counts_is_the_same_file(kind):
+    """The selection half of the construction (dinth_build_dictionary_from_ngrams) over counts made by a plain
+    Python counter == the whole construction (dinth_build_dictionary): what the device's counting kernel feeds."""
+    coll = host.synth_collection(60_000, universe=50_000, seed=21)
+    entries = _python_ngram_entries(coll, kind == host.MULTI_PACKED)
+    got = host.build_dictionary_from_ngrams(kind, coll.gaps, coll.num_postings, entries)
+    assert got == host.build_dictionary(kind, coll)
+    with pytest.raises(Exception):
+        bad = entries.copy()
+        bad["pos"][0] = coll.num_postings  # points past the integers
+        host.build_dictionary_from_ngrams(kind, coll.gaps, coll.num_postings, bad)

@@ -311,3 +311,29 @@ def test_seeded_sweep_of_small_collections(device, kind):
         same_list = units["list"][1:] == units["list"][:-1]
         assert np.array_equal(ends[:-1][same_list], units["in_off"][1:][same_list])
         assert int(ends[-1]) == enc.size
+
+
+@pytest.mark.parametrize("kind", ALL_KINDS)
+@pytest.mark.parametrize("corpus_name", ["small_corpus", "sparse_corpus"])
+def test_block_statistics_on_the_device(device, request, kind, corpus_name):
+    """the n-gram counting of the dictionary construction on the device (dint_count_ngrams,
+    statistics_collectors.hpp:90-118) + the host's selection == the host-only construction, byte for byte."""
+    coll = request.getfixturevalue(corpus_name).coll
+    got, ms = device.build_dictionary(kind, coll)
+    assert got == host.build_dictionary(kind, coll)
+    sampled, _ = device.build_dictionary(kind, coll, max_sample_ints=coll.num_postings // 3)
+    assert sampled == host.build_dictionary(kind, coll, max_sample_ints=coll.num_postings // 3)
+    assert ms > 0
+
+
+def test_ngram_counts_of_a_tiny_collection(device):
+    import torch
+
+    gaps = np.array([5, 5, 5, 5, 1, 2, 1, 2, 9], dtype=np.uint32)           # two lists: 8 + 1 integers
+    starts = np.array([0, 8, 9], dtype=np.uint64)
+    entries, _ = device.count_ngrams(torch.from_numpy(gaps.view(np.int32)).cuda(), starts, multi=False)
+    got = {(tuple(gaps[int(e["pos"]):int(e["pos"]) + int(e["len"])])): int(e["freq"]) for e in entries}
+    want = {(5, 5, 5, 5, 1, 2, 1, 2): 1, (5, 5, 5, 5): 1, (1, 2, 1, 2): 1, (5, 5): 2, (1, 2): 2, (5,): 4, (1,): 2, (2,): 2, (9,): 1}
+    assert got == want
+    none, _ = device.count_ngrams(torch.from_numpy(gaps.view(np.int32)).cuda(), starts, multi=True)   # no whole 256-block
+    assert none.size == 0
