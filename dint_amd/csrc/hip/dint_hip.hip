@@ -502,6 +502,12 @@ int dint_dict_create(int kind, const void* file_bytes, size_t len, int device, d
         !hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_multi_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsWords * 4)),
                 "hipFuncSetAttribute") ||
+        !hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_single_index_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsWords * 4)),
+                "hipFuncSetAttribute") ||
+        !hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_multi_index_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsWords * 4)),
+                "hipFuncSetAttribute") ||
         !hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(&interpolative_tails_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(kTailLdsBytes)),
                 "hipFuncSetAttribute")) {
@@ -671,6 +677,15 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
     const uint32_t grid = uint32_t(std::min<uint64_t>(blocks_needed, std::max<uint32_t>(1, dd->compute_units) * kBlocksPerCU));
     const size_t lds_bytes = (size_t(dd->view.hot_words) + kClassTableWords + kWavesPerBlock * kScratchWords) * 4;
     dint_dict* mut = const_cast<dint_dict*>(dd);
+    // (an in-index launch — blocks, docIDs, freqs + 1 — runs the kernels compiled for that; the vroom kernels carry none of it)
+    const bool index_launch = only_full != 0 || plus_one != 0 || d_unit_base != nullptr || d_gaps_left != nullptr;
+    auto launch_kernel = [&]() {
+        const bool multi = dd->kind == DINT_DICT_MULTI_PACKED;
+        if (index_launch)
+            hipLaunchKernelGGL(multi ? decode_multi_index_kernel : decode_single_index_kernel, dim3(grid), dim3(kBlockThreads), lds_bytes, s, a);
+        else
+            hipLaunchKernelGGL(multi ? decode_multi_kernel : decode_single_kernel, dim3(grid), dim3(kBlockThreads), lds_bytes, s, a);
+    };
     if (d_zeroed_queue && (n_units < schedule_from || dd->no_bundles)) {
         // the lean launch: the caller brings the (zeroed) queue counters, nothing is timed, nothing scheduled — one
         // API call (a query's pages: the host-side cost of a launch sequence is what a single query waits for)
@@ -684,10 +699,7 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
         a.urec = nullptr;
         a.cbase = nullptr;
         a.spans = d_spans;
-        if (dd->kind == DINT_DICT_MULTI_PACKED)
-            hipLaunchKernelGGL(decode_multi_kernel, dim3(grid), dim3(kBlockThreads), lds_bytes, s, a);
-        else
-            hipLaunchKernelGGL(decode_single_kernel, dim3(grid), dim3(kBlockThreads), lds_bytes, s, a);
+        launch_kernel();
         HIP_TRY(hipGetLastError());
         return DINT_OK;
     }
@@ -749,10 +761,7 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
         a.cbase = d_cbase;
     }
     HIP_TRY(hipEventRecord(mut->slot_start[slot], s));
-    if (dd->kind == DINT_DICT_MULTI_PACKED)
-        hipLaunchKernelGGL(decode_multi_kernel, dim3(grid), dim3(kBlockThreads), lds_bytes, s, a);
-    else
-        hipLaunchKernelGGL(decode_single_kernel, dim3(grid), dim3(kBlockThreads), lds_bytes, s, a);
+    launch_kernel();
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(mut->slot_stop[slot], s));
     HIP_TRY(hipEventRecord(mut->slot_done[slot], s));

@@ -522,6 +522,7 @@ __device__ __forceinline__ void expand_batch(uint32_t bt, uint32_t out_int, cons
     // lane constants: this lane owns outputs 4*lane .. 4*lane+3 of every group
     const uint32_t sh = (4 * lane) & 31u;                 // bit position of its nibble in its flag word
     const uint32_t pair_byte = (lane >> 3) * 8;           // its {flag, base} pair inside a group's 8 pairs
+    out_int = uniform(out_int);  // (the stores' scalar offset: an SGPR, not a loop over the values a VGPR might hold)
 #pragma unroll
     for (uint32_t rd = 0; rd != ROUNDS; ++rd) {
         if (rd * GROUPS * 4 * kWave < bt) {  // wave-uniform
@@ -1618,9 +1619,19 @@ __device__ __forceinline__ decode_args own_scalars(const decode_args& k) {
     return a;
 }
 
-template <bool MULTI>
+// INDEX: an in-index launch (256-posting blocks: docIDs formed in the expansion, freqs + 1, full blocks only). The
+// vroom kernels are compiled without any of that: the per-group branches of the expansion, and the masks the compiler
+// puts on every gathered integer because the docID arithmetic might read it, are gone from their loops.
+template <bool MULTI, bool INDEX>
 __device__ __forceinline__ void decode_kernel_body(const decode_args& kernarg) {
-    const decode_args a = own_scalars(kernarg);
+    decode_args a_ = own_scalars(kernarg);
+    if (!INDEX) {
+        a_.unit_base = nullptr;
+        a_.gaps_left = nullptr;
+        a_.plus_one = 0;
+        a_.only_full = 0;
+    }
+    const decode_args a = a_;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     // the dictionary's hot part, 16 bytes a thread and step (hot_words is a multiple of 4): five steps instead of
     // eighteen dependent round trips — nothing for a launch that decodes 10^9 integers, a third of one that decodes a
@@ -1717,10 +1728,16 @@ __device__ __forceinline__ void decode_kernel_body(const decode_args& kernarg) {
 #define DINT_MIN_WAVES 1
 #endif
 __global__ __launch_bounds__(kBlockThreads, DINT_MIN_WAVES) void decode_single_kernel(decode_args a) {
-    decode_kernel_body<false>(a);
+    decode_kernel_body<false, false>(a);
 }
 __global__ __launch_bounds__(kBlockThreads, DINT_MIN_WAVES) void decode_multi_kernel(decode_args a) {
-    decode_kernel_body<true>(a);
+    decode_kernel_body<true, false>(a);
+}
+__global__ __launch_bounds__(kBlockThreads, DINT_MIN_WAVES) void decode_single_index_kernel(decode_args a) {
+    decode_kernel_body<false, true>(a);
+}
+__global__ __launch_bounds__(kBlockThreads, DINT_MIN_WAVES) void decode_multi_index_kernel(decode_args a) {
+    decode_kernel_body<true, true>(a);
 }
 
 // ---- in-index path: helper kernels -------------------------------------------------------------
