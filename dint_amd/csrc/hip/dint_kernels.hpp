@@ -1179,7 +1179,6 @@ __device__ __forceinline__ void bundle_map(const wave_ctx& c, const u32x4& rc, u
     const uint32_t pk0 = my_n | (my_lanes << 16);
     const uint32_t inc0 = wave_inclusive_sum(pk0);
     const uint32_t my_lane0 = (inc0 - pk0) >> 16;      // first lane of this lane's unit
-    const uint32_t my_out0 = (inc0 - pk0) & 0xFFFFu;   // its first output, relative to the bundle
     bh.used = readlane(inc0, 63) >> 16;
     bh.total = readlane(inc0, 63) & 0xFFFFu;
     bh.in0 = in0;
@@ -1187,15 +1186,23 @@ __device__ __forceinline__ void bundle_map(const wave_ctx& c, const u32x4& rc, u
     bh.u0 = chunk * kChunkUnits + p;
     bh.cnt = cnt;
     // lane -> unit: a bit per unit at its first lane (distinct bits: their sum is their OR), units before a lane = bits below it
-    const uint32_t hlo = has && my_lane0 < 32 ? 1u << my_lane0 : 0u, hhi = has && my_lane0 >= 32 ? 1u << (my_lane0 - 32) : 0u;
-    const uint32_t mlo = readlane(wave_inclusive_sum(hlo), 63), mhi = readlane(wave_inclusive_sum(hhi), 63);
+    uint32_t mlo, mhi;
+    if (cnt <= 12) {  // (wave-uniform; the usual bundle: a handful of blocks) the bits gathered on the scalar side
+        uint64_t heads = 0;
+        for (uint32_t m = 0; m != cnt; ++m) heads |= 1ull << (readlane(inc0 - pk0, m) >> 16);
+        mlo = uint32_t(heads), mhi = uint32_t(heads >> 32);
+    } else {
+        const uint32_t hlo = has && my_lane0 < 32 ? 1u << my_lane0 : 0u, hhi = has && my_lane0 >= 32 ? 1u << (my_lane0 - 32) : 0u;
+        mlo = readlane(wave_inclusive_sum(hlo), 63), mhi = readlane(wave_inclusive_sum(hhi), 63);
+    }
     const uint32_t own = lane < 32 ? (mlo >> lane) & 1u : (mhi >> (lane - 32)) & 1u;
     const uint32_t seg = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u)) + own - 1u;  // lane 0 is always a head
     const int sl_ = int(seg);
     const uint32_t seg_rel = uint32_t(__shfl(my_rel, sl_));
     const uint32_t seg_pk = uint32_t(__shfl(my_pk, sl_));
-    const uint32_t seg_lane0 = uint32_t(__shfl(my_lane0, sl_));
-    const uint32_t seg_out0 = uint32_t(__shfl(my_out0, sl_));
+    // (first lane and first output of the unit: one value, one shuffle)
+    const uint32_t seg_at = uint32_t(__shfl(inc0 - pk0, sl_));
+    const uint32_t seg_lane0 = seg_at >> 16, seg_out0 = seg_at & 0xFFFFu;
     const uint32_t sel = MULTI ? (seg_pk >> 14) & 15u : 0u;
     const uint32_t narrow = sel >= 6 ? 1u : 0u;
     const uint32_t dict = narrow ? sel - 6 : sel;
