@@ -119,8 +119,9 @@ def cpu_baseline(kind, dict_file, enc, list_byte_starts, seconds):
            "sample": f"{passes} pass(es) over the same encoded stream, {lists} list decodes ({ints} postings), per-list "
                      f"timing summed as in vroom_env/decode.cpp:139-150, {sec:.1f}s of decode time"}
     cores = len(os.sched_getaffinity(0))
-    bounds = [int(list_byte_starts[np.searchsorted(list_byte_starts, enc.size * k // cores)]) if k else 0 for k in range(cores)]
-    bounds.append(enc.size)
+    # thread k takes the lists that begin in [k, k + 1) / cores of the stream's bytes (a thread may get none)
+    cut = np.searchsorted(list_byte_starts, [enc.size * k // cores for k in range(1, cores)])
+    bounds = [0] + [int(list_byte_starts[i]) if i < len(list_byte_starts) else enc.size for i in cut] + [enc.size]
     res = [None] * cores
 
     def work(k, t0):

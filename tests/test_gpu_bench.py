@@ -1,0 +1,37 @@
+"""bench.py end to end on one GPU at a small size: the driver's command form, the line's contract."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("extra", [[], ["--type", "multi_packed_dint", "--unit-ints", "256"], ["--type", "single_rect_dint", "--workload", "clueweb"]],
+                         ids=["single_packed", "multi_block_units", "single_rect_clueweb"])
+def test_bench_line_contract(extra):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--postings", "3e6",
+           "--replicate", "2", "--dict-sample", "1e6", "--cpu-seconds", "0.5"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["bit_exact"] is True and d["value"] > 0 and d["higher_is_better"] is True and d["dtype"] == "u32"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["config"]["ints_per_gpu_per_step"] >= 6_000_000 * 0.9
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["kernel_launches_timed"] == 3
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["kernel_ms"] > 0
+    lo, med, hi = rf["kernel_ms_min_median_max"]
+    assert lo <= med <= hi
+    assert rf["traffic"] is None  # not measured in this process: only a same-command PMC file may fill it
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["all_cores"]["cores"] >= 1 and cb["cpu_model"]
