@@ -154,7 +154,7 @@ struct decode_args {
     // sum_{j<=i} (gap_j + 1) - 1 (dict_posting_list.hpp:111-124, :304), one wave scan per block in the expansion.
     const uint32_t* unit_base;  // nullable; per unit: the block's docID base
     uint8_t* gaps_left;         // with unit_base; per unit, zero at launch: set where a block had to be left as gaps (it
-                                // held a slow codeword) for finalize_postings_kernel
+                                // held a slow codeword) for the flagged fix-up
 };
 
 struct __attribute__((packed, aligned(1))) u32x4_a1 {
@@ -944,7 +944,7 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const w
         }
         // (in-index docs part: the segment is one 256-posting block = one group of one tile; with a slow codeword in
         // it, or spread over two tiles — more than 256 slots: a block full of exceptions — it stays gaps and
-        // finalize_postings_kernel is told)
+        // the flagged fix-up (finalize_flagged_kernel, interpolative_tails_kernel) is told)
         const bool as_docids = block_base != nullptr && !tile_slow && produced == 0 && last_tile && t.total <= ROUNDS * GROUPS * 256;
         if (block_base != nullptr && !as_docids && lane == 0) *gaps_left = 1;
         expand_tile<ROUNDS, GROUPS>(t, plain, tile_wide, a.plus_one, as_docids ? block_base : nullptr, produced, c.lds, c.scratch, rs_out, lane, pf, [&]() {
@@ -1425,7 +1425,7 @@ __device__ __forceinline__ void bundle_process(const decode_args& a, const wave_
         }
     }
     // (in-index docs parts: every unit of the bundle is a 256-posting block, so group g of the expansion is unit
-    // u0 + g; a slow codeword anywhere leaves the whole bundle as gaps for finalize_postings_kernel)
+    // u0 + g; a slow codeword anywhere leaves the whole bundle as gaps for the flagged fix-up)
     const bool as_docids = a.unit_base != nullptr && !tile_slow && total <= kMaxCap;
     if (a.unit_base != nullptr && !as_docids && has) a.gaps_left[u0 + lane] = 1;
     // (a bundle is one batch by construction: the schedule packs at most kMaxCap integers into one)
@@ -1975,37 +1975,8 @@ __global__ __launch_bounds__(64) void interpolative_tails_kernel(const uint8_t* 
     }
 }
 
-// gaps -> docIDs (docid_i = base + sum_{j<=i} gap_j + i, dict_posting_list.hpp:111-124) and
-// freq - 1 -> freq; one wave per block, 4 consecutive postings per lane.
-__global__ void finalize_postings_kernel(const dint_block_ref* blocks, uint64_t n_blocks, uint32_t* docids,
-                                         uint32_t* freqs, uint64_t out_capacity, const uint8_t* todo = nullptr) {
-    const uint32_t lane = lane_id();
-    const uint64_t b = (uint64_t(blockIdx.x) * blockDim.x + threadIdx.x) / kWave;
-    if (b >= n_blocks) return;
-    if (todo && !todo[b]) return;  // (the decode kernels left docIDs already)
-    const uint32_t n = blocks[b].n;
-    const uint64_t at = blocks[b].out_off;
-    if (n == 0 || n > 256 || at + n > out_capacity) return;
-    uint32_t g[4], local = 0;
-#pragma unroll
-    for (uint32_t k = 0; k != 4; ++k) {
-        const uint32_t i = 4 * lane + k;
-        g[k] = i < n ? docids[at + i] + 1 : 0;
-        local += g[k];
-    }
-    uint32_t run = blocks[b].base + wave_inclusive_sum(local) - local - 1;
-#pragma unroll
-    for (uint32_t k = 0; k != 4; ++k) {
-        const uint32_t i = 4 * lane + k;
-        run += g[k];
-        if (i < n) {
-            docids[at + i] = run;
-            if (freqs) freqs[at + i] += 1;
-        }
-    }
-}
-
-// The same for the few blocks the decode kernels had to leave as gaps (flags in `todo`): one wave per 64 blocks,
+// gaps -> docIDs (docid_i = base + sum_{j<=i} gap_j + i, dict_posting_list.hpp:111-124) for the few blocks the decode
+// kernels had to leave as gaps (flags in `todo`): one wave per 64 blocks,
 // every lane looks at one flag; the rare block that has it set is summed by the whole wave.
 __global__ __launch_bounds__(64) void finalize_flagged_kernel(const dint_block_ref* blocks, uint64_t n_blocks, uint32_t* docids,
                                                               uint64_t out_capacity, const uint8_t* todo) {
