@@ -1169,6 +1169,11 @@ static int and_queries_impl(dint_query_index* qi, const dint_dict* freqs_dict, c
         counts[q] = 0;
         if (freq_sums) freq_sums[q] = 0;
         if (t.empty()) continue;
+        if (t.size() == 1 && !freqs_dict) {  // one list: every posting is a result (and_query<false> would walk it and count)
+            counts[q] = qi->list_len[t[0]];
+            t.clear();
+            continue;
+        }
         rounds = std::max(rounds, t.size() - 1);
         for (uint32_t b = qi->list_first[t[0]]; b != qi->list_first[t[0] + 1]; ++b) {
             h_page_block.push_back(b);
@@ -1318,7 +1323,8 @@ static int and_queries_impl(dint_query_index* qi, const dint_dict* freqs_dict, c
     HIP_TRY(hipMemcpyAsync(h_counts, d_counts, n_queries * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     qi->claims_dirty = false;
-    for (size_t q = 0; q != n_queries; ++q) counts[q] = h_counts[q];
+    for (size_t q = 0; q != n_queries; ++q)
+        if (!plan[q].empty()) counts[q] = h_counts[q];
     if (freqs_dict)
         for (size_t q = 0; q != n_queries; ++q) freq_sums[q] = h_sums[q];
     return DINT_OK;

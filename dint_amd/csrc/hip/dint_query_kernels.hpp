@@ -185,10 +185,11 @@ __global__ void and_release_kernel(const uint32_t* touched, uint32_t n_touched, 
 // results += 1 per surviving candidate (queries.hpp:72-76); a page belongs to one query
 __global__ void and_count_kernel(const uint32_t* cand, uint64_t n_slots, const uint32_t* page_query,
                                  unsigned long long* counts) {
+    // (a workgroup = the 256 slots of one page = one query: one atomic per page that has a survivor)
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     const bool alive = i < n_slots && cand[i] != kDeadCandidate;
-    const uint64_t votes = __ballot(alive);
-    if ((threadIdx.x & 63u) == 0 && votes) atomicAdd(&counts[page_query[i / kPageSlots]], (unsigned long long)__popcll(votes));
+    const int n = __syncthreads_count(alive);
+    if (threadIdx.x == 0 && n) atomicAdd(&counts[page_query[i / kPageSlots]], (unsigned long long)n);
 }
 
 }  // namespace dint_dev
