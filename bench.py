@@ -257,6 +257,8 @@ def main():
     elapsed = time.perf_counter() - t_start
     # per-launch kernel time of the timed launches themselves: the event pairs the library recorded around them
     kernel_ms = np.asarray(d.recent_kernel_ms(min(args.steps, 64)), dtype=np.float64)
+    # the clock the last timed launch actually ran at (its first wave's cycle count over its duration)
+    shader_mhz = round(float(d.last_kernel_clock_mhz()), 1) if hasattr(d, "last_kernel_clock_mhz") else None
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -360,6 +362,7 @@ def main():
                 "kernel_ms_min_median_max": [round(float(kernel_ms.min()), 4), round(float(np.median(kernel_ms)), 4),
                                              round(float(kernel_ms.max()), 4)],
                 "kernel_launches_timed": int(kernel_ms.size),
+                "shader_mhz": shader_mhz,
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
             "cpu_baseline": cpu,

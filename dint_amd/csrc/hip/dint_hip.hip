@@ -1540,6 +1540,25 @@ int dint_decode_block_host(const dint_dict* dd, const uint8_t* in, size_t in_byt
     return st;
 }
 
+int dint_last_kernel_clock_mhz(const dint_dict* dd, float* mhz) {
+    if (!dd || !mhz) return DINT_ERR_ARG;
+    int slot;
+    {
+        std::lock_guard<std::mutex> lock(const_cast<dint_dict*>(dd)->launch_mutex);
+        slot = dd->last_slot;
+    }
+    if (slot < 0) return DINT_ERR_ARG;
+    float ms = 0.f;
+    uint64_t cycles = 0;
+    HIP_TRY(hipSetDevice(dd->device));
+    HIP_TRY(hipEventSynchronize(dd->slot_stop[slot]));
+    HIP_TRY(hipEventElapsedTime(&ms, dd->slot_start[slot], dd->slot_stop[slot]));
+    HIP_TRY(hipMemcpy(&cycles, dd->d_queues + size_t(slot) * (kQueueShards + 1) * kQueueStride + kQueueShards * kQueueStride + kClockWordAt, 8,
+                      hipMemcpyDeviceToHost));
+    *mhz = ms > 0.f ? float(double(cycles) / (double(ms) * 1e3)) : 0.f;
+    return DINT_OK;
+}
+
 int dint_recent_kernel_ms(const dint_dict* dd, float* ms, size_t max_n, size_t* n_out) {
     if (!dd || (!ms && max_n) || !n_out) return DINT_ERR_ARG;
     int last;

@@ -100,6 +100,7 @@ constexpr uint32_t kMetaOffMask = (1u << 20) - 1;     // hot: byte offset of the
                                                       // bits 20-21: staging cells a cold codeword takes (1: up to 6 integers, 2: up to 14, 3)
 constexpr uint32_t kQueueShards = 8;                  // dynamic unit queue: one counter per shard
 constexpr uint32_t kQueueStride = 32;                 // words between counters (own 128-byte line each)
+constexpr uint32_t kClockWordAt = 16;                 // in the chunk counter's line: shader-clock cycles of the launch's first wave (u64)
 constexpr uint32_t kMaxUnitInts = 1u << 28;           // byte offsets inside a unit's output stay 32-bit
 
 // One dictionary of the (possibly multi-) dictionary file.
@@ -1639,6 +1640,9 @@ __device__ __forceinline__ void decode_kernel_body(const decode_args& kernarg) {
         a_.only_full = 0;
     }
     const decode_args a = a_;
+    // (the first wave of the launch notes the shader clock at both ends: cycles / kernel time = the clock the kernel
+    // actually ran at — boxes of one pool differ by a tenth in speed for the same binary, and this says why)
+    const uint64_t clock0 = __builtin_amdgcn_s_memtime();
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     // the dictionary's hot part, 16 bytes a thread and step (hot_words is a multiple of 4): five steps instead of
     // eighteen dependent round trips — nothing for a launch that decodes 10^9 integers, a third of one that decodes a
@@ -1729,6 +1733,8 @@ __device__ __forceinline__ void decode_kernel_body(const decode_args& kernarg) {
 #ifdef DINT_PROFILE
     prof_end(pf);
 #endif
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        *reinterpret_cast<uint64_t*>(a.chunk_queue + kClockWordAt) = __builtin_amdgcn_s_memtime() - clock0;
 }
 
 #ifndef DINT_MIN_WAVES

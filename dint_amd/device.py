@@ -33,7 +33,7 @@ ABI_SYMBOLS = (
     "dint_stream_stats_get",
     "dint_decode_block_host", "dint_index_posting_lists", "dint_decode_posting_blocks",
     "dint_block_table_create", "dint_block_table_destroy", "dint_decode_block_table",
-    "dint_query_index_create", "dint_query_index_destroy", "dint_and_queries", "dint_and_queries_freqs", "dint_count_ngrams",
+    "dint_query_index_create", "dint_query_index_destroy", "dint_and_queries", "dint_and_queries_freqs", "dint_count_ngrams", "dint_last_kernel_clock_mhz",
 )
 
 #: dint_block_ref (include/dint_hip.h)
@@ -80,6 +80,7 @@ def _load():
     lib.dint_decode_units.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, vp]
     lib.dint_decode_list_host.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
     lib.dint_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.dint_last_kernel_clock_mhz.argtypes = [vp, C.POINTER(C.c_float)]
     lib.dint_recent_kernel_ms.argtypes = [vp, vp, sz, C.POINTER(sz)]
     lib.dint_stream_stats_get.argtypes = [vp, vp, sz, C.POINTER(StreamStats)]
     lib.dint_decode_block_host.argtypes = [vp, vp, sz, vp, u32, sz, C.POINTER(sz)]
@@ -189,6 +190,12 @@ class Dictionary:
         ms = C.c_float()
         _check(_lib.dint_last_kernel_ms(self._h, C.byref(ms)), "dint_last_kernel_ms")
         return ms.value
+
+    def last_kernel_clock_mhz(self) -> float:
+        """The shader clock the most recent decode kernel ran at (its first wave's cycle count / its duration)."""
+        mhz = C.c_float()
+        _check(_lib.dint_last_kernel_clock_mhz(self._h, C.byref(mhz)), "dint_last_kernel_clock_mhz")
+        return mhz.value
 
     def recent_kernel_ms(self, max_n: int = 64) -> np.ndarray:
         """Kernel times (ms) of the most recent launches, oldest first (from their own event pairs)."""

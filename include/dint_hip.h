@@ -258,6 +258,9 @@ int dint_last_kernel_ms(const dint_dict* dict, float* ms);
  * that many event pairs); *n = how many were written. Synchronises them. What bench.py reports its
  * per-launch kernel time from: the events of the timed launches themselves. */
 int dint_recent_kernel_ms(const dint_dict* dict, float* ms, size_t max_n, size_t* n);
+/* The shader clock the most recent decode kernel ran at, MHz: cycles counted by the launch's first wavefront
+ * (s_memtime at both ends) over the kernel's duration from its event pair. (Boxes of a pool differ.) */
+int dint_last_kernel_clock_mhz(const dint_dict* dict, float* mhz);
 
 /* What a vroom stream is made of, by the dictionary's device layout (host pre-pass, like
  * dint_index_stream): codewords, exceptions, how many codewords find their integers on chip. */
