@@ -1069,7 +1069,7 @@ __global__ __launch_bounds__(256) void bundle_schedule_kernel(const dint_unit* u
         for (uint32_t j = tid; j != tid + 64; ++j) {
             const uint32_t l = lanes[j] & 255u, m = lanes[j] >> 8;
             // (a bundle decodes to at most kMaxCap integers: one expansion batch; in-index: 8 blocks, groups = blocks)
-            const bool cont = l != 0 && prev_l != 0 && pre[j] != 0 && in_use + l <= kWave - 1 && ints + m <= kMaxCap;
+            const bool cont = l != 0 && prev_l != 0 && pre[j] != 0 && in_use + l <= kWave && ints + m <= kMaxCap;
             start[j] = cont ? 0 : 1;
             in_use = cont ? in_use + l : l;
             ints = cont ? ints + m : m;
@@ -1161,7 +1161,7 @@ struct bundle_head {     // wave-uniform
     uint64_t in0;        // the chunk's stream base
     uint64_t out0;       // the bundle's first output (absolute, integers)
     uint32_t u0, cnt;    // first unit, units
-    uint32_t used, total;  // lanes in use (< 64), integers
+    uint32_t used, total;  // lanes in use (<= 64), integers
 };
 
 // Lanes and outputs of each unit by one packed scan over the units' records (one per lane, from the chunk's
