@@ -59,6 +59,9 @@ namespace dint_dev {
 #ifndef DINT_BLOCK_THREADS
 #define DINT_BLOCK_THREADS 1024
 #endif
+#ifndef DINT_FF_OPEN
+#define DINT_FF_OPEN 4  // bundles the multi-dictionary schedule keeps open while it packs a chunk (first fit)
+#endif
 #ifndef DINT_GATHER_AUX
 #define DINT_GATHER_AUX 0  // cache policy of the metadata / row gathers (L2-resident tables, no reuse in L1)
 #endif
@@ -509,6 +512,13 @@ __device__ __forceinline__ void tables_general(const tile_slots& t, uint8_t* fw,
     }
 }
 
+// A first-fit bundle (the multi-dictionary kernel, see bundle_map_first_fit) is any set of up to 8 units of one chunk;
+// member m's outputs are positions [256 m, 256 m + n) of the tile — one expansion group — and are stored where the unit says.
+struct group_out {
+    uint32_t* base;            // the chunk's output base (wave-uniform)
+    uint32_t unit_n, rel_out;  // lane g: member g's unit (its lane in the chunk) | its integers << 8; its outputs' offset from the base
+};
+
 // ---- expansion of a batch of `bt` outputs, GROUPS * 256 per round: each lane takes 4 consecutive outputs of
 // every 256-output group — flag word + rank base -> 4 ranks -> 4 deltas -> 4 LDS gathers (u16) -> one 16-byte
 // non-temporal store; every source is an LDS byte address by now. Stores are whole 16-byte quads: the
@@ -519,7 +529,7 @@ __device__ __forceinline__ void tables_general(const tile_slots& t, uint8_t* fw,
 template <uint32_t ROUNDS, uint32_t GROUPS, bool WIDE>
 __device__ __forceinline__ void expand_batch(uint32_t bt, uint32_t out_int, const uint8_t* lds_bytes, const uint8_t* fw,
                                              const uint8_t* delta, const __amdgpu_buffer_rsrc_t rs_out, uint32_t lane,
-                                             uint32_t plus_one, const uint32_t* group_base) {
+                                             uint32_t plus_one, const uint32_t* group_base, const group_out* go = nullptr) {
     // lane constants: this lane owns outputs 4*lane .. 4*lane+3 of every group
     const uint32_t sh = (4 * lane) & 31u;                 // bit position of its nibble in its flag word
     const uint32_t pair_byte = (lane >> 3) * 8;           // its {flag, base} pair inside a group's 8 pairs
@@ -569,12 +579,18 @@ __device__ __forceinline__ void expand_batch(uint32_t bt, uint32_t out_int, cons
                 const uint32_t p0 = (rd * GROUPS + g) * 4 * kWave + 4 * lane;
                 if ((rd * GROUPS + g) * 4 * kWave < bt) {  // wave-uniform
                     if (group_base) {  // wave-uniform: the group is one 256-posting block — gaps to docIDs
-                        const uint32_t base = uniform(group_base[rd * GROUPS + g]);
+                        const uint32_t base = uniform(group_base[go ? readlane(go->unit_n, rd * GROUPS + g) & 255u : rd * GROUPS + g]);
                         const uint32_t v0 = x[g][0] + 1u, v1 = v0 + x[g][1] + 1u, v2 = v1 + x[g][2] + 1u, v3 = v2 + x[g][3] + 1u;
                         const uint32_t before = wave_inclusive_sum(v3) - v3 + base - 1u;
                         x[g][0] = before + v0, x[g][1] = before + v1, x[g][2] = before + v2, x[g][3] = before + v3;
                     }
-                    if (p0 < bt) {
+                    if (go) {  // wave-uniform: the group's outputs have a place of their own, and end where its unit ends
+                        u32x4 xv = {x[g][0], x[g][1], x[g][2], x[g][3]};
+                        if (plus_one) xv += 1u;
+                        uint32_t* const at = go->base + readlane(go->rel_out, rd * GROUPS + g);
+                        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(at, 0, int(4 * (readlane(go->unit_n, rd * GROUPS + g) >> 8)), 0x00020000);
+                        __builtin_amdgcn_raw_buffer_store_b128(xv, rs, 16 * lane, 0, DINT_STORE_AUX);
+                    } else if (p0 < bt) {
                         u32x4 xv = {x[g][0], x[g][1], x[g][2], x[g][3]};
                         if (plus_one) xv += 1u;  // wave-uniform branch: nothing on the plain decode path
                         __builtin_amdgcn_raw_buffer_store_b128(xv, rs_out, 16 * g * kWave + 16 * lane, obyte, DINT_STORE_AUX);
@@ -596,7 +612,7 @@ template <uint32_t ROUNDS, uint32_t GROUPS, bool ONE_BATCH = false, class Before
 __device__ __forceinline__ void expand_tile(const tile_slots& t, bool plain, bool wide, uint32_t plus_one,
                                             const uint32_t* group_base, uint32_t out_int0,
                                             const uint32_t* lds, uint32_t* scratch, const __amdgpu_buffer_rsrc_t rs_out,
-                                            uint32_t lane, prof_t& pf, BeforeGathers&& before_gathers) {
+                                            uint32_t lane, prof_t& pf, BeforeGathers&& before_gathers, const group_out* go = nullptr) {
     (void)pf;
     constexpr uint32_t kCap = ROUNDS * GROUPS * 256;
     static_assert(kCap <= kMaxCap, "the flag bitmap holds 2048 positions");
@@ -614,9 +630,9 @@ __device__ __forceinline__ void expand_tile(const tile_slots& t, bool plain, boo
         before_gathers();
         SECTION(pf, 9, "9_expand");
         if (__builtin_expect(wide, 0))
-            expand_batch<ROUNDS, GROUPS, true>(total, out_int0, lds_bytes, fw, delta, rs_out, lane, plus_one, group_base);
+            expand_batch<ROUNDS, GROUPS, true>(total, out_int0, lds_bytes, fw, delta, rs_out, lane, plus_one, group_base, go);
         else
-            expand_batch<ROUNDS, GROUPS, false>(total, out_int0, lds_bytes, fw, delta, rs_out, lane, plus_one, group_base);
+            expand_batch<ROUNDS, GROUPS, false>(total, out_int0, lds_bytes, fw, delta, rs_out, lane, plus_one, group_base, go);
         // the flag words go back to zero for the next batch (this wave's LDS operations execute in order)
         *reinterpret_cast<uint32_t*>(fw + 8 * lane) = 0;
         wave_lds_fence();
@@ -654,7 +670,9 @@ __device__ __forceinline__ void expand_tile(const tile_slots& t, bool plain, boo
 // slot if `narrow`, else 16).
 __device__ __forceinline__ void slow_stores(bool narrow, const wave_ctx& c, const tile_slots& t, uint32_t slowb, uint32_t plus_one, uint32_t pos0,
                                             uint32_t seg_n, const uint8_t* slot_addr, uint32_t hot_base, uint32_t hot_k,
-                                            uint32_t meta_base, const __amdgpu_buffer_rsrc_t rs_out) {
+                                            uint32_t meta_base, const __amdgpu_buffer_rsrc_t rs_out, uint32_t store_shift = 0) {
+    // (store_shift, per lane: what takes a position of the tile to the integer's place behind rs_out's base — first-fit
+    // bundles, whose members' outputs are not the tile's positions)
     // the zeros must be in memory first: two stores of one wave to one address are only ordered by the wait
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 #pragma unroll
@@ -667,7 +685,7 @@ __device__ __forceinline__ void slow_stores(bool narrow, const wave_ctx& c, cons
                 const uint8_t* const lp = sp + (narrow ? 1 : 2);
                 uint32_t v = uint32_t(lp[0]) | (uint32_t(lp[1]) << 8);
                 if (sv == 1) v |= (uint32_t(lp[2]) << 16) | (uint32_t(lp[3]) << 24);
-                __builtin_amdgcn_raw_buffer_store_b32(v + plus_one, rs_out, 4 * pos, 0, DINT_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b32(v + plus_one, rs_out, 4 * (pos + store_shift), 0, DINT_STORE_AUX);
             } else {
                 const uint32_t m = sv < hot_k ? c.lds[hot_base + sv] : __builtin_amdgcn_raw_buffer_load_b32(c.rs_dict, c.heads_base + 16 * (meta_base + sv), 0, 0);
                 const uint32_t goff = __builtin_amdgcn_raw_buffer_load_b32(c.rs_dict, c.goff_base + 4 * (meta_base + sv), 0, 0);
@@ -676,7 +694,7 @@ __device__ __forceinline__ void slow_stores(bool narrow, const wave_ctx& c, cons
 #pragma nounroll
                 for (uint32_t j = 0; j < cnt; ++j) {
                     const uint32_t v = __builtin_amdgcn_raw_buffer_load_b32(c.rs_dict, c.gtable_base + 4 * (goff + j), 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(v + plus_one, rs_out, 4 * (pos + j), 0, DINT_STORE_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b32(v + plus_one, rs_out, 4 * (pos + j + store_shift), 0, DINT_STORE_AUX);
                 }
             }
         }
@@ -1024,6 +1042,7 @@ __global__ __launch_bounds__(256) void bundle_schedule_kernel(const dint_unit* u
                                                               uint32_t only_full, uint32_t multi, uint8_t* sched,
                                                               uint32_t* block_items, u32x4* urec, uint64_t* cbase) {
     __shared__ uint32_t lanes[256], pre[256];  // lanes: the unit's lanes | its integers << 8
+    __shared__ uint32_t place[256];            // first-fit launches: bundle id | first lane << 8 | member index << 16
     __shared__ uint8_t start[256];
     const uint32_t tid = threadIdx.x;
     const uint64_t i = uint64_t(blockIdx.x) * 256 + tid;
@@ -1043,7 +1062,7 @@ __global__ __launch_bounds__(256) void bundle_schedule_kernel(const dint_unit* u
         // (in-index launches decode only the full blocks; the other units stay on their own and are skipped)
         if (n >= 1 && n <= kBundleMaxInts && (!only_full || n == 256) && nxt > in && nxt - in <= kBundleMaxBytes &&
             nxt <= enc_bytes && out <= out_capacity && out_capacity - out >= n && in >= in0 && in - in0 <= 0xFFFFFFFFull && out >= out0 &&
-            out - out0 <= 0xFFFFFFFFull) {
+            out - out0 < (multi ? (1ull << 28) : (1ull << 32))) {
             if (!multi) {
                 const uint32_t l = uint32_t((nxt - in + 7) >> 3);
                 if (l <= kWave - 1 && in + 8ull * l <= enc_bytes) L = l;  // every lane's 8-byte load stays inside the buffer
@@ -1063,7 +1082,38 @@ __global__ __launch_bounds__(256) void bundle_schedule_kernel(const dint_unit* u
     __syncthreads();
     // greedy packing, one thread per chunk: a bundle takes units while their lanes fit a wave (the chain through
     // in_use is the only serial part, the LDS reads are unrolled ahead of it)
-    if ((tid & 63u) == 0) {
+    if ((tid & 63u) == 0 && multi) {
+        // The multi-dictionary kernel's bundles need not be runs of consecutive units (every member's 256 outputs are a
+        // group of their own, stored where the unit says): first fit over four open bundles — a tile's cost does
+        // not depend on how full it is, and units of 15 to 40 lanes packed in order fill 51 of 64 lanes, first fit 57.
+        constexpr uint32_t kOpen = DINT_FF_OPEN;
+        uint32_t used[kOpen], mem[kOpen], id[kOpen], n_open = 0, next_id = 0;
+        for (uint32_t j = tid; j != tid + 64; ++j) {
+            const uint32_t l = lanes[j] & 255u;
+            start[j] = 1;
+            place[j] = 0;
+            if (l == 0) continue;
+            uint32_t b = kOpen;
+            for (uint32_t k = 0; k != kOpen; ++k)
+                if (b == kOpen && k < n_open && used[k] + l <= kWave && mem[k] < 8) b = k;
+            if (b == kOpen) {  // a new bundle: in a free slot, or in place of the fullest open one
+                if (n_open < kOpen) {
+                    b = n_open++;
+                } else {
+                    b = 0;
+                    for (uint32_t k = 1; k != kOpen; ++k)
+                        if (used[k] > used[b]) b = k;
+                }
+                id[b] = next_id++;
+                used[b] = 0;
+                mem[b] = 0;
+            }
+            place[j] = id[b] | (used[b] << 8) | (mem[b] << 16);
+            start[j] = mem[b] == 0 ? 1 : 0;
+            used[b] += l;
+            mem[b] += 1;
+        }
+    } else if ((tid & 63u) == 0) {
         uint32_t in_use = 0, ints = 0, prev_l = 0;
 #pragma unroll 16
         for (uint32_t j = tid; j != tid + 64; ++j) {
@@ -1079,8 +1129,8 @@ __global__ __launch_bounds__(256) void bundle_schedule_kernel(const dint_unit* u
     __syncthreads();
     uint32_t c = 0;
     if (start[tid] != 0 && i < n_units) {
-        c = 1;
-        if (L != 0)
+        c = 1;  // (first-fit launches: "the bundle's first member", not a count)
+        if (L != 0 && !multi)
             while (tid + c < 256 && ((tid + c) & 63u) != 0 && i + c < n_units && !start[tid + c]) ++c;
     }
     // Multi-dictionary kernel: a unit that fits a tile goes through the bundle path even when it has no neighbour
@@ -1096,7 +1146,7 @@ __global__ __launch_bounds__(256) void bundle_schedule_kernel(const dint_unit* u
     r.x = uint32_t(in - in0);
     r.y = uint32_t(out - out0);
     r.z = ((n - 1u) & 255u) | (L << 8) | (sel << 14) | (c << 18);
-    r.w = 0;
+    r.w = multi ? place[tid] : 0u;
     urec[i] = r;
     if ((tid & 63u) == 0) {
         cbase[2 * (i >> 6)] = in0;
@@ -1155,14 +1205,19 @@ __global__ __launch_bounds__(256) void bundle_items_kernel(const uint8_t* sched,
 struct bundle_lane {
     uint32_t par;        // its unit's n - 1 | first lane << 8 | first output (inside the bundle) << 14 | 8-bit slots << 28 | dictionary << 29
     uint32_t slot_rel;   // its first slot: byte offset from the chunk's in0
-    uint32_t seg;        // its unit: member index inside the bundle
+    uint32_t seg;        // its unit: member index inside the bundle (| the unit's lane in its chunk << 8: first-fit bundles)
 };
-struct bundle_head {     // wave-uniform
+struct bundle_head {     // wave-uniform ...
     uint64_t in0;        // the chunk's stream base
-    uint64_t out0;       // the bundle's first output (absolute, integers)
-    uint32_t u0, cnt;    // first unit, units
-    uint32_t used, total;  // lanes in use (<= 64), integers
+    uint64_t out0;       // the bundle's first output (absolute, integers); first-fit bundles: the chunk's output base
+    uint32_t u0, cnt;    // first unit (first-fit bundles: the chunk's first unit), units
+    uint32_t used, total;  // lanes in use (<= 64), integers (first-fit bundles: 256 per member, see below)
+    // ... except, for first-fit bundles, what lane g knows about member g (= output group g): its unit's lane in the
+    // chunk | its integers << 8, and its outputs' offset from the chunk's output base
+    uint32_t g_unit_n, g_rel_out;
 };
+
+
 
 // Lanes and outputs of each unit by one packed scan over the units' records (one per lane, from the chunk's
 // registers: unit u0 + lane is chunk lane p + lane). Registers and cross-lane operations only: it runs in the
@@ -1212,6 +1267,50 @@ __device__ __forceinline__ void bundle_map(const wave_ctx& c, const u32x4& rc, u
     bl.seg = seg;
 }
 
+// The same for a first-fit bundle: the units of the chunk whose record names bundle `b` (their first lane and member
+// index come from the schedule), gathered on the scalar side — at most 8.
+__device__ __forceinline__ void bundle_map_first_fit(const wave_ctx& c, const u32x4& rc, uint32_t chunk, uint32_t b, uint64_t in0,
+                                                     uint64_t chunk_out0, bundle_lane& bl, bundle_head& bh) {
+    const uint32_t lane = c.lane;
+    uint64_t members = __ballot(((rc.z >> 8) & 63u) != 0 && (rc.w & 255u) == b);
+    uint64_t heads = 0, units_of = 0;  // a bit at every member's first lane; member m's chunk lane in byte m
+    uint32_t cnt = 0, used = 0;
+    while (members != 0 && cnt != 8) {  // (in unit order = member order = lane order)
+        const uint32_t u = uint32_t(__builtin_ctzll(members));
+        members &= members - 1;
+        const uint32_t lane0 = (readlane(rc.w, u) >> 8) & 63u;
+        heads |= 1ull << lane0;
+        units_of |= uint64_t(u) << (8 * cnt);
+        used = lane0 + ((readlane(rc.z, u) >> 8) & 63u);
+        ++cnt;
+    }
+    bh.used = used;
+    bh.total = 256 * cnt;
+    bh.in0 = in0;
+    bh.out0 = chunk_out0;
+    bh.u0 = chunk * kChunkUnits;
+    bh.cnt = cnt;
+    const uint32_t mlo = uint32_t(heads), mhi = uint32_t(heads >> 32);
+    const uint32_t own = lane < 32 ? (mlo >> lane) & 1u : (mhi >> (lane - 32)) & 1u;
+    const uint32_t seg = (__builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u)) + own - 1u) & 7u;  // lane 0 is a head
+    const uint32_t unit = uint32_t(units_of >> (8 * seg)) & 63u;
+    const uint32_t seg_rel = uint32_t(__shfl(rc.x, int(unit)));
+    const uint32_t seg_pk = uint32_t(__shfl(rc.z, int(unit)));
+    const uint32_t seg_lane0 = (uint32_t(__shfl(rc.w, int(unit))) >> 8) & 63u;
+    const uint32_t sel = (seg_pk >> 14) & 15u;
+    const uint32_t narrow = sel >= 6 ? 1u : 0u;
+    const uint32_t dict = narrow ? sel - 6 : sel;
+    bl.par = (seg_pk & 255u) | (seg_lane0 << 8) | ((256u * seg) << 14) | (narrow << 28) | (dict << 29);
+    bl.slot_rel = seg_rel + 1u + (narrow ? 4u : 8u) * (lane - seg_lane0);
+    bl.seg = seg | (unit << 8);
+    // lane g: member g (the shuffles with every lane enabled: a cross-lane read under `lane < cnt` finds the lanes
+    // outside the branch silent)
+    const uint32_t gu = uint32_t(units_of >> (8 * (lane & 7u))) & 63u;
+    const uint32_t g_pk = uint32_t(__shfl(rc.z, int(gu)));
+    bh.g_rel_out = uint32_t(__shfl(rc.y, int(gu)));
+    bh.g_unit_n = gu | ((lane < cnt ? (g_pk & 255u) + 1u : 0u) << 8);
+}
+
 // the lane's 8 stream bytes (the schedule made sure they lie inside the buffer)
 __device__ __forceinline__ uint64_t bundle_raw(const decode_args& a, const bundle_lane& bl, const bundle_head& bh, uint32_t lane) {
     uint64_t raw = 0;
@@ -1236,13 +1335,15 @@ __device__ __forceinline__ void bundle_process(const decode_args& a, const wave_
     const uint64_t u0 = bh.u0;
     const uint32_t cnt = bh.cnt, used = bh.used, total = bh.total;
     const uint64_t out0 = bh.out0;
-    if (total == 0 || out0 > a.out_capacity || a.out_capacity - out0 < total) {
+    // (first-fit bundles — the multi-dictionary kernel's: the schedule checked every member's place in the output)
+    if (total == 0 || (!MULTI && (out0 > a.out_capacity || a.out_capacity - out0 < total))) {
         issue_next();
         return;
     }
     const bool has = lane < cnt;
     const bool lane_used = lane < used;
-    const uint32_t seg = bl.seg;
+    const uint32_t seg = bl.seg & 255u;
+    const uint32_t seg_unit = MULTI ? bl.seg >> 8 : seg;  // the lane's unit behind u0
     const uint32_t seg_n = (bl.par & 255u) + 1u;
     const uint32_t seg_lane0 = (bl.par >> 8) & 63u;
     const uint32_t seg_out0 = (bl.par >> 14) & 0x3FFFu;
@@ -1403,12 +1504,14 @@ __device__ __forceinline__ void bundle_process(const decode_args& a, const wave_
         const uint32_t next_lane = above ? uint32_t(__builtin_ctzll(above)) : lane;
         const uint32_t next_seg = uint32_t(__shfl(seg, int(next_lane)));  // (unconditional: every lane takes part)
         if (last_end != 0 && (above == 0 || next_seg != seg))
-            a.end_off[u0 + seg] = slot_lane + (narrow ? 1ull : 2ull) * last_end;
+            a.end_off[u0 + seg_unit] = slot_lane + (narrow ? 1ull : 2ull) * last_end;
     }
 
     uint32_t* const out = a.out + out0;
     uint32_t* const out_u = reinterpret_cast<uint32_t*>(uniform64(reinterpret_cast<uint64_t>(out)));
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out_u, 0, int(total * 4), 0x00020000);
+    // (first-fit bundles: rs_out is the slow path's only — everything from the chunk's output base on, see store_shift)
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out_u, 0, MULTI ? 0x7FFFFFFC : int(total * 4), 0x00020000);
+    group_out go{out_u, bh.g_unit_n, bh.g_rel_out};
     // the heads into their cells; the tails of the large ones behind the flag/delta phase (decode_segment)
     uint32_t t3[kSPL];
 #pragma unroll
@@ -1428,7 +1531,7 @@ __device__ __forceinline__ void bundle_process(const decode_args& a, const wave_
     // (in-index docs parts: every unit of the bundle is a 256-posting block, so group g of the expansion is unit
     // u0 + g; a slow codeword anywhere leaves the whole bundle as gaps for the flagged fix-up)
     const bool as_docids = a.unit_base != nullptr && !tile_slow && total <= kMaxCap;
-    if (a.unit_base != nullptr && !as_docids && has) a.gaps_left[u0 + lane] = 1;
+    if (a.unit_base != nullptr && !as_docids && has) a.gaps_left[u0 + (MULTI ? bh.g_unit_n & 255u : lane)] = 1;
     // (a bundle is one batch by construction: the schedule packs at most kMaxCap integers into one)
 #ifndef DINT_BUNDLE_GROUPS
 #define DINT_BUNDLE_GROUPS DINT_GROUPS
@@ -1445,11 +1548,13 @@ __device__ __forceinline__ void bundle_process(const decode_args& a, const wave_
         }
         wave_lds_fence();
         issue_next();
-    });
+    }, MULTI ? &go : nullptr);
     if (tile_slow) {
         // (positions in slow_stores are relative to the bundle; a unit's clamp is what `room` must be)
         const uint8_t* const my_slots = a.enc + slot_lane;
-        slow_stores(MULTI && narrow, c, t, slowb, a.plus_one, 0u, seg_out0 + seg_n, my_slots, hot_base, hot_k, meta_base, rs_out);
+        // first-fit bundles: the lane's unit's outputs begin at its own offset, not at the tile's position 256 * member
+        const uint32_t shift = MULTI ? uint32_t(__shfl(bh.g_rel_out, int(seg))) - seg_out0 : 0u;
+        slow_stores(MULTI && narrow, c, t, slowb, a.plus_one, 0u, seg_out0 + seg_n, my_slots, hot_base, hot_k, meta_base, rs_out, shift);
     }
     SECTION(pf, 13, "epilogue");
 }
@@ -1536,7 +1641,10 @@ __device__ __forceinline__ bool decode_bundle_chunks(const decode_args& a, const
         cnt = (readlane(rc.z, p) >> 18) & 127u;
         return true;
     };
-    auto map_here = [&](bundle_lane& l, bundle_head& h) { bundle_map<MULTI>(c, rc, ch, p, cnt, in0, out0, l, h); };
+    auto map_here = [&](bundle_lane& l, bundle_head& h) {
+        if (MULTI) bundle_map_first_fit(c, rc, ch, readlane(rc.w, p) & 255u, in0, out0, l, h);
+        else bundle_map<MULTI>(c, rc, ch, p, cnt, in0, out0, l, h);
+    };
     if (!advance()) return true;
     bundle_lane bl;
     bundle_head bh;

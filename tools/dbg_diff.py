@@ -45,3 +45,5 @@ for it in range(int(os.environ.get("LAUNCHES", "3"))):
             in_unit = bad[which == u] - uo[u]
             print(f"  unit {u}: n={un[u]} first bad at {i - uo[u]} (last {in_unit.max()}, {in_unit.size} bad); "
                   f"want {coll.gaps[i:i+6]} got {got[i:i+6]}")
+            if os.environ.get("BAD_INDICES"):
+                print("     bad offsets:", list(in_unit[:80]), " unit in_off", int(units["in_off"][u]), "out_off", int(uo[u]))
