@@ -163,8 +163,13 @@ struct dint_dict {
     // behind the event of the launch that used the slot last
     static constexpr uint32_t kQueueSlots = 64;
     uint32_t* d_queues = nullptr;
-    uint8_t* d_sched[kQueueSlots] = {};   // per slot: the bundle schedule of the launch (grow-only)
-    size_t sched_cap[kQueueSlots] = {};
+    // the bundle schedule of a launch (22 bytes per unit): a few workspaces taken in turn — a launch waits (on the host,
+    // normally not at all) until the launch that last used its workspace is done. (One per queue slot was 64
+    // allocations of half a gigabyte for a block-granular table of 2e7 units.)
+    static constexpr uint32_t kSchedSlots = 4;
+    uint8_t* d_sched[kSchedSlots] = {};
+    size_t sched_cap[kSchedSlots] = {};
+    int sched_user[kSchedSlots] = {-1, -1, -1, -1};  // the queue slot of the launch that used it last
     hipEvent_t slot_done[kQueueSlots] = {};
     hipEvent_t slot_start[kQueueSlots] = {}, slot_stop[kQueueSlots] = {};
     bool slot_used[kQueueSlots] = {};
@@ -729,15 +734,21 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
         const size_t n_chunks = (n_units + kChunkUnits - 1) / kChunkUnits;
         const size_t need = 16 * n_units + 16 * n_chunks + 4 * n_units + 4 * n_blocks + 4 + 2 * n_units;
         if (cache && !cache->d_mem) HIP_TRY(hipMalloc(&cache->d_mem, need));
-        if (!cache && mut->sched_cap[slot] < need) {
-            if (mut->d_sched[slot]) HIP_TRY(hipFree(mut->d_sched[slot]));
-            mut->d_sched[slot] = nullptr;
-            mut->sched_cap[slot] = 0;
-            const size_t want = need + need / 4 + 4096;
-            HIP_TRY(hipMalloc(&mut->d_sched[slot], want));
-            mut->sched_cap[slot] = want;
+        const uint32_t ss = uint32_t(mut->launches % dint_dict::kSchedSlots);
+        if (!cache) {
+            const int prev = mut->sched_user[ss];
+            if (prev >= 0 && prev != int(slot) && mut->slot_used[prev]) HIP_TRY(hipEventSynchronize(mut->slot_done[prev]));
+            mut->sched_user[ss] = int(slot);
         }
-        u32x4* const d_urec = reinterpret_cast<u32x4*>(cache ? cache->d_mem : mut->d_sched[slot]);
+        if (!cache && mut->sched_cap[ss] < need) {
+            if (mut->d_sched[ss]) HIP_TRY(hipFree(mut->d_sched[ss]));
+            mut->d_sched[ss] = nullptr;
+            mut->sched_cap[ss] = 0;
+            const size_t want = need + need / 4 + 4096;
+            HIP_TRY(hipMalloc(&mut->d_sched[ss], want));
+            mut->sched_cap[ss] = want;
+        }
+        u32x4* const d_urec = reinterpret_cast<u32x4*>(cache ? cache->d_mem : mut->d_sched[ss]);
         uint64_t* const d_cbase = reinterpret_cast<uint64_t*>(d_urec + n_units);
         uint32_t* const d_items = reinterpret_cast<uint32_t*>(d_cbase + 2 * n_chunks);
         uint32_t* const d_block = d_items + n_units;
@@ -748,6 +759,8 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
             hipLaunchKernelGGL(bundle_schedule_kernel, dim3(uint32_t(n_blocks)), dim3(256), 0, s, d_units, d_spans, uint64_t(n_units),
                                d_enc, uint64_t(enc_bytes), uint64_t(out_capacity), only_full,
                                uint32_t(dd->kind == DINT_DICT_MULTI_PACKED), d_sch, d_block, d_urec, d_cbase);
+            if (dd->kind == DINT_DICT_MULTI_PACKED)
+                hipLaunchKernelGGL(bundle_pack_kernel, dim3(uint32_t((n_chunks + 63) / 64)), dim3(64), 0, s, d_urec, uint64_t(n_units));
             hipLaunchKernelGGL(bundle_offsets_kernel, dim3(1), dim3(1024), 0, s, d_block, uint32_t(n_blocks), d_n_items);
             hipLaunchKernelGGL(bundle_items_kernel, dim3(uint32_t(n_blocks)), dim3(256), 0, s, d_sch, uint64_t(n_units), d_block,
                                d_items, d_item_cnt);

@@ -1082,37 +1082,11 @@ __global__ __launch_bounds__(256) void bundle_schedule_kernel(const dint_unit* u
     __syncthreads();
     // greedy packing, one thread per chunk: a bundle takes units while their lanes fit a wave (the chain through
     // in_use is the only serial part, the LDS reads are unrolled ahead of it)
-    if ((tid & 63u) == 0 && multi) {
-        // The multi-dictionary kernel's bundles need not be runs of consecutive units (every member's 256 outputs are a
-        // group of their own, stored where the unit says): first fit over four open bundles — a tile's cost does
-        // not depend on how full it is, and units of 15 to 40 lanes packed in order fill 51 of 64 lanes, first fit 57.
-        constexpr uint32_t kOpen = DINT_FF_OPEN;
-        uint32_t used[kOpen], mem[kOpen], id[kOpen], n_open = 0, next_id = 0;
-        for (uint32_t j = tid; j != tid + 64; ++j) {
-            const uint32_t l = lanes[j] & 255u;
-            start[j] = 1;
-            place[j] = 0;
-            if (l == 0) continue;
-            uint32_t b = kOpen;
-            for (uint32_t k = 0; k != kOpen; ++k)
-                if (b == kOpen && k < n_open && used[k] + l <= kWave && mem[k] < 8) b = k;
-            if (b == kOpen) {  // a new bundle: in a free slot, or in place of the fullest open one
-                if (n_open < kOpen) {
-                    b = n_open++;
-                } else {
-                    b = 0;
-                    for (uint32_t k = 1; k != kOpen; ++k)
-                        if (used[k] > used[b]) b = k;
-                }
-                id[b] = next_id++;
-                used[b] = 0;
-                mem[b] = 0;
-            }
-            place[j] = id[b] | (used[b] << 8) | (mem[b] << 16);
-            start[j] = mem[b] == 0 ? 1 : 0;
-            used[b] += l;
-            mem[b] += 1;
-        }
+    if (multi) {
+        // (the multi-dictionary kernel's bundles are packed by bundle_pack_kernel, behind this kernel: here every unit
+        // that fits a tile is a bundle member, the others are the unit queue's)
+        start[tid] = L != 0 ? 0 : 1;
+        place[tid] = 0;
     } else if ((tid & 63u) == 0) {
         uint32_t in_use = 0, ints = 0, prev_l = 0;
 #pragma unroll 16
@@ -1129,7 +1103,7 @@ __global__ __launch_bounds__(256) void bundle_schedule_kernel(const dint_unit* u
     __syncthreads();
     uint32_t c = 0;
     if (start[tid] != 0 && i < n_units) {
-        c = 1;  // (first-fit launches: "the bundle's first member", not a count)
+        c = 1;
         if (L != 0 && !multi)
             while (tid + c < 256 && ((tid + c) & 63u) != 0 && i + c < n_units && !start[tid + c]) ++c;
     }
@@ -1151,6 +1125,65 @@ __global__ __launch_bounds__(256) void bundle_schedule_kernel(const dint_unit* u
     if ((tid & 63u) == 0) {
         cbase[2 * (i >> 6)] = in0;
         cbase[2 * (i >> 6) + 1] = out0;
+    }
+}
+
+// The multi-dictionary kernel's bundles need not be runs of consecutive units (every member's 256 outputs are an
+// expansion group of their own, stored where the unit says): FIRST FIT over a few open bundles — a tile's cost
+// does not depend on how full it is, and units of 15 to 40 lanes packed in order fill 51 of 64 lanes, first fit 57.
+// One thread per chunk, 64 chunks to a wave (the packing of a chunk is a serial walk over its 64 units: as a loop of
+// one lane per wave inside bundle_schedule_kernel it took 1.5 ms for 2e7 units; here the 64 lanes of a wave walk 64
+// chunks together). Rewrites the units' records: bundle id | first lane << 8 | member index << 16 in .w, "first
+// member" in the count field of .z.
+__global__ __launch_bounds__(64) void bundle_pack_kernel(u32x4* urec, uint64_t n_units) {
+    __shared__ uint32_t zs[64][65];  // the chunk's packed words, a row per thread (odd stride: conflict-free)
+    constexpr uint32_t kOpen = DINT_FF_OPEN;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t base = (uint64_t(blockIdx.x) * 64 + tid) * kChunkUnits;
+    for (uint32_t j = 0; j != kChunkUnits; ++j) zs[tid][j] = base + j < n_units ? urec[base + j].z : 0u;
+    uint32_t used[kOpen], mem[kOpen], id[kOpen], n_open = 0, next_id = 0;
+#pragma unroll
+    for (uint32_t k = 0; k != kOpen; ++k) used[k] = 0, mem[k] = 0, id[k] = 0;
+    for (uint32_t j = 0; j != kChunkUnits; ++j) {
+        const uint32_t z = zs[tid][j];
+        const uint32_t l = (z >> 8) & 63u;
+        uint32_t b = kOpen;
+#pragma unroll
+        for (uint32_t k = 0; k != kOpen; ++k)
+            if (b == kOpen && k < n_open && used[k] + l <= kWave && mem[k] < 8) b = k;
+        const bool fresh = b == kOpen;  // a new bundle: in a free slot, or in place of the fullest open one
+        if (fresh) {
+            b = n_open < kOpen ? n_open : 0u;
+            if (n_open == kOpen) {
+                uint32_t most = used[0];
+#pragma unroll
+                for (uint32_t k = 1; k != kOpen; ++k)
+                    if (used[k] > most) most = used[k], b = k;
+            }
+        }
+        uint32_t pl = 0;
+#pragma unroll
+        for (uint32_t k = 0; k != kOpen; ++k)
+            if (k == b && l != 0) {
+                if (fresh) id[k] = next_id, used[k] = 0, mem[k] = 0;
+                pl = id[k] | (used[k] << 8) | (mem[k] << 16) | (mem[k] == 0 ? 1u << 31 : 0u);
+                used[k] += l;
+                mem[k] += 1;
+            }
+        if (fresh && l != 0) {
+            next_id += 1;
+            n_open += n_open < kOpen ? 1u : 0u;
+        }
+        zs[tid][j] = pl;  // (the row is this thread's own)
+    }
+    for (uint32_t j = 0; j != kChunkUnits; ++j) {
+        const uint32_t pl = zs[tid][j];
+        if (base + j < n_units && pl != 0) {  // (a member: its first-lane field or its "first" bit is set... or both are 0 only for member 0 of bundle 0 at lane 0, which has the bit)
+            u32x4 r = urec[base + j];
+            r.z = (r.z & ~(127u << 18)) | ((pl >> 31) << 18);
+            r.w = pl & 0x7FFFFFFFu;
+            urec[base + j] = r;
+        }
     }
 }
 
