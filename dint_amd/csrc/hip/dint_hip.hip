@@ -425,6 +425,7 @@ struct dint_query_index {
     // one call = one host-to-device copy (everything the call's kernels read from the host, staged in pinned memory),
     // one clear (every counter the call's launches count in), the launches, one copy back
     void* h_stage = nullptr;
+    void* d_stage = nullptr;
     size_t h_stage_cap = 0;
     device_buffer<uint32_t> inputs, ctrl;
     device_buffer<uint32_t> cand, target, probe, fprobe, tails, spans, bases;
@@ -1064,11 +1065,11 @@ int dint_query_index_create(const dint_dict* docs_dict, const uint8_t* d_index, 
     bool ok = hip_ok(hipSetDevice(docs_dict->device), "hipSetDevice") &&
               hip_ok(hipMalloc(&qi->d_blocks, nb * sizeof(dint_block_ref)), "hipMalloc(blocks)") &&
               hip_ok(hipMalloc(&qi->d_block_max, nb * 4), "hipMalloc(block_max)") &&
-              hip_ok(hipMalloc(&qi->d_needed, nb * 4), "hipMalloc(needed)") &&
-              hip_ok(hipMalloc(&qi->d_rank, nb * 4), "hipMalloc(rank)") &&
-              hip_ok(hipMalloc(&qi->d_touched, nb * 4), "hipMalloc(touched)") &&
+              hip_ok(hipMalloc(&qi->d_needed, 2 * nb * 4), "hipMalloc(needed)") &&  // (two sets of each: round_tail)
+              hip_ok(hipMalloc(&qi->d_rank, 2 * nb * 4), "hipMalloc(rank)") &&
+              hip_ok(hipMalloc(&qi->d_touched, 2 * nb * 4), "hipMalloc(touched)") &&
               hip_ok(hipMalloc(&qi->d_n_touched, 8), "hipMalloc(n_touched)") &&  // {touched blocks, short pages} of a round
-              hip_ok(hipMemset(qi->d_needed, 0, nb * 4), "hipMemset(needed)");
+              hip_ok(hipMemset(qi->d_needed, 0, 2 * nb * 4), "hipMemset(needed)");
     if (ok && n_blocks)
         ok = hip_ok(hipMemcpy(qi->d_blocks, blocks, n_blocks * sizeof(dint_block_ref), hipMemcpyHostToDevice), "hipMemcpy(blocks)") &&
              hip_ok(hipMemcpy(qi->d_block_max, maxs.data(), n_blocks * 4, hipMemcpyHostToDevice), "hipMemcpy(block_max)");
@@ -1120,11 +1121,32 @@ static int decode_pages(dint_query_index* qi, size_t n_pages, uint32_t* d_docs, 
 constexpr size_t kCtrlQueueAt = 32;
 constexpr size_t kCtrlWords = kCtrlQueueAt + (kQueueShards + 1) * kQueueStride;
 
+static size_t lean_pages() {
+    const char* e = std::getenv("DINT_QUERY_LEAN_PAGES");  // (tests force either form)
+    return e ? size_t(std::strtoull(e, nullptr, 10)) : size_t(2048);
+}
+
+// (one workgroup walks all the candidates: past a few pages the probe and search launches, a thread per candidate, win)
+static size_t tail_pages() {
+    const char* e = std::getenv("DINT_QUERY_TAIL_PAGES");
+    return e ? size_t(std::strtoull(e, nullptr, 10)) : size_t(4);
+}
+static int decode_pages_lean(dint_query_index* qi, const uint32_t* d_ids, const uint32_t* d_count, size_t bound, uint32_t* d_docs,
+                             uint32_t* ctrl, uint32_t retire, hipStream_t s, const query_pages* search,
+                             const round_tail* tail = nullptr);
+
 // Pages -> docIDs, three launches on the stream: the pages are the blocks ids[0 .. *count) (count null: ids[0 .. bound)),
 // `bound` >= their number is what the launches are sized for. `ctrl`: this decode's (cleared) control words.
 // retire: the slots past each page's last posting are marked dead (candidate pages).
+// `search` (candidate pages): what the first round's search needs; *searched says whether it was done along the way.
 static int decode_pages_counted(dint_query_index* qi, const uint32_t* d_ids, const uint32_t* d_count, size_t bound, uint32_t* d_docs,
-                                uint32_t* ctrl, uint32_t retire, hipStream_t s) {
+                                uint32_t* ctrl, uint32_t retire, hipStream_t s, const query_pages* search = nullptr,
+                                bool* searched = nullptr) {
+    if (searched) *searched = false;
+    if (bound < lean_pages() && qi->index_bytes >= 8) {
+        if (searched) *searched = search != nullptr;
+        return decode_pages_lean(qi, d_ids, d_count, bound, d_docs, ctrl, retire, s, search);
+    }
     if (!qi->sub.ensure(bound) || !qi->units.ensure(bound) || !qi->spans.ensure(bound) || !qi->bases.ensure(bound) ||
         !qi->ends.ensure(bound) || !qi->gaps_left.ensure(bound) || !qi->tails.ensure(bound + 1))
         return DINT_ERR_HIP;
@@ -1140,6 +1162,45 @@ static int decode_pages_counted(dint_query_index* qi, const uint32_t* d_ids, con
     // (the grid is sized for "every page is a short block": the waves with nothing to do leave at once)
     hipLaunchKernelGGL(fix_pages_kernel, dim3(uint32_t((bound + kTailLanes - 1) / kTailLanes)), dim3(64), kTailLdsBytes, s, qi->d_index,
                        uint64_t(qi->index_bytes), qi->sub.p, uint64_t(bound), qi->tails.p, d_n_tails, d_docs, cap, qi->gaps_left.p, retire);
+    HIP_TRY(hipGetLastError());
+    return DINT_OK;
+}
+
+// The same in ONE launch, for the rounds of a few pages (a single query: the launches are what it waits for):
+// decode_*_query_kernel looks the blocks up itself, sums what it has to leave as gaps and runs the short blocks'
+// interpolative code in place — no prepare, no fix-up launch. Past kLeanPages the three-launch form above wins: its
+// decode packs several blocks to a tile, and its short blocks run eight to a wave.
+static int decode_pages_lean(dint_query_index* qi, const uint32_t* d_ids, const uint32_t* d_count, size_t bound, uint32_t* d_docs,
+                             uint32_t* ctrl, uint32_t retire, hipStream_t s, const query_pages* search, const round_tail* tail) {
+    if (!qi->gaps_left.ensure(bound)) return DINT_ERR_HIP;
+    const dint_dict* dd = qi->docs;
+    decode_args a{};
+    a.dict = dd->view;
+    a.enc = qi->d_index;
+    a.enc_bytes = qi->index_bytes;
+    a.n_units = bound;
+    a.out = d_docs;
+    a.out_capacity = uint64_t(bound) * kPageSlots;
+    a.gaps_left = qi->gaps_left.p;
+    const uint64_t blocks_needed = (uint64_t(bound) + kWavesPerBlock - 1) / kWavesPerBlock;
+    const uint32_t grid = uint32_t(std::min<uint64_t>(blocks_needed, std::max<uint32_t>(1, dd->compute_units) * kBlocksPerCU));
+    const size_t lds_bytes = (size_t(dd->view.hot_words) + kClassTableWords + kWavesPerBlock * kScratchWords) * 4;
+    a.queue = ctrl + kCtrlQueueAt;
+    a.chunk_queue = a.queue + kQueueShards * kQueueStride;
+    a.n_shards = std::min<uint32_t>(kQueueShards, grid);
+    query_pages qp{};
+    if (search) qp = *search;  // (the first round's search, for the candidate pages)
+    qp.blocks = qi->d_blocks;
+    qp.ids = d_ids;
+    qp.count = d_count;
+    qp.bound = bound;
+    qp.retire = retire;
+    round_tail rt{};
+    if (tail) rt = *tail;
+    if (dd->kind == DINT_DICT_MULTI_PACKED)
+        hipLaunchKernelGGL(decode_multi_query_kernel, dim3(grid), dim3(kBlockThreads), lds_bytes, s, a, qp, rt);
+    else
+        hipLaunchKernelGGL(decode_single_query_kernel, dim3(grid), dim3(kBlockThreads), lds_bytes, s, a, qp, rt);
     HIP_TRY(hipGetLastError());
     return DINT_OK;
 }
@@ -1207,10 +1268,13 @@ static int and_queries_impl(dint_query_index* qi, const dint_dict* freqs_dict, c
     std::lock_guard<std::mutex> lock(qi->mutex);
     HIP_TRY(hipSetDevice(qi->docs->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // inputs: {page -> block, page -> query, per round and query: first block and block count of the round's list}
-    const size_t in_words = 2 * n_pages + h_first.size() + h_blocks.size();
-    const size_t ctrl_words = (rounds + 1) * kCtrlWords + 2 * n_queries;  // ... and the result counters (u64 each) behind them
-    const size_t stage_bytes = std::max(in_words * 4, n_queries * sizeof(unsigned long long));
+    // inputs: {page -> block, page -> query, per round and query: first block and block count of the round's list},
+    // and behind them — zeros, copied in with them: one copy instead of a copy and a clear — every counter the
+    // call's launches count in, and the result counters (u64 each)
+    const size_t in_words = (2 * n_pages + h_first.size() + h_blocks.size() + 31) / 32 * 32;
+    const size_t ctrl_words = (rounds + 1) * kCtrlWords + 2 * n_queries;
+    const size_t up_words = in_words + ctrl_words;
+    const size_t stage_bytes = std::max(up_words * 4, n_queries * sizeof(unsigned long long));
     if (qi->h_stage_cap < stage_bytes) {
         if (qi->h_stage) (void)hipHostFree(qi->h_stage);
         qi->h_stage = nullptr;
@@ -1218,32 +1282,49 @@ static int and_queries_impl(dint_query_index* qi, const dint_dict* freqs_dict, c
         const size_t want = stage_bytes + stage_bytes / 2 + 4096;
         HIP_TRY(hipHostMalloc(&qi->h_stage, want, hipHostMallocDefault));
         qi->h_stage_cap = want;
+        qi->d_stage = nullptr;  // the same memory as the kernels see it (the last probe writes the results there)
+        if (hipHostGetDevicePointer(&qi->d_stage, qi->h_stage, 0) != hipSuccess) qi->d_stage = nullptr;
     }
-    if (!qi->inputs.ensure(in_words) || !qi->ctrl.ensure(ctrl_words) || !qi->cand.ensure(n_slots) || !qi->target.ensure(n_slots))
-        return DINT_ERR_HIP;
+    if (!qi->inputs.ensure(up_words) || !qi->cand.ensure(n_slots) || !qi->target.ensure(n_slots)) return DINT_ERR_HIP;
     {
         uint32_t* h = static_cast<uint32_t*>(qi->h_stage);
         std::memcpy(h, h_page_block.data(), n_pages * 4);
         std::memcpy(h + n_pages, h_page_query.data(), n_pages * 4);
         std::memcpy(h + 2 * n_pages, h_first.data(), h_first.size() * 4);
         std::memcpy(h + 2 * n_pages + h_first.size(), h_blocks.data(), h_blocks.size() * 4);
+        std::memset(h + in_words, 0, ctrl_words * 4);
     }
     uint32_t* const d_page_block = qi->inputs.p;
     uint32_t* const d_page_query = d_page_block + n_pages;
     uint32_t* const d_term_first = d_page_query + n_pages;
     uint32_t* const d_term_blocks = d_term_first + h_first.size();
-    unsigned long long* const d_counts = reinterpret_cast<unsigned long long*>(qi->ctrl.p + (rounds + 1) * kCtrlWords);
-    HIP_TRY(hipMemcpyAsync(qi->inputs.p, qi->h_stage, in_words * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemsetAsync(qi->ctrl.p, 0, ctrl_words * 4, s));
+    uint32_t* const d_ctrl = qi->inputs.p + in_words;
+    unsigned long long* const d_counts = reinterpret_cast<unsigned long long*>(d_ctrl + (rounds + 1) * kCtrlWords);
+    HIP_TRY(hipMemcpyAsync(qi->inputs.p, qi->h_stage, up_words * 4, hipMemcpyHostToDevice, s));
 
     const uint32_t tb = 256;
     const uint32_t slot_grid = uint32_t(n_pages);  // 256 slots per page = one workgroup
     if (qi->claims_dirty) {  // (a call that failed between a search and its release left claim flags behind)
-        HIP_TRY(hipMemsetAsync(qi->d_needed, 0, std::max<size_t>(1, qi->n_blocks) * 4, s));
+        HIP_TRY(hipMemsetAsync(qi->d_needed, 0, 2 * std::max<size_t>(1, qi->n_blocks) * 4, s));
         qi->claims_dirty = false;
     }
     // candidates: the rarest list of every query
-    int st = decode_pages_counted(qi, d_page_block, nullptr, n_pages, qi->cand.p, qi->ctrl.p, 1u, s);
+    uint64_t round0_blocks = 0;
+    if (rounds)
+        for (size_t q = 0; q != n_queries; ++q) round0_blocks += h_blocks[q];
+    query_pages search0{};
+    search0.page_query = d_page_query;
+    search0.term_first = d_term_first;
+    search0.term_blocks = d_term_blocks;
+    search0.block_max = qi->d_block_max;
+    search0.target = qi->target.p;
+    search0.needed = qi->d_needed;
+    search0.rank = qi->d_rank;
+    search0.touched = qi->d_touched;
+    search0.n_touched = d_ctrl + kCtrlWords;
+    bool searched0 = false;
+    int st = decode_pages_counted(qi, d_page_block, nullptr, n_pages, qi->cand.p, d_ctrl, 1u, s, round0_blocks ? &search0 : nullptr,
+                                  &searched0);
     if (st != DINT_OK) {
         (void)hipStreamSynchronize(s);
         return st;
@@ -1258,16 +1339,79 @@ static int and_queries_impl(dint_query_index* qi, const dint_dict* freqs_dict, c
     // the 200 us a query took.) Past kAsyncPages the count is read back after all: launches sized for a bound far
     // above the truth cost more than the wait.
     constexpr size_t kAsyncPages = 32768;
+    size_t last_round = rounds;  // the last round that has anything to probe counts the survivors as well
+    for (size_t r = 0; r != rounds; ++r)
+        for (size_t q = 0; q != n_queries; ++q)
+            if (h_blocks[r * n_queries + q]) {
+                last_round = r;
+                break;
+            }
+    bool counted = false;
+    // the last probe hands the results over itself (a few pages: every workgroup of it passes through one counter)
+    bool results_to_host = !freqs_dict && qi->d_stage != nullptr && n_pages <= 4096;
+    // Few candidates, few pages in every round (a single query): one launch per round — round_tail.
+    bool tail_form = searched0 && n_pages <= tail_pages();
+    std::vector<size_t> round_bound(rounds, 0);
     for (size_t r = 0; r != rounds; ++r) {
+        uint64_t list_blocks = 0;
+        for (size_t q = 0; q != n_queries; ++q) list_blocks += h_blocks[r * n_queries + q];
+        round_bound[r] = size_t(std::min<uint64_t>(n_slots, list_blocks));
+        tail_form = tail_form && list_blocks != 0 && round_bound[r] < lean_pages();
+    }
+    if (tail_form) {
+        const size_t nb = std::max<size_t>(1, qi->n_blocks);
+        for (size_t r = 0; r != rounds; ++r) {
+            const size_t set = r & 1, next_set = set ^ 1;
+            uint32_t* const ctrl = d_ctrl + (r + 1) * kCtrlWords;
+            if (!qi->probe.ensure(uint64_t(round_bound[r]) * kPageSlots)) {
+                (void)hipStreamSynchronize(s);
+                return DINT_ERR_HIP;
+            }
+            round_tail t{};
+            t.done = ctrl + 2;
+            t.cand = qi->cand.p;
+            t.n_slots = n_slots;
+            t.page_query = d_page_query;
+            t.blocks = qi->d_blocks;
+            t.target = qi->target.p;
+            t.term_blocks = d_term_blocks + r * n_queries;
+            t.rank = qi->d_rank + set * nb;
+            t.probe = qi->probe.p;
+            t.touched = qi->d_touched + set * nb;
+            t.n_touched = ctrl;
+            t.needed = qi->d_needed + set * nb;
+            if (r + 1 != rounds) {
+                t.next_first = d_term_first + (r + 1) * n_queries;
+                t.next_blocks = d_term_blocks + (r + 1) * n_queries;
+                t.block_max = qi->d_block_max;
+                t.next_needed = qi->d_needed + next_set * nb;
+                t.next_rank = qi->d_rank + next_set * nb;
+                t.next_touched = qi->d_touched + next_set * nb;
+                t.next_n_touched = d_ctrl + (r + 2) * kCtrlWords;
+            } else {
+                t.counts = d_counts;
+                t.host_counts = results_to_host ? static_cast<unsigned long long*>(qi->d_stage) : nullptr;
+                t.n_queries = uint32_t(n_queries);
+            }
+            st = decode_pages_lean(qi, t.touched, ctrl, round_bound[r], qi->probe.p, ctrl, 0u, s, nullptr, &t);
+            if (st != DINT_OK) {
+                (void)hipStreamSynchronize(s);
+                return st;
+            }
+        }
+        counted = true;
+    }
+    for (size_t r = 0; r != rounds && !tail_form; ++r) {
         const uint32_t* first = d_term_first + r * n_queries;
         const uint32_t* nblk = d_term_blocks + r * n_queries;
-        uint32_t* const ctrl = qi->ctrl.p + (r + 1) * kCtrlWords;
+        uint32_t* const ctrl = d_ctrl + (r + 1) * kCtrlWords;
         uint64_t list_blocks = 0;
         for (size_t q = 0; q != n_queries; ++q) list_blocks += h_blocks[r * n_queries + q];
         if (list_blocks == 0) continue;  // no query has a term for this round
         size_t bound = size_t(std::min<uint64_t>(n_slots, list_blocks));
-        hipLaunchKernelGGL(and_search_kernel, dim3(slot_grid), dim3(tb), 0, s, qi->cand.p, n_slots, d_page_query,
-                           first, nblk, qi->d_block_max, qi->target.p, qi->d_needed, qi->d_rank, qi->d_touched, ctrl);
+        if (r != 0 || !searched0)
+            hipLaunchKernelGGL(and_search_kernel, dim3(slot_grid), dim3(tb), 0, s, qi->cand.p, n_slots, d_page_query,
+                               first, nblk, qi->d_block_max, qi->target.p, qi->d_needed, qi->d_rank, qi->d_touched, ctrl);
         const uint32_t* d_count = ctrl;
         if (bound > kAsyncPages) {
             uint32_t n_touched = 0;
@@ -1287,9 +1431,15 @@ static int and_queries_impl(dint_query_index* qi, const dint_dict* freqs_dict, c
             return st;
         }
         hipLaunchKernelGGL(and_probe_release_kernel, dim3(slot_grid), dim3(tb), 0, s, qi->cand.p, n_slots, d_page_query, nblk, qi->d_blocks,
-                           qi->target.p, qi->d_rank, qi->probe.p, qi->d_touched, ctrl, qi->d_needed);
+                           qi->target.p, qi->d_rank, qi->probe.p, qi->d_touched, ctrl, qi->d_needed,
+                           r == last_round ? d_counts : static_cast<unsigned long long*>(nullptr), ctrl + 2,
+                           r == last_round && results_to_host ? static_cast<unsigned long long*>(qi->d_stage)
+                                                              : static_cast<unsigned long long*>(nullptr),
+                           uint32_t(n_queries));
+        counted = counted || r == last_round;
     }
-    hipLaunchKernelGGL(and_count_kernel, dim3(slot_grid), dim3(tb), 0, s, qi->cand.p, n_slots, d_page_query, d_counts);
+    results_to_host = results_to_host && counted;
+    if (!counted) hipLaunchKernelGGL(and_count_kernel, dim3(slot_grid), dim3(tb), 0, s, qi->cand.p, n_slots, d_page_query, d_counts);
     HIP_TRY(hipGetLastError());
     // ---- and_query<true> (queries.hpp:72-76): the freq of every term at every match. Lazily, like the reference's
     // freq(): a freqs part is decoded only for the blocks that hold a match — term by term, the blocks the
@@ -1333,7 +1483,7 @@ static int and_queries_impl(dint_query_index* qi, const dint_dict* freqs_dict, c
         HIP_TRY(hipMemcpyAsync(h_sums.data(), qi->freq_sums.p, n_queries * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     }
     unsigned long long* const h_counts = static_cast<unsigned long long*>(qi->h_stage);  // (the inputs have long been copied)
-    HIP_TRY(hipMemcpyAsync(h_counts, d_counts, n_queries * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    if (!results_to_host) HIP_TRY(hipMemcpyAsync(h_counts, d_counts, n_queries * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     qi->claims_dirty = false;
     for (size_t q = 0; q != n_queries; ++q)

@@ -1748,6 +1748,33 @@ __device__ __forceinline__ void decode_unit_multi(const decode_args& a, const wa
     if (a.end_off && lane == 0) a.end_off[unit_index] = pos;
 }
 
+}  // namespace dint_dev
+#include "dint_query_kernels.hpp"  // round_tail: what a query round does behind its decode
+namespace dint_dev {
+
+// The pages of a query round (dint_query_kernels.hpp): page i = block ids[i] of the index's block table, decoded to
+// docIDs at out[256 i ..). The query kernels below take their work from this instead of a unit table.
+struct query_pages {
+    const dint_block_ref* blocks;  // the index's block table
+    const uint32_t* ids;           // page -> block
+    const uint32_t* count;         // nullable: the pages in use (the device knows; the launch is sized for `bound`)
+    uint64_t bound;
+    uint32_t retire;               // candidate pages: the slots past a page's last posting are marked dead
+    // candidate pages, term_blocks set: the first round's block-max search rides along (and_search_kernel's job, same
+    // arguments) — the wave that decoded a page searches for its 256 candidates
+    const uint32_t* page_query;
+    const uint32_t* term_first;
+    const uint32_t* term_blocks;
+    const uint32_t* block_max;
+    uint32_t* target;
+    uint32_t* needed;
+    uint32_t* rank;
+    uint32_t* touched;
+    uint32_t* n_touched;
+};
+template <bool MULTI>
+__device__ __forceinline__ void decode_query_page(const decode_args& a, const wave_ctx& c, const query_pages& qp, uint64_t page, prof_t& pf);
+
 // Units are handed out dynamically: their cost varies a lot (a sparse list full
 // of exceptions takes several times longer than a dense one of the same length),
 // so a static unit -> wave map leaves most of the chip idle behind the slowest
@@ -1771,8 +1798,9 @@ __device__ __forceinline__ decode_args own_scalars(const decode_args& k) {
 // INDEX: an in-index launch (256-posting blocks: docIDs formed in the expansion, freqs + 1, full blocks only). The
 // vroom kernels are compiled without any of that: the per-group branches of the expansion, and the masks the compiler
 // puts on every gathered integer because the docID arithmetic might read it, are gone from their loops.
-template <bool MULTI, bool INDEX>
-__device__ __forceinline__ void decode_kernel_body(const decode_args& kernarg) {
+template <bool MULTI, bool INDEX, bool QUERY = false>
+__device__ __forceinline__ void decode_kernel_body(const decode_args& kernarg, const query_pages* qp = nullptr,
+                                                   const round_tail* tail = nullptr) {
     decode_args a_ = own_scalars(kernarg);
     if (!INDEX) {
         a_.unit_base = nullptr;
@@ -1818,7 +1846,12 @@ __device__ __forceinline__ void decode_kernel_body(const decode_args& kernarg) {
     // are not equal work.
     const uint32_t shard = blockIdx.x % a.n_shards;  // n_shards = min(kQueueShards, gridDim.x)
     // with a schedule the queue hands out the units that are decoded on their own; the bundles follow
-    const uint64_t n_work = a.sched ? uint64_t(uniform(*a.n_items)) : a.n_units;
+    uint64_t n_work_ = a.sched ? uint64_t(uniform(*a.n_items)) : a.n_units;
+    if (QUERY) {
+        n_work_ = qp->bound;
+        if (qp->count) n_work_ = uniform(*qp->count) < n_work_ ? uniform(*qp->count) : n_work_;
+    }
+    const uint64_t n_work = n_work_;
     const uint64_t per_shard = (n_work + a.n_shards - 1) / a.n_shards;
     uint32_t cur = shard, tried = 0;
     // A draw is two steps: the ticket (one returning atomic on the shard's counter) is asked for while the
@@ -1856,8 +1889,10 @@ __device__ __forceinline__ void decode_kernel_body(const decode_args& kernarg) {
     while (w != ~0ull) {
         SECTION(pf, 14, "draw");
         uint32_t ticket = ask();
-        const uint64_t uu = uniform64(a.sched ? uint64_t(a.items[w]) : w);
-        if (MULTI) {
+        const uint64_t uu = uniform64(!QUERY && a.sched ? uint64_t(a.items[w]) : w);
+        if (QUERY) {
+            decode_query_page<MULTI>(a, c, *qp, uu, pf);
+        } else if (MULTI) {
             decode_unit_multi(a, c, uu, pf);
         } else {
             const uint32_t cc = uniform(a.sched ? uint32_t(a.item_cnt[w]) : 1u);
@@ -1867,7 +1902,7 @@ __device__ __forceinline__ void decode_kernel_body(const decode_args& kernarg) {
         asm volatile("" : "+v"(ticket));
         w = take(ticket);
     }
-    if (MULTI && a.sched) {
+    if (MULTI && !QUERY && a.sched) {
         uint32_t chunk_tk = chunk_ticket(a, lane);
         (void)decode_bundle_chunks<true>(a, c, pf, chunk_tk, ~0u);
     }
@@ -1876,6 +1911,22 @@ __device__ __forceinline__ void decode_kernel_body(const decode_args& kernarg) {
 #endif
     if (blockIdx.x == 0 && threadIdx.x == 0)
         *reinterpret_cast<uint64_t*>(a.chunk_queue + kClockWordAt) = __builtin_amdgcn_s_memtime() - clock0;
+    if (QUERY) {
+        if (!tail->done) return;  // (uniform)
+        // the rest of the round: by the workgroup that finishes last, with every page of the launch in memory
+        // (a launch of ONE workgroup — a round of up to 16 pages, the common case of a single query — needs the
+        // barrier and nothing else; an agent-scope fence writes back and invalidates this XCD's L2, microseconds each)
+        __shared__ uint32_t last;
+        if (gridDim.x != 1) __threadfence();  // (every wave: its pages' stores)
+        __syncthreads();
+        if (gridDim.x != 1) {
+            if (threadIdx.x == 0) last = atomicAdd(tail->done, 1u) == gridDim.x - 1 ? 1u : 0u;
+            __syncthreads();
+            if (!last) return;
+            __threadfence();
+        }
+        and_round_tail(*tail);
+    }
 }
 
 #ifndef DINT_MIN_WAVES
@@ -2189,6 +2240,124 @@ __global__ __launch_bounds__(64) void fix_pages_kernel(const uint8_t* index, uin
             for (uint32_t i = lane; i < 256; i += 64)
                 if (i >= n) docids[at + i] = 0xFFFFFFFFu;
     }
+}
+
+// ---- a query's pages in ONE launch ----------------------------------------------------------------
+// What prepare_pages_kernel + the decode kernel + fix_pages_kernel do in three launches, for the small rounds
+// (a single query, a handful of pages) where the launches themselves are what the caller waits for: the wave that
+// draws page i looks its block up itself, decodes a full block through the DINT front end and expansion (docIDs
+// formed there), sums a block the expansion had to leave as gaps on the spot, and runs the interpolative code of
+// a short block in its first lane (there is at most one short block per list).
+template <bool MULTI>
+__device__ __forceinline__ void decode_query_page(const decode_args& a, const wave_ctx& c, const query_pages& qp, uint64_t page, prof_t& pf) {
+    const uint32_t lane = c.lane;
+    const dint_block_ref* const r = qp.blocks + uniform(qp.ids[page]);
+    const uint32_t n = uniform(r->n);
+    const uint64_t at = page * 256;
+    if (n == 0 || n > 256 || at + 256 > a.out_capacity) return;
+    uint32_t* const out = a.out + at;
+    const uint64_t in_off = uniform64(r->in_off);
+    if (n == 256) {
+        volatile uint8_t* const flag = a.gaps_left + page;  // written and read by this wave's first lane only
+        if (lane == 0) *flag = 0;
+        chain_io ch{};
+        if (!MULTI) {
+            decode_segment<16, kRounds, kGroups, 0>(a, c, a.dict.first, in_off, 256, out, ch, pf, false, false, &r->base,
+                                                    a.gaps_left + page);
+        } else {
+            const uint64_t sp = in_off < a.enc_bytes ? in_off : a.enc_bytes - 1;
+            const uint32_t sel = uniform(a.enc[sp]);
+            const bool narrow = sel >= 6;
+            const uint32_t d = (narrow ? sel - 6 : sel) % 6;
+            dict_desc dd;
+            dd.meta_base = uniform(c.descs[4 * d]);
+            dd.hot_base = uniform(c.descs[4 * d + 1]);
+            dd.hot_k = uniform(c.descs[4 * d + 2]);
+            dd.pad = 0;
+            decode_segment<0, 1, 1, -1>(a, c, dd, in_off + 1, 256, out, ch, pf, narrow, false, &r->base, a.gaps_left + page);
+        }
+        uint32_t left = 0;
+        if (lane == 0) left = *flag;
+        if (uniform(left) != 0) {
+            // gaps -> docIDs (docid_i = base + sum_{j<=i} gap_j + i, dict_posting_list.hpp:111-124), behind the block's stores
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+            uint32_t g[4], local = 0;
+#pragma unroll
+            for (uint32_t k = 0; k != 4; ++k) {
+                g[k] = __hip_atomic_load(out + 4 * lane + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+                local += g[k];
+            }
+            uint32_t run = uniform(r->base) + wave_inclusive_sum(local) - local - 1;
+#pragma unroll
+            for (uint32_t k = 0; k != 4; ++k) {
+                run += g[k];
+                out[4 * lane + k] = run;
+            }
+        }
+    } else {
+        // a short block: binary interpolative code (block_codecs.hpp:130-150) — the code IS the prefix sums
+        uint32_t* const o = stage_of(c.scratch);  // (the staging cells are free between two segments)
+        uint32_t* const stack = o + kTailRow;
+        static_assert(kTailRow + kTailStack <= kStageWords, "the interpolative decoder's row and stack live in the staging cells");
+        const uint32_t base = uniform(r->base);
+        if (lane == 0 && in_off < a.enc_bytes)
+            (void)interpolative_prefix_sums(a.enc + in_off, a.enc_bytes - in_off, n, uniform(r->max) - base - (n - 1), o, stack);
+        wave_lds_fence();
+        for (uint32_t i = lane; i < 256; i += kWave) {
+            if (i < n) out[i] = o[i] + base + i;
+            else if (qp.retire) out[i] = 0xFFFFFFFFu;
+        }
+        wave_lds_fence();
+    }
+    if (!qp.term_blocks) return;
+    // ---- the first round's block-max search for this page's candidates (next_geq's skipping, dict_posting_list.hpp:
+    // 126-147; and_search_kernel): lane l takes candidates 4 l .. 4 l + 3, read back behind the page's stores
+    constexpr uint32_t kDead = 0xFFFFFFFFu;
+    const uint32_t q = uniform(qp.page_query[page]);
+    const uint32_t nb = uniform(qp.term_blocks[q]);
+    if (nb == 0) return;  // the query has one term only: its candidates pass
+    const uint32_t fb = uniform(qp.term_first[q]);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    uint32_t gb[4];
+#pragma unroll
+    for (uint32_t k = 0; k != 4; ++k) {
+        const uint32_t i = 4 * lane + k;
+        const uint32_t cand = __hip_atomic_load(out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gb[k] = kDead;
+        if (cand != kDead) {
+            uint32_t lo = 0, len = nb;
+            while (len) {  // first block of the list whose maximum is >= the candidate
+                const uint32_t half = len >> 1;
+                const bool right = qp.block_max[fb + lo + half] < cand;
+                lo = right ? lo + half + 1 : lo;
+                len = right ? len - half - 1 : half;
+            }
+            if (lo == nb) {
+                out[i] = kDead;  // past the list's last block
+            } else {
+                gb[k] = fb + lo;
+                qp.target[at + i] = gb[k];
+            }
+        }
+    }
+    // candidates are sorted, neighbours mostly fall into the same block: one claim per run
+    const uint32_t before = __shfl_up(gb[3], 1);
+#pragma unroll
+    for (uint32_t k = 0; k != 4; ++k) {
+        const bool lead = gb[k] != kDead && (k == 0 ? (lane == 0 || before != gb[0]) : gb[k - 1] != gb[k]);
+        if (lead && atomicExch(&qp.needed[gb[k]], 1u) == 0u) {
+            const uint32_t kk = atomicAdd(qp.n_touched, 1u);
+            qp.touched[kk] = gb[k];
+            qp.rank[gb[k]] = kk;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlockThreads, DINT_MIN_WAVES) void decode_single_query_kernel(decode_args a, query_pages qp, round_tail t) {
+    decode_kernel_body<false, true, true>(a, &qp, &t);
+}
+__global__ __launch_bounds__(kBlockThreads, DINT_MIN_WAVES) void decode_multi_query_kernel(decode_args a, query_pages qp, round_tail t) {
+    decode_kernel_body<true, true, true>(a, &qp, &t);
 }
 
 // test hook: out[i] = inclusive prefix sum of in[0..i] over one wave

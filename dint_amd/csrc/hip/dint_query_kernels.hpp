@@ -78,6 +78,88 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* a, uint32_t 
     return lo;
 }
 
+// A whole round behind its decode, in the decode's own launch (few candidates — a single query: a launch less is a
+// tenth of what the caller waits): the workgroup of decode_*_query_kernel that finishes last probes every candidate in
+// the pages just decoded (and_probe_release_kernel), and either searches the NEXT round's list for the survivors
+// (and_search_kernel) or, behind the last round, counts them and hands the results to the host. Two rounds' claim
+// flags / ranks / touched lists are live at once here — this round's are read and released while the next round's
+// are written; a list may be one query's term in this round and another's in the next — so rounds alternate
+// between two sets of them.
+struct round_tail {
+    uint32_t* done;  // null: no tail. Zero at launch: the workgroups that have finished
+    uint32_t* cand;
+    uint64_t n_slots;
+    const uint32_t* page_query;
+    const dint_block_ref* blocks;
+    uint32_t* target;
+    // this round
+    const uint32_t* term_blocks;
+    const uint32_t* rank;
+    const uint32_t* probe;
+    const uint32_t* touched;
+    const uint32_t* n_touched;
+    uint32_t* needed;
+    // the next round (next_blocks null: this was the last one)
+    const uint32_t* next_first;
+    const uint32_t* next_blocks;
+    const uint32_t* block_max;
+    uint32_t* next_needed;
+    uint32_t* next_rank;
+    uint32_t* next_touched;
+    uint32_t* next_n_touched;
+    // the last round
+    unsigned long long* counts;
+    unsigned long long* host_counts;  // nullable (pinned host memory, as the device sees it)
+    uint32_t n_queries;
+};
+
+// (every thread of one workgroup; n_slots is a multiple of 256, so wavefronts stay whole inside the loop)
+__device__ __forceinline__ void and_round_tail(const round_tail& t) {
+    const uint32_t nt = *t.n_touched;
+    for (uint32_t k = threadIdx.x; k < nt; k += blockDim.x) t.needed[t.touched[k]] = 0;
+    for (uint64_t i = threadIdx.x; i < t.n_slots; i += blockDim.x) {
+        uint32_t gb = kDeadCandidate;
+        const uint32_t c = t.cand[i];
+        if (c != kDeadCandidate) {
+            const uint32_t q = t.page_query[i / kPageSlots];
+            bool alive = true;
+            if (t.term_blocks[q] != 0) {
+                const uint32_t b = t.target[i];
+                const uint32_t n = t.blocks[b].n;
+                const uint32_t* page = t.probe + uint64_t(t.rank[b]) * kPageSlots;
+                const uint32_t pos = lower_bound_u32(page, n, c);
+                alive = pos != n && page[pos] == c;
+            }
+            if (alive && t.next_blocks) {
+                const uint32_t nb = t.next_blocks[q];
+                if (nb) {
+                    const uint32_t fb = t.next_first[q];
+                    const uint32_t pos = lower_bound_u32(t.block_max + fb, nb, c);
+                    if (pos == nb) {
+                        alive = false;
+                    } else {
+                        gb = fb + pos;
+                        t.target[i] = gb;
+                    }
+                }
+            }
+            if (!alive) t.cand[i] = kDeadCandidate;
+            else if (!t.next_blocks) atomicAdd(&t.counts[q], 1ull);
+        }
+        const uint32_t prev = __shfl_up(gb, 1);
+        const bool lead = gb != kDeadCandidate && ((threadIdx.x & 63u) == 0 || prev != gb);
+        if (lead && atomicExch(&t.next_needed[gb], 1u) == 0u) {
+            const uint32_t k = atomicAdd(t.next_n_touched, 1u);
+            t.next_touched[k] = gb;
+            t.next_rank[gb] = k;
+        }
+    }
+    if (t.next_blocks || !t.host_counts) return;
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < t.n_queries; q += blockDim.x)
+        t.host_counts[q] = __hip_atomic_load(&t.counts[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Round step A: block-max search. term_first/term_blocks give, per query, the block range of
 // this round's list (term_blocks == 0: the query has no such term and its candidates pass).
 // Touched blocks are appended once to `touched`, and rank[block] is their position there.
@@ -115,20 +197,50 @@ __global__ void and_search_kernel(uint32_t* cand, uint64_t n_slots, const uint32
 }
 
 // Round steps B and C in one launch: each live candidate looks itself up in its (now decoded) block, and — thread k, for the k-th touched block — the claim flag cleared for
-// the next round (the probe reads target / rank, not the flags).
+// the next round (the probe reads target / rank, not the flags). `counts` (the last round): the survivors of the
+// workgroup's page — one query's — are added to the query's result on the spot (and_count_kernel's job);
+// `host_counts`: ... and the results written to the host's (pinned) memory by the last workgroup to finish.
 __global__ void and_probe_release_kernel(uint32_t* cand, uint64_t n_slots, const uint32_t* page_query, const uint32_t* term_blocks,
                                          const dint_block_ref* blocks, const uint32_t* target, const uint32_t* rank,
-                                         const uint32_t* probe, const uint32_t* touched, const uint32_t* n_touched, uint32_t* needed) {
+                                         const uint32_t* probe, const uint32_t* touched, const uint32_t* n_touched, uint32_t* needed,
+                                         unsigned long long* counts, uint32_t* done, unsigned long long* host_counts, uint32_t n_queries) {
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i < *n_touched) needed[touched[i]] = 0;
-    if (i >= n_slots) return;
-    const uint32_t c = cand[i];
-    if (c == kDeadCandidate || term_blocks[page_query[i / kPageSlots]] == 0) return;
-    const uint32_t gb = target[i];
-    const uint32_t n = blocks[gb].n;
-    const uint32_t* page = probe + uint64_t(rank[gb]) * kPageSlots;
-    const uint32_t pos = lower_bound_u32(page, n, c);
-    if (pos == n || page[pos] != c) cand[i] = kDeadCandidate;
+    bool alive = false;
+    if (i < n_slots) {
+        const uint32_t c = cand[i];
+        if (c != kDeadCandidate) {
+            alive = true;
+            if (term_blocks[page_query[i / kPageSlots]] != 0) {
+                const uint32_t gb = target[i];
+                const uint32_t n = blocks[gb].n;
+                const uint32_t* page = probe + uint64_t(rank[gb]) * kPageSlots;
+                const uint32_t pos = lower_bound_u32(page, n, c);
+                if (pos == n || page[pos] != c) {
+                    cand[i] = kDeadCandidate;
+                    alive = false;
+                }
+            }
+        }
+    }
+    if (!counts) return;  // (uniform)
+    const int n = __syncthreads_count(alive);
+    if (threadIdx.x == 0 && n) atomicAdd(&counts[page_query[i / kPageSlots]], (unsigned long long)n);
+    if (!host_counts) return;  // (uniform)
+    // ... and the workgroup that finishes last hands the results to the host (pinned memory, written from here: no
+    // copy back, one stream operation less for the caller to wait for)
+    __shared__ uint32_t last;
+    if (gridDim.x != 1) {  // (one workgroup: nobody to wait for, and no fence — an agent-scope fence costs microseconds here)
+        if (threadIdx.x == 0) {
+            __threadfence();
+            last = atomicAdd(done, 1u) == gridDim.x - 1 ? 1u : 0u;
+        }
+        __syncthreads();
+        if (!last) return;
+        __threadfence();
+    }
+    for (uint32_t q = threadIdx.x; q < n_queries; q += blockDim.x)
+        host_counts[q] = __hip_atomic_load(&counts[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // and_query<true>, step A per term: the block each match (surviving candidate) falls into — for the rarest term

@@ -26,7 +26,13 @@ def main():
     ap.add_argument("--type", default="single_packed_dint")
     ap.add_argument("--runs", type=int, default=3)
     ap.add_argument("--cpu-queries", type=int, default=500)
+    ap.add_argument("--forms", action="store_true", help="also time the single-query calls with each launch form forced")
     args = ap.parse_args()
+    args.forms = [("three_launches_per_decode", {"DINT_QUERY_LEAN_PAGES": "0"}),
+                  ("one_launch_per_decode", {"DINT_QUERY_TAIL_PAGES": "0"}),
+                  ("round_tail_up_to_4_pages", {"DINT_QUERY_TAIL_PAGES": "4"}),
+                  ("round_tail_up_to_16_pages", {"DINT_QUERY_TAIL_PAGES": "16"}),
+                  ("round_tail_up_to_64_pages", {"DINT_QUERY_TAIL_PAGES": "64"})] if args.forms else []
 
     import torch
     from dint_amd import device, host
@@ -53,6 +59,7 @@ def main():
            "index_bytes": int(idx.size)}
     for name, qs in workloads.items():
         counts = qi.and_queries(qs)  # warm-up (and the first, untimed pass)
+        pages = [min(-(-int(coll.lens[t]) // 256) for t in q) for q in qs if len(q)]
         t_batch = []
         for _ in range(args.runs):
             torch.cuda.synchronize()
@@ -68,13 +75,24 @@ def main():
         stream = torch.cuda.current_stream().cuda_stream
         for t, o, c in packed:
             qi.and_queries_packed(t, o, c, stream)
-        single = []
-        for (t, o, c), want in zip(packed, counts):
-            t0 = time.perf_counter()
-            qi.and_queries_packed(t, o, c, stream)
-            single.append((time.perf_counter() - t0) * 1e6)
-            assert int(c[0]) == int(want)
-        single = np.sort(np.array(single))
+        def singles():
+            us = []
+            for (t, o, c), want in zip(packed, counts):
+                t0 = time.perf_counter()
+                qi.and_queries_packed(t, o, c, stream)
+                us.append((time.perf_counter() - t0) * 1e6)
+                assert int(c[0]) == int(want)
+            return np.sort(np.array(us))
+        single = singles()
+        # the same calls with the launch forms forced (dint_hip.hip: lean_pages, tail_pages) — in this process, on
+        # this box: boxes differ by more than the forms do
+        forms = {}
+        for form, env in args.forms:
+            os.environ.update(env)
+            singles()
+            forms[form] = float(singles().mean())
+            for k in env:
+                del os.environ[k]
         cpu_q = qs[:args.cpu_queries]
         cpu = []
         for q in cpu_q:
@@ -89,6 +107,8 @@ def main():
             "queries": len(qs), "results": int(counts.sum()),
             "gpu_batch_us_per_query": min(t_batch) * 1e6 / len(qs),
             "gpu_single": {"avg": float(single.mean()), "q50": pct(single, 50), "q90": pct(single, 90), "q95": pct(single, 95)},
+            "gpu_single_avg_by_form": forms,
+            "candidate_pages_q50_q90": [float(np.percentile(pages, 50)), float(np.percentile(pages, 90))],
             "cpu_oracle": {"avg": float(cpu.mean()), "q50": pct(cpu, 50), "q90": pct(cpu, 90), "q95": pct(cpu, 95), "cores": 1},
         }
     print(json.dumps(out))

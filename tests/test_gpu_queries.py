@@ -95,6 +95,57 @@ def test_disjoint_and_identical_lists(device):
     assert list(got) == [0, 0, 0, len(ev), 0, len(a), 1500, 2000]
 
 
+@pytest.mark.parametrize("lean_pages", ["0", "1000000000"])
+@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
+def test_both_page_decode_forms(device, small_corpus, monkeypatch, kind, lean_pages):
+    """A round's pages are decoded by one launch (few pages: decode_*_query_kernel) or by three (prepare, the
+    scheduled decode kernel, fix-up); DINT_QUERY_LEAN_PAGES moves the switch — both forms, forced, on batches
+    and on single queries."""
+    monkeypatch.setenv("DINT_QUERY_LEAN_PAGES", lean_pages)
+    ix = get_index(small_corpus, kind)
+    qi = _query_index(device, ix, kind)
+    qs = reference_queries(len(ix.lens))[:300] + heavy_queries(ix.lens, 100, seed=5)
+    want = np.array([intersect(ix.docids, ix.bounds, q) for q in qs], dtype=np.uint64)
+    assert np.array_equal(qi.and_queries(qs), want)
+    for q, w in list(zip(qs, want))[::9]:
+        assert int(qi.and_queries([q])[0]) == int(w)
+    qi.close()
+
+
+@pytest.mark.parametrize("lean_pages", ["0", "1000000000"])
+@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
+def test_blocks_left_as_gaps(device, monkeypatch, kind, lean_pages):
+    """Blocks the expansion cannot turn into docIDs on the fly — a dictionary entry holding a value >= 65536 (a
+    constant stride of 70000: the dictionary learns runs of 69999), or more than 256 slots in the block (every gap
+    an exception) — are summed afterwards, by the decoding wave or by the fix-up launch."""
+    monkeypatch.setenv("DINT_QUERY_LEAN_PAGES", lean_pages)
+    r = np.random.default_rng(77)
+    stride = (np.arange(700, dtype=np.uint64) * 70000).astype(np.uint32)
+    wild = np.cumsum(r.integers(100000, 3000000, 700, dtype=np.uint64)).astype(np.uint32)
+    both = np.union1d(stride, wild).astype(np.uint32)
+    dense = np.arange(0, 2_000_000, 7, dtype=np.uint32)
+    lists = [stride, wild, both, dense]
+    docids = np.concatenate(lists)
+    lens = np.array([len(x) for x in lists], dtype=np.uint32)
+    bounds = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    gaps = np.concatenate([host.docids_to_gaps(x) for x in lists])
+    coll = host.Collection(gaps, lens)
+    freqs = np.ones(docids.size, dtype=np.uint32)
+    dd = host.build_dictionary(kind, coll)
+    fd = host.build_dictionary(kind, host.Collection(freqs - 1, lens))
+    idx, offs = host.build_index(kind, dd, fd, docids, freqs, lens)
+    qi = device.QueryIndex(device.Dictionary(kind, dd), idx, offs)
+    qs = [[0, 2], [1, 2], [0, 1], [0, 3], [1, 3], [2, 3], [0, 1, 2], [3, 2, 1]]
+    want = [intersect(docids, bounds, q) for q in qs]
+    assert want[0] == len(stride) and want[1] == len(wild)
+    assert list(qi.and_queries(qs)) == want
+    for q, w in zip(qs, want):
+        assert int(qi.and_queries([q])[0]) == w
+    od = oracle.OracleDict(kind, dd)
+    assert oracle.and_query(od, idx, offs, int(docids.max()) + 1, [0, 2]) == want[0]
+    qi.close()
+
+
 @pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.RECTANGULAR, host.MULTI_PACKED])
 @pytest.mark.parametrize("corpus_name", ["small_corpus", "dense_corpus"])
 def test_with_freqs_matches_oracle(device, request, kind, corpus_name):
