@@ -1816,8 +1816,25 @@ __device__ __forceinline__ void decode_kernel_body(const decode_args& kernarg, c
     // the dictionary's hot part, 16 bytes a thread and step (hot_words is a multiple of 4): five steps instead of
     // eighteen dependent round trips — nothing for a launch that decodes 10^9 integers, a third of one that decodes a
     // query's handful of pages
-    for (uint32_t i = threadIdx.x; 4 * i < a.dict.hot_words; i += kBlockThreads)
-        reinterpret_cast<u32x4*>(lds)[i] = reinterpret_cast<const u32x4*>(a.dict.lds_image)[i];
+    // (the query kernels: all of a thread's loads in flight before the first lands in LDS — a launch of one
+    // workgroup, a query's round, waits for this copy: one round trip instead of five)
+    if (!QUERY) {
+        for (uint32_t i = threadIdx.x; 4 * i < a.dict.hot_words; i += kBlockThreads)
+            reinterpret_cast<u32x4*>(lds)[i] = reinterpret_cast<const u32x4*>(a.dict.lds_image)[i];
+    } else {
+        constexpr uint32_t kSteps = (kHotImageWords / 4 + kBlockThreads - 1) / kBlockThreads;
+        u32x4 part[kSteps];
+#pragma unroll
+        for (uint32_t k = 0; k != kSteps; ++k) {
+            const uint32_t i = threadIdx.x + k * kBlockThreads;
+            if (4 * i < a.dict.hot_words) part[k] = reinterpret_cast<const u32x4*>(a.dict.lds_image)[i];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k != kSteps; ++k) {
+            const uint32_t i = threadIdx.x + k * kBlockThreads;
+            if (4 * i < a.dict.hot_words) reinterpret_cast<u32x4*>(lds)[i] = part[k];
+        }
+    }
     uint16_t* const cls = reinterpret_cast<uint16_t*>(lds + a.dict.hot_words);
     build_class_table(cls);
     uint32_t* const descs = lds + a.dict.hot_words + kDescWordAt;

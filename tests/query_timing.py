@@ -66,6 +66,19 @@ def main():
             t0 = time.perf_counter()
             qi.and_queries(qs)
             t_batch.append(time.perf_counter() - t0)
+        batch_forms = {}
+        for form, env in ([("three_launches_per_decode", {"DINT_QUERY_LEAN_PAGES": "0"}),
+                           ("one_launch_per_decode", {"DINT_QUERY_LEAN_PAGES": "1000000000"})] if args.forms else []):
+            os.environ.update(env)
+            qi.and_queries(qs)
+            ts = []
+            for _ in range(args.runs):
+                t0 = time.perf_counter()
+                qi.and_queries(qs)
+                ts.append(time.perf_counter() - t0)
+            batch_forms[form] = min(ts) * 1e6 / len(qs)
+            for k in env:
+                del os.environ[k]
         # one query per call, the reference's op_perftest shape: the queries are parsed (packed) beforehand, the
         # timed region is the call
         packed = []
@@ -108,6 +121,7 @@ def main():
             "gpu_batch_us_per_query": min(t_batch) * 1e6 / len(qs),
             "gpu_single": {"avg": float(single.mean()), "q50": pct(single, 50), "q90": pct(single, 90), "q95": pct(single, 95)},
             "gpu_single_avg_by_form": forms,
+            "gpu_batch_us_per_query_by_form": batch_forms,
             "candidate_pages_q50_q90": [float(np.percentile(pages, 50)), float(np.percentile(pages, 90))],
             "cpu_oracle": {"avg": float(cpu.mean()), "q50": pct(cpu, 50), "q90": pct(cpu, 90), "q95": pct(cpu, 95), "cores": 1},
         }
