@@ -171,6 +171,7 @@ struct __attribute__((packed, aligned(1))) u32_a1 {
     uint32_t v;
 };
 typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
 __device__ __forceinline__ uint32_t lane_id() {
     return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -2259,6 +2260,89 @@ __global__ __launch_bounds__(64) void fix_pages_kernel(const uint8_t* index, uin
     }
 }
 
+// One short block by a whole wavefront (the query kernels: ONE short block to a wave, and the launch waits for it).
+// The code is serial — where a value's bits start depends on every value before it — but the ORDER the reference's
+// recursion visits the positions in (node, left subtree, right subtree, interpolative_coding.hpp:128-146) depends on
+// n alone, and so do the two neighbours whose values bound each node (low = the value at a - 1 or 0, high = the
+// value at b). So: the lanes lay the traversal out in parallel (rank of every position by a walk down the implicit
+// tree) and copy the block's bytes into LDS, and what is left of the serial loop is branch-free: two LDS reads for the
+// bounds, a bit reader that always holds 32 valid bits (the next word is read one node ahead), one LDS write — no
+// stack, no trip to memory, no branch per node. Every lane runs the loop on the same values (nothing crosses lanes).
+// tmp: 3 x 256 + 2 words of LDS.   -> component k of lane l = prefix sum l + 64 k (n <= 255).
+// (A version with the values in registers across the lanes, read by v_readlane, was no faster than the one-lane
+// decoder with its LDS stack: picking one of four registers by a scalar index compiles to a ladder of branches.)
+// (not inlined: next to decode_segment its live registers cost the page decode sixteen spills)
+__device__ __attribute__((noinline)) u32x4 interpolative_block_wave(const uint8_t* p, uint64_t limit, uint32_t n, uint32_t sum, uint32_t lane,
+                                                                    lds_u32* tmp) {
+    lds_u32* const ord = tmp;            // [256]: the traversal, entry = position | (a + 1) << 8 | (b + 1) << 16
+    lds_u32* const win = tmp + 256;      // [256 + 1]: the block's first 1024 bytes (254 values of at most 32 bits)
+    lds_u32* const o = tmp + 256 + 257;  // [1 + 256]: o[0] = 0 (the lower bound of the leftmost nodes), o[1 + i] = prefix sum i
+#pragma unroll
+    for (uint32_t k = 0; k != 4; ++k) {
+        const uint64_t byte = 4ull * (lane + 64 * k);
+        uint32_t w = 0;
+        if (byte + 4 <= limit) {
+            w = reinterpret_cast<const u32_a1*>(p + byte)->v;
+        } else {
+            for (uint32_t i = 0; i != 4; ++i)
+                if (byte + i < limit) w |= uint32_t(p[byte + i]) << (8 * i);
+        }
+        win[lane + 64 * k] = w;
+        o[1 + lane + 64 * k] = lane + 64 * k == n - 1 ? sum : 0u;
+        ord[lane + 64 * k] = 0;
+    }
+    if (lane == 0) win[256] = 0, o[0] = 0;
+    wave_lds_fence();
+    // the traversal: position m is visited as number rank(m)
+#pragma unroll
+    for (uint32_t k = 0; k != 4; ++k) {
+        const uint32_t m = lane + 64 * k;
+        if (m + 1 < n) {
+            uint32_t off = 0, cnt = n - 1, rank = 0, a1 = 0, b = n - 1;
+            for (;;) {
+                const uint32_t h = cnt >> 1, mid = off + h;
+                if (m == mid) break;
+                if (m < mid) {  // into the left subtree: behind the node itself; bounded above by the node
+                    rank += 1;
+                    b = mid;
+                    cnt = h;
+                } else {        // into the right subtree: behind the node and its left subtree; bounded below by the node
+                    rank += 1 + h;
+                    a1 = mid + 1;
+                    off = mid + 1;
+                    cnt = cnt - h - 1;
+                }
+            }
+            ord[rank] = m | (a1 << 8) | ((b + 1) << 16);
+        }
+    }
+    wave_lds_fence();
+    uint64_t buf = (uint64_t(win[1]) << 32) | win[0];  // (least significant bit first, tail_bits::read)
+    uint32_t avail = 64, wi = 2;
+    uint32_t next_w = win[2], e = ord[0];
+    for (uint32_t s = 0; s + 1 < n; ++s) {
+        const uint32_t mid = e & 255u, a1 = (e >> 8) & 255u, b1 = (e >> 16) & 511u;
+        e = ord[(s + 1) & 255u];
+        const uint32_t hi = o[b1], lo = o[a1];
+        const uint32_t u = hi - lo + 1;
+        const uint32_t bits = (31u - uint32_t(__builtin_clz(u | 1u))) & 31u;
+        const uint32_t thr = uint32_t((uint64_t(2) << bits) - u);
+        uint32_t v = uint32_t(buf) & ((1u << bits) - 1u);
+        const uint32_t more = v >= thr ? 1u : 0u;  // one more bit: (v << 1) + bit - thr
+        v = more ? (v << 1) + (uint32_t(buf >> bits) & 1u) - thr : v;
+        buf >>= bits + more;
+        avail -= bits + more;
+        const bool refill = avail <= 32;
+        buf |= refill ? uint64_t(next_w) << avail : uint64_t(0);
+        avail += refill ? 32u : 0u;
+        wi += refill ? 1u : 0u;
+        next_w = win[wi < 256 ? wi : 256];
+        o[1 + mid] = lo + v;
+    }
+    wave_lds_fence();
+    return u32x4{o[1 + lane], o[65 + lane], o[129 + lane], o[193 + lane]};
+}
+
 // ---- a query's pages in ONE launch ----------------------------------------------------------------
 // What prepare_pages_kernel + the decode kernel + fix_pages_kernel do in three launches, for the small rounds
 // (a single query, a handful of pages) where the launches themselves are what the caller waits for: the wave that
@@ -2313,18 +2397,18 @@ __device__ __forceinline__ void decode_query_page(const decode_args& a, const wa
         }
     } else {
         // a short block: binary interpolative code (block_codecs.hpp:130-150) — the code IS the prefix sums
-        uint32_t* const o = stage_of(c.scratch);  // (the staging cells are free between two segments)
-        uint32_t* const stack = o + kTailRow;
-        static_assert(kTailRow + kTailStack <= kStageWords, "the interpolative decoder's row and stack live in the staging cells");
+        lds_u32* const tmp = (lds_u32*)stage_of(c.scratch);  // (the staging cells are free between two segments)
+        static_assert(3 * 256 + 2 <= kStageWords, "the interpolative decoder's tables live in the staging cells");
         const uint32_t base = uniform(r->base);
-        if (lane == 0 && in_off < a.enc_bytes)
-            (void)interpolative_prefix_sums(a.enc + in_off, a.enc_bytes - in_off, n, uniform(r->max) - base - (n - 1), o, stack);
-        wave_lds_fence();
-        for (uint32_t i = lane; i < 256; i += kWave) {
-            if (i < n) out[i] = o[i] + base + i;
+        u32x4 ov = {0, 0, 0, 0};
+        if (in_off < a.enc_bytes)
+            ov = interpolative_block_wave(a.enc + in_off, a.enc_bytes - in_off, n, uniform(r->max) - base - (n - 1), lane, tmp);
+#pragma unroll
+        for (uint32_t k = 0; k != 4; ++k) {
+            const uint32_t i = lane + 64 * k;
+            if (i < n) out[i] = ov[k] + base + i;
             else if (qp.retire) out[i] = 0xFFFFFFFFu;
         }
-        wave_lds_fence();
     }
     if (!qp.term_blocks) return;
     // ---- the first round's block-max search for this page's candidates (next_geq's skipping, dict_posting_list.hpp:
@@ -2335,24 +2419,37 @@ __device__ __forceinline__ void decode_query_page(const decode_args& a, const wa
     if (nb == 0) return;  // the query has one term only: its candidates pass
     const uint32_t fb = uniform(qp.term_first[q]);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-    uint32_t gb[4];
+    // (the four searches of a lane step together — four loads in flight per round trip, not four searches one
+    // after the other: the block maxima of a long list are a dozen dependent trips to memory)
+    uint32_t gb[4], cand[4], lo[4], len[4];
+#pragma unroll
+    for (uint32_t k = 0; k != 4; ++k) {
+        cand[k] = __hip_atomic_load(out + 4 * lane + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lo[k] = 0;
+        len[k] = cand[k] != kDead ? nb : 0u;
+    }
+    while ((len[0] | len[1] | len[2] | len[3]) != 0) {  // first block of the list whose maximum is >= the candidate
+        uint32_t bm[4];
+#pragma unroll
+        for (uint32_t k = 0; k != 4; ++k) bm[k] = len[k] ? qp.block_max[fb + lo[k] + (len[k] >> 1)] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k != 4; ++k)
+            if (len[k]) {
+                const uint32_t half = len[k] >> 1;
+                const bool right = bm[k] < cand[k];
+                lo[k] = right ? lo[k] + half + 1 : lo[k];
+                len[k] = right ? len[k] - half - 1 : half;
+            }
+    }
 #pragma unroll
     for (uint32_t k = 0; k != 4; ++k) {
         const uint32_t i = 4 * lane + k;
-        const uint32_t cand = __hip_atomic_load(out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         gb[k] = kDead;
-        if (cand != kDead) {
-            uint32_t lo = 0, len = nb;
-            while (len) {  // first block of the list whose maximum is >= the candidate
-                const uint32_t half = len >> 1;
-                const bool right = qp.block_max[fb + lo + half] < cand;
-                lo = right ? lo + half + 1 : lo;
-                len = right ? len - half - 1 : half;
-            }
-            if (lo == nb) {
+        if (cand[k] != kDead) {
+            if (lo[k] == nb) {
                 out[i] = kDead;  // past the list's last block
             } else {
-                gb[k] = fb + lo;
+                gb[k] = fb + lo[k];
                 qp.target[at + i] = gb[k];
             }
         }
