@@ -213,7 +213,11 @@ void dint_query_index_destroy(dint_query_index* qi);
 /* counts[q] = number of documents that contain every term of query q (duplicate terms count
  * once, queries.hpp:28-31; an empty query counts 0, :38). terms/query_offsets/counts are HOST
  * arrays: query q is terms[query_offsets[q] .. query_offsets[q+1]). A term >= n_lists is
- * DINT_ERR_ARG. The call enqueues on `stream` and returns after synchronising it. */
+ * DINT_ERR_ARG. The call enqueues on `stream` and returns after synchronising it: one copy in, then one launch
+ * per term for a query of a few pages, three per round for a batch. Two environment variables,
+ * read per call, exist for tests and measurements: DINT_QUERY_LEAN_PAGES (page decodes of at least this many
+ * pages take the three-launch form; unset: none does) and DINT_QUERY_TAIL_PAGES (calls of at most this many
+ * candidate pages run a whole round per launch; unset: 4). */
 int dint_and_queries(dint_query_index* qi, const uint32_t* terms, const uint64_t* query_offsets,
                      size_t n_queries, uint64_t* counts, void* stream);
 
