@@ -1338,10 +1338,11 @@ static int and_queries_impl(dint_query_index* qi, const dint_dict* freqs_dict, c
     // A round: block-max search -> the touched blocks, without duplicates -> decoded -> every candidate probes its
     // block. How many blocks a round touches only the device knows; the host knows a bound (the live candidates at
     // most, and no more blocks than the round's lists have) and sizes the launches for that — nothing on the host
-    // waits for a round: a call is one copy in, one clear, five launches per round, one copy back. (Round 1 read the
+    // waits for a round: a call is one copy in, then per round search, page decode, probe. (Round 1 read the
     // count back every round and made fourteen API calls per round: a query at a time, the host's share was most of
     // the 200 us a query took.) Past kAsyncPages the count is read back after all: launches sized for a bound far
-    // above the truth cost more than the wait.
+    // above the truth cost more than the wait (measured again with the one-launch decode at 131072: every workgroup
+    // of a grid sized for the bound loads the dictionary image, 1.41 against 1.34 us per query).
     constexpr size_t kAsyncPages = 32768;
     size_t last_round = rounds;  // the last round that has anything to probe counts the survivors as well
     for (size_t r = 0; r != rounds; ++r)
