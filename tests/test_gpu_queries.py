@@ -112,6 +112,42 @@ def test_both_page_decode_forms(device, small_corpus, monkeypatch, kind, lean_pa
     qi.close()
 
 
+@pytest.mark.parametrize("tail_pages", ["0", "4", "64"])
+@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
+def test_round_tail_over_several_workgroups(device, monkeypatch, kind, tail_pages):
+    """A small call runs a whole round per launch (round_tail): the workgroup of the page decode that finishes last
+    probes and searches. A short rarest list whose postings fall into every block of two long lists makes the
+    rounds' page decodes launches of several workgroups (the fenced hand-over), a rarest list of one short block
+    the launch of one; DINT_QUERY_TAIL_PAGES = 0 is the same call without the tail."""
+    monkeypatch.setenv("DINT_QUERY_TAIL_PAGES", tail_pages)
+    r = np.random.default_rng(5)
+    long_a = np.arange(0, 60000, 3, dtype=np.uint32)                      # 20000 postings, 79 blocks
+    long_b = np.unique(r.integers(0, 60000, 30000)).astype(np.uint32)     # ~ 24000 postings
+    rare = np.arange(0, 60000, 75, dtype=np.uint32)                       # 800 postings: 4 pages, spread over every block
+    tiny = np.arange(30, 60000, 1500, dtype=np.uint32)                    # 40 postings: one short block
+    lists = [long_a, long_b, rare, tiny]
+    docids = np.concatenate(lists)
+    lens = np.array([len(x) for x in lists], dtype=np.uint32)
+    bounds = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    gaps = np.concatenate([host.docids_to_gaps(x) for x in lists])
+    coll = host.Collection(gaps, lens)
+    freqs = np.ones(docids.size, dtype=np.uint32)
+    dd = host.build_dictionary(kind, coll)
+    fd = host.build_dictionary(kind, host.Collection(freqs - 1, lens))
+    idx, offs = host.build_index(kind, dd, fd, docids, freqs, lens)
+    qi = device.QueryIndex(device.Dictionary(kind, dd), idx, offs)
+    qs = [[2, 0], [2, 1], [2, 0, 1], [3, 0, 1], [3, 2], [3, 2, 0, 1], [0, 1]]
+    want = [intersect(docids, bounds, q) for q in qs]
+    assert want[0] == len(rare) and want[2] > 50
+    for q, w in zip(qs, want):
+        assert int(qi.and_queries([q])[0]) == w
+    assert list(qi.and_queries(qs[:2] + [[3, 0]])) == want[:2] + [intersect(docids, bounds, [3, 0])]  # a small batch
+    fdev = device.Dictionary(kind, fd)
+    c, sm, _ = qi.and_queries_with_freqs(fdev, [[2, 0, 1]])
+    assert int(c[0]) == want[2] and int(sm[0]) == 3 * want[2]  # every freq is 1
+    qi.close()
+
+
 @pytest.mark.parametrize("lean_pages", ["0", "1000000000"])
 @pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
 def test_blocks_left_as_gaps(device, monkeypatch, kind, lean_pages):
