@@ -286,6 +286,45 @@ def main():
         if not bit_exact:
             raise SystemExit("FATAL: decoded integers differ from the encoder's input")
 
+    # ---- the box: what plain fill and copy kernels reach on the same output buffer, after the timed region (boxes of
+    # one pool differ by 15 % in the decode kernel's time at equal clocks: this says whether their HBM does too) -----
+    box_probe = None
+    if dev.type == "cuda" and rank == 0:
+        half = (n_ints // 2) & ~1023
+        probe = {}
+        for name, fn, nbytes in (("fill_gbps", lambda: out_dev.zero_(), 4 * n_ints),
+                                 ("copy_gbps", lambda: out_dev[:half].copy_(out_dev[half:2 * half]), 8 * half)):
+            if nbytes == 0:
+                continue
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                fn()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            probe[name] = round(3 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        # ... and random 4-byte gathers from a table that fits one XCD's L2 (2 MB) and from one that only the
+        # memory-side cache holds (64 MB): the decode kernel's cold codewords are such gathers
+        g = torch.Generator(device=dev)
+        g.manual_seed(1)
+        for name, words in (("gather_2mb_gps", 1 << 19), ("gather_64mb_gps", 1 << 24)):
+            table = torch.arange(words, dtype=torch.int32, device=dev)
+            idx = torch.randint(0, words, (1 << 26,), dtype=torch.int64, device=dev, generator=g)
+            torch.take(table, idx)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                torch.take(table, idx)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            probe[name] = round(3 * idx.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+            del table, idx
+        props = torch.cuda.get_device_properties(dev)
+        probe["compute_units"] = int(props.multi_processor_count)
+        probe["device"] = f"{props.name} {getattr(props, 'gcnArchName', '')}".strip()
+        box_probe = probe
+
     if rank == 0:
         # ---- what the stream is made of (host pre-pass over one replica) -------------
         st = d.stream_stats(enc)
@@ -363,6 +402,7 @@ def main():
                                              round(float(kernel_ms.max()), 4)],
                 "kernel_launches_timed": int(kernel_ms.size),
                 "shader_mhz": shader_mhz,
+                "box_probe": box_probe,  # torch's fill / copy over the output buffer: GB/s written, GB/s read + written
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
             "cpu_baseline": cpu,
