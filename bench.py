@@ -61,6 +61,14 @@ def parse_args(argv=None):
                     help="JSON written by tools/pmc_traffic.py from rocprofv3 --pmc passes of THIS command; without it "
                          "roofline.traffic is null (HBM counters cannot be read from inside the run)")
     ap.add_argument("--no-verify", action="store_true", help="skip the full bit-exact output check")
+    ap.add_argument("--as-rank", default=None, metavar="K/W",
+                    help="one process, one GPU, decoding exactly the shard rank K of a W-rank job would get "
+                         "(sharding.partition_lists(lens_all, W)[K] of the W x postings collection): BASELINE config 4's "
+                         "1-of-8 shards on a single-GPU box. The line says `emulated_rank`; it is not a scaling measurement")
+    ap.add_argument("--rank-timeout", type=float, default=3600.0,
+                    help="--gpus N launched from this process: seconds a rank may run before all of them are stopped")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="initialise torch.distributed (RCCL on a GPU) even with one rank, and run the reductions through it")
     return ap.parse_args(argv)
 
 
@@ -71,22 +79,62 @@ def log(rank, *a):
 
 def launch_ranks(args) -> int:
     """`python bench.py --gpus N` on its own: start N fresh processes, one per GPU, and relay rank 0's line.
-    (This process has not touched the GPU; the children are new processes, not a re-exec.)"""
+    (This process has not touched the GPU; the children are new processes, not a re-exec.) When a rank fails or
+    the time runs out, the others are stopped (they would wait in a collective for ever) and the exit code is
+    not zero."""
+    import signal
+    import tempfile
+
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
+    out0 = tempfile.TemporaryFile()
     for rank in range(args.gpus):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0)
+                                      stdout=out0 if rank == 0 else subprocess.DEVNULL, start_new_session=True))
+    deadline = time.monotonic() + args.rank_timeout
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for rank, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = f"rank {rank} exited with code {p.returncode}"
+                break
+        else:
+            if time.monotonic() > deadline:
+                failed = f"no result after {args.rank_timeout:.0f}s"
+            else:
+                time.sleep(0.2)
+    if failed is None:
+        bad = [(r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0]
+        if bad:
+            failed = f"rank {bad[0][0]} exited with code {bad[0][1]}"
+    if failed is not None:
+        for p in procs:  # exactly the process groups started above
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGTERM)
+                except ProcessLookupError:
+                    pass
+        t_kill = time.monotonic() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                p.wait()
+        print(f"[bench] {failed}: all ranks stopped", file=sys.stderr, flush=True)
+        return 1
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
-    return max(abs(c) for c in codes)
+    return 0
 
 
 def cpu_model() -> str:
@@ -99,12 +147,24 @@ def cpu_model() -> str:
     return "unknown"
 
 
+def physical_cores() -> int:
+    """Distinct (socket, core) pairs among the CPUs this process may run on."""
+    try:
+        allowed = os.sched_getaffinity(0)
+        seen = set()
+        for cpu in allowed:
+            base = f"/sys/devices/system/cpu/cpu{cpu}/topology/"
+            with open(base + "physical_package_id") as f, open(base + "core_id") as g:
+                seen.add((f.read().strip(), g.read().strip()))
+        return len(seen) or len(allowed)
+    except OSError:
+        return len(os.sched_getaffinity(0))
+
+
 def cpu_baseline(kind, dict_file, enc, list_byte_starts, seconds):
     """The oracle's restatement of the reference decode, timed on this host: (i) one thread, per-list timing
     summed exactly like vroom_env/decode.cpp:139-150; (ii) every core, the lists statically partitioned by
     stream bytes, wall time. A bounded sample: each leg stops after about `seconds` of decode time."""
-    import threading
-
     import numpy as np
 
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -118,31 +178,18 @@ def cpu_baseline(kind, dict_file, enc, list_byte_starts, seconds):
     one = {"value": round(ints / sec / 1e6, 2), "unit": "M ints/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
            "sample": f"{passes} pass(es) over the same encoded stream, {lists} list decodes ({ints} postings), per-list "
                      f"timing summed as in vroom_env/decode.cpp:139-150, {sec:.1f}s of decode time"}
-    cores = len(os.sched_getaffinity(0))
-    # thread k takes the lists that begin in [k, k + 1) / cores of the stream's bytes (a thread may get none)
-    cut = np.searchsorted(list_byte_starts, [enc.size * k // cores for k in range(1, cores)])
-    bounds = [0] + [int(list_byte_starts[i]) if i < len(list_byte_starts) else enc.size for i in cut] + [enc.size]
-    res = [None] * cores
-
-    def work(k, t0):
-        a, b = bounds[k], bounds[k + 1]
-        n = passes_k = 0
-        while b > a and time.perf_counter() - t0 < seconds:  # whole passes over the thread's range
-            n += od.time_stream(enc[a:b])[1]
-            passes_k += 1
-        res[k] = (n, passes_k)
-
-    t0 = time.perf_counter()
-    th = [threading.Thread(target=work, args=(k, t0)) for k in range(cores)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    wall = time.perf_counter() - t0
-    tot = sum(r[0] for r in res)
-    one["all_cores"] = {"value": round(tot / wall / 1e6, 2), "unit": "M ints/s", "cores": cores,
-                        "sample": f"{cores} threads, contiguous list ranges of equal stream bytes, whole passes until {seconds:.0f}s: "
-                                  f"{tot} postings in {wall:.1f}s wall (first thread start to last thread end)"}
+    threads = len(os.sched_getaffinity(0))
+    phys = physical_cores()
+    # thread k takes the lists that begin in [k, k + 1) / threads of the stream's bytes (a thread may get none): one
+    # pthread each inside liboracle, a persistent decode buffer per thread, all looping until `seconds` have passed
+    cut = np.searchsorted(list_byte_starts, [enc.size * k // threads for k in range(1, threads)])
+    starts = [0] + [int(list_byte_starts[i]) if i < len(list_byte_starts) else enc.size for i in cut]
+    wall, tot, nlists = od.time_stream_parallel(enc, starts, seconds)
+    one["all_cores"] = {"value": round(tot / wall / 1e6, 2), "unit": "M ints/s", "cores": phys, "threads": threads,
+                        "speedup_over_one_core": round(tot / wall / (ints / sec), 1),
+                        "sample": f"{threads} pthreads ({phys} physical cores), contiguous list ranges of equal stream bytes, "
+                                  f"each looping over its range with its own reused buffer for {seconds:.0f}s: {nlists} list "
+                                  f"decodes, {tot} postings in {wall:.2f}s wall (first thread start to last thread end)"}
     return one
 
 
@@ -160,6 +207,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    # the shard this process decodes: its own rank's — or, --as-rank K/W, the one rank K of a W-rank job would get
+    shard_rank, shard_world = rank, world
+    if args.as_rank is not None:
+        if world != 1:
+            raise SystemExit("--as-rank emulates one rank of a larger job in ONE process (--gpus 1)")
+        try:
+            shard_rank, shard_world = (int(x) for x in args.as_rank.split("/"))
+        except ValueError:
+            raise SystemExit("--as-rank wants K/W, e.g. 3/8")
+        if not 0 <= shard_rank < shard_world:
+            raise SystemExit("--as-rank K/W: 0 <= K < W")
 
     import numpy as np
     import torch
@@ -179,11 +237,15 @@ def main():
         backend, dev = "nccl", torch.device("cuda", local_rank)
     from dint_amd import host, sharding
 
-    distributed = world > 1
+    distributed = world > 1 or args.force_process_group
     if distributed:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:  # (one rank on its own, --force-process-group)
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
 
     kind = host.KIND_BY_TYPE[args.type]
@@ -195,15 +257,24 @@ def main():
     # The collection is `world * postings` postings; list lengths are drawn once
     # (same on every rank) and contiguous list ranges balanced by postings are
     # handed to the ranks.
-    lens_all = host.synth_lengths(p, postings * world)
-    lo, hi = sharding.partition_lists(lens_all, world)[rank]
+    lens_all = host.synth_lengths(p, postings * shard_world)
+    lo, hi = sharding.partition_lists(lens_all, shard_world)[shard_rank]
     lens = lens_all[lo:hi]
     gaps = host.synth_gaps(p, lens, first_list_id=lo, threads=threads)
     coll = host.Collection(gaps, lens)
     log(rank, f"rank shard: lists [{lo},{hi}) = {coll.num_postings} postings, generated in {time.time() - t0:.1f}s")
 
     t0 = time.time()
-    if rank == 0:
+    if rank == 0 and shard_rank != 0:
+        # --as-rank K/W, K != 0: the job's dictionary comes from RANK 0's first lists, not from this shard's —
+        # regenerate that prefix sample (the lists build_dictionary would take from rank 0's shard)
+        hi0 = sharding.partition_lists(lens_all, shard_world)[0][1]
+        cum = np.cumsum(lens_all[:hi0], dtype=np.uint64)
+        j = max(1, int(np.searchsorted(cum, int(args.dict_sample), side="right"))) if args.dict_sample else hi0
+        sample = host.Collection(host.synth_gaps(p, lens_all[:j], first_list_id=0, threads=threads), lens_all[:j])
+        dict_file = host.build_dictionary(kind, sample, max_sample_ints=int(args.dict_sample), threads=threads)
+        del sample
+    elif rank == 0:
         # dictionary statistics from a prefix sample of the collection (rank 0's first lists)
         dict_file = host.build_dictionary(kind, coll, max_sample_ints=int(args.dict_sample), threads=threads)
     else:
@@ -372,7 +443,13 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u32",
-            "data": "synthetic",
+            "data": "synthetic" if not stub else "stub",
+            **({"stub": stub, "stub_note": "the device layer was replaced by a test stand-in: nothing was decoded, value and "
+                                           "roofline are not measurements"} if stub else {}),
+            **({"emulated_rank": f"{shard_rank}/{shard_world}",
+                "emulated_note": f"one process on one GPU decoding the shard rank {shard_rank} of a {shard_world}-rank job "
+                                 f"would get (lists [{lo},{hi}) of {len(lens_all)}); not a scaling measurement"}
+               if args.as_rank is not None else {}),
             "bit_exact": bit_exact,
             "config": {
                 "workload": f"{args.type} decode, DSF-65536-16 dictionary (hot set in LDS), {args.workload}-shaped synthetic "
@@ -386,7 +463,8 @@ def main():
                 **stream,
                 "hot_codewords_in_lds": int(info.hot_entries),
                 "lds_bytes": int(info.lds_bytes),
-                "parallelism": f"list-range x{world}",
+                "parallelism": f"list-range x{world}" if args.as_rank is None else f"list-range shard {shard_rank} of {shard_world}",
+                "process_group": (backend if not stub else "gloo") if distributed else None,
             },
             "roofline": {
                 "bound": "hbm",

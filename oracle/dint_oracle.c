@@ -5,6 +5,7 @@
 #define _POSIX_C_SOURCE 200809L
 #include "dint_oracle.h"
 
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -332,6 +333,107 @@ double oracle_time_stream(const oracle_dict* d, const uint8_t* enc, size_t enc_b
     if (ints_decoded) *ints_decoded = ints;
     if (lists_decoded) *lists_decoded = lists;
     return elapsed;
+}
+
+/* The all-cores leg of the CPU baseline: the decode.cpp loop (vroom_env/decode.cpp:139-150: header::read,
+ * then Decoder::decode into ONE reused, zeroed-once buffer) on every thread over its own contiguous range of lists; a
+ * thread's buffer is persistent and as long as its longest list needs. Every thread walks its range again and again
+ * until `seconds` have passed since the common start (looked at every 32 lists), so all of them end together; the
+ * rate is the integers all threads decoded over the wall time from the first thread's start to the last one's end. */
+typedef struct {
+    const oracle_dict* d;
+    const uint8_t* begin;
+    const uint8_t* end;
+    uint32_t* buf;
+    double t_start, seconds, t_first, t_last;
+    uint64_t ints, lists;
+} par_job;
+
+static void* par_worker(void* arg) {
+    par_job* j = (par_job*)arg;
+    j->t_first = now_sec();
+    uint64_t ints = 0, lists = 0;
+    int stop = j->begin == j->end;
+    while (!stop) {
+        const uint8_t* p = j->begin;
+        while (p != j->end) {
+            uint32_t n, universe;
+            p = oracle_header_read(p, &n, &universe);
+            p = oracle_decode_list(j->d, p, j->buf, n);
+            ints += n;
+            if ((++lists & 31u) == 0 && now_sec() - j->t_start >= j->seconds) {
+                stop = 1;
+                break;
+            }
+        }
+        if (now_sec() - j->t_start >= j->seconds) stop = 1;
+    }
+    volatile uint32_t sink = j->buf[0];
+    (void)sink;
+    j->ints = ints;
+    j->lists = lists;
+    j->t_last = now_sec();
+    return NULL;
+}
+
+double oracle_time_stream_parallel(const oracle_dict* d, const uint8_t* enc, size_t enc_bytes, const uint64_t* range_starts,
+                                   uint32_t n_threads, double seconds, uint64_t* ints_decoded, uint64_t* lists_decoded) {
+    if (n_threads == 0) return -1.0;
+    par_job* jobs = (par_job*)calloc(n_threads, sizeof *jobs);
+    pthread_t* th = (pthread_t*)calloc(n_threads, sizeof *th);
+    if (!jobs || !th) {
+        free(jobs);
+        free(th);
+        return -1.0;
+    }
+    double result = -1.0;
+    uint32_t made = 0;
+    uint32_t* scratch = (uint32_t*)calloc((size_t)MAX_LIST + BLOCK + MAX_ENTRY, 4);
+    if (!scratch) goto done;
+    /* set-up, untimed: the ranges and every thread's buffer (sized by a pass over its headers) */
+    for (uint32_t k = 0; k != n_threads; ++k) {
+        const uint64_t a = range_starts[k], b = k + 1 < n_threads ? range_starts[k + 1] : enc_bytes;
+        if (a > b || b > enc_bytes) goto done;
+        jobs[k].d = d;
+        jobs[k].begin = enc + a;
+        jobs[k].end = enc + b;
+        jobs[k].seconds = seconds;
+        uint32_t longest = 0;
+        const uint8_t* p = jobs[k].begin; /* one walk to find the range's longest list (payloads carry no length) */
+        while (p != jobs[k].end) {
+            uint32_t n, universe;
+            p = oracle_header_read(p, &n, &universe);
+            p = oracle_decode_list(d, p, scratch, n);
+            if (n > longest) longest = n;
+        }
+        jobs[k].buf = (uint32_t*)calloc((size_t)longest + BLOCK + MAX_ENTRY, 4);
+        if (!jobs[k].buf) goto done;
+    }
+    {
+        const double t0 = now_sec();
+        for (uint32_t k = 0; k != n_threads; ++k) jobs[k].t_start = t0;
+        for (; made != n_threads; ++made)
+            if (pthread_create(&th[made], NULL, par_worker, &jobs[made]) != 0) break;
+        for (uint32_t k = 0; k != made; ++k) pthread_join(th[k], NULL);
+        if (made != n_threads) goto done;
+        double first = jobs[0].t_first, last = jobs[0].t_last;
+        uint64_t ints = 0, lists = 0;
+        for (uint32_t k = 0; k != n_threads; ++k) {
+            if (jobs[k].t_first < first) first = jobs[k].t_first;
+            if (jobs[k].t_last > last) last = jobs[k].t_last;
+            ints += jobs[k].ints;
+            lists += jobs[k].lists;
+        }
+        if (ints_decoded) *ints_decoded = ints;
+        if (lists_decoded) *lists_decoded = lists;
+        result = last - first;
+    }
+done:
+    free(scratch);
+    for (uint32_t k = 0; k != n_threads; ++k) free(jobs[k].buf);
+    free(jobs);
+    free(th);
+    return result;
 }
 
 /* ---- in-index path --------------------------------------------------------------------- */

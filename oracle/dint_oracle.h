@@ -70,6 +70,13 @@ uint64_t oracle_decode_stream(const oracle_dict* d, const uint8_t* enc, size_t e
 double oracle_time_stream(const oracle_dict* d, const uint8_t* enc, size_t enc_bytes, uint64_t max_lists,
                           double max_seconds, uint64_t* ints_decoded, uint64_t* lists_decoded);
 
+/* The all-cores leg of the same benchmark: thread k runs the decode.cpp loop over the lists whose headers start in
+ * [range_starts[k], range_starts[k + 1]) (the last range ends at enc_bytes; an empty range is allowed), with its own
+ * persistent zeroed-once buffer, again and again until `seconds` have passed. Returns the wall time from the first
+ * thread's start to the last thread's end (buffers and ranges are set up before), or a negative value on failure. */
+double oracle_time_stream_parallel(const oracle_dict* d, const uint8_t* enc, size_t enc_bytes, const uint64_t* range_starts,
+                                   uint32_t n_threads, double seconds, uint64_t* ints_decoded, uint64_t* lists_decoded);
+
 /* ---- in-index path ------------------------------------------------------------------- */
 
 /* interpolative_block::decode (include/ds2i/block_codecs.hpp:130-150): n <= 256 values whose

@@ -51,6 +51,9 @@ def _load():
     lib.oracle_time_stream.restype = C.c_double
     lib.oracle_time_stream.argtypes = [vp, vp, C.c_size_t, C.c_uint64, C.c_double,
                                        C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.oracle_time_stream_parallel.restype = C.c_double
+    lib.oracle_time_stream_parallel.argtypes = [vp, vp, C.c_size_t, vp, C.c_uint32, C.c_double,
+                                                C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     return lib
 
 
@@ -106,6 +109,19 @@ class OracleDict:
         if sec < 0:
             raise MemoryError("oracle: could not allocate the 50M-int decode buffer")
         return sec, ints.value, lists.value
+
+
+    def time_stream_parallel(self, enc: np.ndarray, range_starts, seconds: float):
+        """The all-cores leg: one pthread per range of lists (byte offsets of the ranges' first headers), each with a
+        persistent buffer, looping for `seconds` -> (wall seconds first start to last end, ints, lists)."""
+        enc = np.ascontiguousarray(enc, dtype=np.uint8)
+        starts = np.ascontiguousarray(range_starts, dtype=np.uint64)
+        ints, lists = C.c_uint64(), C.c_uint64()
+        wall = _lib.oracle_time_stream_parallel(self._h, enc.ctypes.data, enc.size, starts.ctypes.data, starts.size,
+                                                seconds, C.byref(ints), C.byref(lists))
+        if wall < 0:
+            raise RuntimeError("oracle: the parallel timing run failed (bad ranges, or out of memory / threads)")
+        return wall, ints.value, lists.value
 
 
 def header_read(enc: np.ndarray, offset: int):

@@ -2,6 +2,8 @@
 multi-process path of bench.py (self-launch, rendezvous, list-range sharding, reductions, the JSON line) run on
 CPU ranks over gloo. It decodes nothing — the product has no CPU decode — so the bench line it produces is
 meaningless as a measurement."""
+import os
+import time
 import types
 
 import numpy as np
@@ -11,6 +13,11 @@ import torch
 class Dictionary:
     def __init__(self, kind, file_bytes, device=0):
         self.kind, self.device = kind, device
+        # (tests of bench.py's launcher: a rank that dies, a rank that never answers)
+        if os.environ.get("BENCH_STUB_FAIL_RANK") == os.environ.get("RANK", "0"):
+            raise RuntimeError("bench_stub: this rank was told to fail")
+        if os.environ.get("BENCH_STUB_HANG_RANK") == os.environ.get("RANK", "0"):
+            time.sleep(3600)
 
     def info(self):
         return types.SimpleNamespace(hot_entries=0, lds_bytes=0)

@@ -130,3 +130,33 @@ def test_readme_shaped_collection_through_the_oracle():
     got, n_lists = oracle.OracleDict(host.RECTANGULAR, dict_file).decode_stream(enc, coll.num_postings)
     assert n_lists == 113_306
     assert np.array_equal(got, coll.gaps)
+
+
+def _list_header_starts(od, enc, lens):
+    """Byte offset of every list's header in a vroom stream: header::read, then Decoder::decode's returned pointer."""
+    starts, off = [], 0
+    for _ in range(int(np.count_nonzero(lens))):
+        starts.append(off)
+        n, _u, pay = oracle.header_read(enc, off)
+        off = pay + od.decode_list(enc, pay, n)[1]
+    assert off == enc.size
+    return np.asarray(starts, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
+def test_all_cores_leg_counts_whole_lists_of_every_range(small_corpus, kind):
+    """bench.py's cpu_baseline.all_cores: pthreads inside liboracle over contiguous list ranges, each with its own
+    persistent buffer; the integers counted are those of the lists decoded (a multiple of nothing in particular, but
+    never fewer than one pass per non-empty range when the time allows it) and an empty range is harmless."""
+    enc, _units = small_corpus.encoded(kind)
+    od = oracle.OracleDict(kind, small_corpus.dict_file(kind))
+    hs = _list_header_starts(od, enc, small_corpus.coll.lens)
+    cut = [0, int(hs[len(hs) // 3]), int(hs[len(hs) // 3]), int(hs[2 * len(hs) // 3])]  # thread 1's range is empty
+    wall, ints, lists = od.time_stream_parallel(enc, cut, 0.3)
+    assert 0.25 < wall < 5.0
+    assert lists >= len(hs) and ints >= small_corpus.coll.num_postings
+    # one thread over everything for a moment shorter than one check interval: exactly whole lists
+    wall1, ints1, lists1 = od.time_stream_parallel(enc, [0], 1e-9)
+    assert lists1 == 32 and ints1 == int(small_corpus.coll.lens[small_corpus.coll.lens > 0][:32].sum())
+    with pytest.raises(RuntimeError):
+        od.time_stream_parallel(enc, [0, enc.size + 1], 0.01)

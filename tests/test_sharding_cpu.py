@@ -107,3 +107,45 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
     assert line["config"]["parallelism"] == "list-range x2"
     assert line["value"] > 0 and line["roofline"]["traffic"] is None
+    assert line["data"] == "stub" and line["stub"] == "bench_stub"  # a stubbed run can not pass for a measurement
+    assert line["config"]["process_group"] == "gloo"
+
+
+def _stub_bench(extra, env_extra, timeout=300):
+    env = dict(os.environ, DINT_BENCH_STUB="bench_stub", PYTHONPATH=os.path.join(ROOT, "tests"), **env_extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--postings", "200000",
+                           "--universe", "300000", "--dict-sample", "100000", "--cpu-seconds", "0", "--no-verify"] + extra,
+                          env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("how", ["BENCH_STUB_FAIL_RANK", "BENCH_STUB_HANG_RANK"])
+def test_bench_launcher_stops_every_rank_when_one_fails_or_hangs(how):
+    """A rank that dies (or never answers) must not leave its siblings waiting in a collective and the caller waiting
+    for them: the launcher stops all of them and exits non-zero, without a result line."""
+    import time
+
+    t0 = time.time()
+    r = _stub_bench(["--gpus", "2", "--rank-timeout", "20"], {how: "1"})
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "all ranks stopped" in r.stderr
+    assert time.time() - t0 < 120
+
+
+def test_bench_as_rank_takes_that_ranks_shard():
+    """--as-rank 3/8: one process decoding the shard rank 3 of an 8-rank job would get."""
+    import json
+
+    r = _stub_bench(["--gpus", "1", "--as-rank", "3/8"], {})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    p = host.synth_params(universe=300000, seed=12345)
+    lens_all = host.synth_lengths(p, 200000 * 8)
+    lo, hi = sharding.partition_lists(lens_all, 8)[3]
+    assert line["emulated_rank"] == "3/8" and f"lists [{lo},{hi})" in line["emulated_note"]
+    assert line["config"]["ints_per_gpu_per_step"] == int(lens_all[lo:hi].sum()) * 5  # (gov2 workload: x5 replicas)
+    assert line["config"]["parallelism"] == "list-range shard 3 of 8" and line["n_gpus"] == 1
+    bad = _stub_bench(["--gpus", "1", "--as-rank", "8/8"], {})
+    assert bad.returncode != 0
