@@ -61,6 +61,9 @@ def parse_args(argv=None):
                     help="JSON written by tools/pmc_traffic.py from rocprofv3 --pmc passes of THIS command; without it "
                          "roofline.traffic is null (HBM counters cannot be read from inside the run)")
     ap.add_argument("--no-verify", action="store_true", help="skip the full bit-exact output check")
+    ap.add_argument("--per-launch-schedule", action="store_true",
+                    help="decode through dint_decode_units (the bundle schedule rebuilt before every launch, and timed) instead "
+                         "of a unit table prepared once during set-up")
     ap.add_argument("--as-rank", default=None, metavar="K/W",
                     help="one process, one GPU, decoding exactly the shard rank K of a W-rank job would get "
                          "(sharding.partition_lists(lens_all, W)[K] of the W x postings collection): BASELINE config 4's "
@@ -315,15 +318,28 @@ def main():
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
 
+    # The unit table is prepared once (set-up, untimed — like the sidecar it is a property of the encoded collection,
+    # SURVEY H3): which tiny units share a tile, the work items of the unit queue. A step is then ONE launch.
+    # --per-launch-schedule: dint_decode_units instead, which rebuilds that schedule before every launch.
+    table = None
+    if not args.per_launch_schedule and hasattr(device, "UnitTable"):
+        table = device.UnitTable(d, enc_dev, units_dev, n_units, n_ints)
+
+    def step():
+        if table is not None:
+            table.decode(out_dev, end_dev)
+        else:
+            d.decode_units(enc_dev, units_dev, n_units, out_dev, end_dev)
+
     # ---- warm-up ------------------------------------------------------------------
     for _ in range(args.warmup):
-        d.decode_units(enc_dev, units_dev, n_units, out_dev, end_dev)
+        step()
     sync_all()
 
     # ---- timed region: exactly K steps (each returns the end offsets too, like the reference's decode) ----
     t_start = time.perf_counter()
     for _ in range(args.steps):
-        d.decode_units(enc_dev, units_dev, n_units, out_dev, end_dev)
+        step()
     sync_all()
     elapsed = time.perf_counter() - t_start
     # per-launch kernel time of the timed launches themselves: the event pairs the library recorded around them
@@ -459,6 +475,7 @@ def main():
                 "lists_per_gpu": int(np.count_nonzero(lens)) * R,
                 "units_per_gpu": n_units,
                 "unit_ints": args.unit_ints,
+                "schedule": "prepared unit table (set-up)" if table is not None else "per launch (timed)",
                 "bits_per_int": round(bpi, 3),
                 **stream,
                 "hot_codewords_in_lds": int(info.hot_entries),

@@ -514,6 +514,12 @@ int dint_dict_create(int kind, const void* file_bytes, size_t len, int device, d
         !hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_multi_index_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsWords * 4)),
                 "hipFuncSetAttribute") ||
+        !hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_single_query_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsWords * 4)),
+                "hipFuncSetAttribute") ||
+        !hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_multi_query_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsWords * 4)),
+                "hipFuncSetAttribute") ||
         !hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(&interpolative_tails_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(kTailLdsBytes)),
                 "hipFuncSetAttribute")) {
@@ -653,8 +659,79 @@ int dint_index_stream(const dint_dict* dd, const uint8_t* enc, size_t enc_bytes,
 // being rebuilt, three small kernels, before every launch.
 struct sched_cache {
     void* d_mem = nullptr;  // (the layout launch_decode gives a slot's schedule workspace)
+    size_t mem_bytes = 0;
     bool valid = false;
+    // What the schedule was built from. bundle_schedule_kernel bakes this launch's bounds checks (stream bytes, output
+    // capacity) and, multi-dictionary streams, the blocks' selector bytes into the unit records: a later launch with
+    // another dictionary, stream, unit table, span table or a SMALLER capacity must not reuse them — it rebuilds.
+    const void* dict = nullptr;
+    const void* d_enc = nullptr;
+    const void* d_units = nullptr;
+    const void* d_spans = nullptr;
+    size_t enc_bytes = 0, n_units = 0, out_capacity = 0;
+    uint32_t only_full = 0;
+    bool matches(const void* dd, const void* enc, size_t eb, const void* units, size_t n, const void* spans, size_t cap,
+                 uint32_t full) const {
+        return valid && dict == dd && d_enc == enc && enc_bytes == eb && d_units == units && n_units == n && d_spans == spans &&
+               cap >= out_capacity && only_full == full;
+    }
 };
+
+// workspace of a schedule: [unit records 16 B x n][chunk bases 16 B x chunks][items u32 x n][block counts/offsets u32 x blocks]
+// [n_items u32][sched u8 x n][item counts u8 x n]
+struct sched_layout {
+    size_t n_units, n_blocks, n_chunks, need;
+    u32x4* d_urec = nullptr;
+    uint64_t* d_cbase = nullptr;
+    uint32_t *d_items = nullptr, *d_block = nullptr, *d_n_items = nullptr;
+    uint8_t *d_sch = nullptr, *d_item_cnt = nullptr;
+    explicit sched_layout(size_t n) : n_units(n), n_blocks((n + 255) / 256), n_chunks((n + kChunkUnits - 1) / kChunkUnits) {
+        need = 16 * n_units + 16 * n_chunks + 4 * n_units + 4 * n_blocks + 4 + 2 * n_units;
+    }
+    void place(void* mem) {
+        d_urec = reinterpret_cast<u32x4*>(mem);
+        d_cbase = reinterpret_cast<uint64_t*>(d_urec + n_units);
+        d_items = reinterpret_cast<uint32_t*>(d_cbase + 2 * n_chunks);
+        d_block = d_items + n_units;
+        d_n_items = d_block + n_blocks;
+        d_sch = reinterpret_cast<uint8_t*>(d_n_items + 1);
+        d_item_cnt = d_sch + n_units;
+    }
+};
+
+static void run_schedule_kernels(const dint_dict* dd, const uint8_t* d_enc, size_t enc_bytes, const dint_unit* d_units, size_t n_units,
+                                 size_t out_capacity, uint32_t only_full, const uint32_t* d_spans, const sched_layout& L, hipStream_t s) {
+    hipLaunchKernelGGL(bundle_schedule_kernel, dim3(uint32_t(L.n_blocks)), dim3(256), 0, s, d_units, d_spans, uint64_t(n_units), d_enc,
+                       uint64_t(enc_bytes), uint64_t(out_capacity), only_full, uint32_t(dd->kind == DINT_DICT_MULTI_PACKED), L.d_sch,
+                       L.d_block, L.d_urec, L.d_cbase);
+    if (dd->kind == DINT_DICT_MULTI_PACKED)
+        hipLaunchKernelGGL(bundle_pack_kernel, dim3(uint32_t((L.n_chunks + 63) / 64)), dim3(64), 0, s, L.d_urec, uint64_t(n_units));
+    hipLaunchKernelGGL(bundle_offsets_kernel, dim3(1), dim3(1024), 0, s, L.d_block, uint32_t(L.n_blocks), L.d_n_items);
+    hipLaunchKernelGGL(bundle_items_kernel, dim3(uint32_t(L.n_blocks)), dim3(256), 0, s, L.d_sch, uint64_t(n_units), L.d_block, L.d_items,
+                       L.d_item_cnt);
+}
+
+// (Re)build a kept schedule on stream `s` and remember what it was built from.
+static int build_schedule(const dint_dict* dd, const uint8_t* d_enc, size_t enc_bytes, const dint_unit* d_units, size_t n_units,
+                          size_t out_capacity, uint32_t only_full, const uint32_t* d_spans, sched_cache* cache, hipStream_t s) {
+    HIP_TRY(hipSetDevice(dd->device));
+    sched_layout L(n_units);
+    cache->valid = false;
+    if (cache->mem_bytes < L.need) {
+        if (cache->d_mem) HIP_TRY(hipFree(cache->d_mem));  // (hipFree waits for the launches that read it)
+        cache->d_mem = nullptr;
+        cache->mem_bytes = 0;
+        HIP_TRY(hipMalloc(&cache->d_mem, L.need));
+        cache->mem_bytes = L.need;
+    }
+    L.place(cache->d_mem);
+    run_schedule_kernels(dd, d_enc, enc_bytes, d_units, n_units, out_capacity, only_full, d_spans, L, s);
+    HIP_TRY(hipGetLastError());
+    cache->valid = true;
+    cache->dict = dd, cache->d_enc = d_enc, cache->enc_bytes = enc_bytes, cache->d_units = d_units, cache->n_units = n_units;
+    cache->d_spans = d_spans, cache->out_capacity = out_capacity, cache->only_full = only_full;
+    return DINT_OK;
+}
 
 static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_bytes, const dint_unit* d_units,
                          size_t n_units, uint32_t* d_out, size_t out_capacity, uint64_t* d_end_off, void* stream,
@@ -725,48 +802,46 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
     a.urec = nullptr;
     a.cbase = nullptr;
     a.spans = d_spans;
+    bool start_recorded = false;
     // (schedule_from: a caller that decodes a handful of units at a time — a query's pages — does without the three
     // schedule launches: with fewer units than waves nothing is gained by sharing tiles)
     if (n_units >= schedule_from && n_units < 0xFFFFFFFFull &&
         !dd->no_bundles) {
-        // workspace of the slot: [unit records 16 B x n][chunk bases 16 B x chunks][items u32 x n][block counts/offsets u32 x blocks]
-        // [n_items u32][sched u8 x n][item counts u8 x n]
-        const size_t n_blocks = (n_units + 255) / 256;
-        const size_t n_chunks = (n_units + kChunkUnits - 1) / kChunkUnits;
-        const size_t need = 16 * n_units + 16 * n_chunks + 4 * n_units + 4 * n_blocks + 4 + 2 * n_units;
-        if (cache && !cache->d_mem) HIP_TRY(hipMalloc(&cache->d_mem, need));
-        const uint32_t ss = uint32_t(mut->launches % dint_dict::kSchedSlots);
-        if (!cache) {
+        sched_layout L(n_units);
+        if (cache) {
+            if (!cache->matches(dd, d_enc, enc_bytes, d_units, n_units, d_spans, out_capacity, only_full)) {
+                // not built yet, or built for other buffers / a larger capacity: (re)built on this stream, and timed with
+                // the launch — the event pair spans what the call put on the stream
+                HIP_TRY(hipEventRecord(mut->slot_start[slot], s));
+                start_recorded = true;
+                const int st = build_schedule(dd, d_enc, enc_bytes, d_units, n_units, out_capacity, only_full, d_spans, cache, s);
+                if (st != DINT_OK) return st;
+            }
+            L.place(cache->d_mem);
+        } else {
+            const uint32_t ss = uint32_t(mut->launches % dint_dict::kSchedSlots);
             const int prev = mut->sched_user[ss];
             if (prev >= 0 && prev != int(slot) && mut->slot_used[prev]) HIP_TRY(hipEventSynchronize(mut->slot_done[prev]));
             mut->sched_user[ss] = int(slot);
+            if (mut->sched_cap[ss] < L.need) {
+                if (mut->d_sched[ss]) HIP_TRY(hipFree(mut->d_sched[ss]));
+                mut->d_sched[ss] = nullptr;
+                mut->sched_cap[ss] = 0;
+                const size_t want = L.need + L.need / 4 + 4096;
+                HIP_TRY(hipMalloc(&mut->d_sched[ss], want));
+                mut->sched_cap[ss] = want;
+            }
+            L.place(mut->d_sched[ss]);
+            HIP_TRY(hipEventRecord(mut->slot_start[slot], s));
+            start_recorded = true;
+            run_schedule_kernels(dd, d_enc, enc_bytes, d_units, n_units, out_capacity, only_full, d_spans, L, s);
         }
-        if (!cache && mut->sched_cap[ss] < need) {
-            if (mut->d_sched[ss]) HIP_TRY(hipFree(mut->d_sched[ss]));
-            mut->d_sched[ss] = nullptr;
-            mut->sched_cap[ss] = 0;
-            const size_t want = need + need / 4 + 4096;
-            HIP_TRY(hipMalloc(&mut->d_sched[ss], want));
-            mut->sched_cap[ss] = want;
-        }
-        u32x4* const d_urec = reinterpret_cast<u32x4*>(cache ? cache->d_mem : mut->d_sched[ss]);
-        uint64_t* const d_cbase = reinterpret_cast<uint64_t*>(d_urec + n_units);
-        uint32_t* const d_items = reinterpret_cast<uint32_t*>(d_cbase + 2 * n_chunks);
-        uint32_t* const d_block = d_items + n_units;
-        uint32_t* const d_n_items = d_block + n_blocks;
-        uint8_t* const d_sch = reinterpret_cast<uint8_t*>(d_n_items + 1);
-        uint8_t* const d_item_cnt = d_sch + n_units;
-        if (!cache || !cache->valid) {
-            hipLaunchKernelGGL(bundle_schedule_kernel, dim3(uint32_t(n_blocks)), dim3(256), 0, s, d_units, d_spans, uint64_t(n_units),
-                               d_enc, uint64_t(enc_bytes), uint64_t(out_capacity), only_full,
-                               uint32_t(dd->kind == DINT_DICT_MULTI_PACKED), d_sch, d_block, d_urec, d_cbase);
-            if (dd->kind == DINT_DICT_MULTI_PACKED)
-                hipLaunchKernelGGL(bundle_pack_kernel, dim3(uint32_t((n_chunks + 63) / 64)), dim3(64), 0, s, d_urec, uint64_t(n_units));
-            hipLaunchKernelGGL(bundle_offsets_kernel, dim3(1), dim3(1024), 0, s, d_block, uint32_t(n_blocks), d_n_items);
-            hipLaunchKernelGGL(bundle_items_kernel, dim3(uint32_t(n_blocks)), dim3(256), 0, s, d_sch, uint64_t(n_units), d_block,
-                               d_items, d_item_cnt);
-            if (cache) cache->valid = true;
-        }
+        uint8_t* const d_sch = L.d_sch;
+        uint32_t* const d_items = L.d_items;
+        uint32_t* const d_n_items = L.d_n_items;
+        uint8_t* const d_item_cnt = L.d_item_cnt;
+        u32x4* const d_urec = L.d_urec;
+        uint64_t* const d_cbase = L.d_cbase;
         a.sched = d_sch;
         a.items = d_items;
         a.n_items = d_n_items;
@@ -774,7 +849,7 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
         a.urec = d_urec;
         a.cbase = d_cbase;
     }
-    HIP_TRY(hipEventRecord(mut->slot_start[slot], s));
+    if (!start_recorded) HIP_TRY(hipEventRecord(mut->slot_start[slot], s));
     launch_kernel();
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(mut->slot_stop[slot], s));
@@ -787,6 +862,56 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
 int dint_decode_units(const dint_dict* dd, const uint8_t* d_enc, size_t enc_bytes, const dint_unit* d_units,
                       size_t n_units, uint32_t* d_out, size_t out_capacity, uint64_t* d_end_off, void* stream) {
     return launch_decode(dd, d_enc, enc_bytes, d_units, n_units, d_out, out_capacity, d_end_off, stream, 0);
+}
+
+struct dint_unit_table {
+    const dint_dict* dict = nullptr;
+    const uint8_t* d_enc = nullptr;
+    size_t enc_bytes = 0;
+    const dint_unit* d_units = nullptr;
+    size_t n_units = 0;
+    size_t out_capacity = 0;
+    sched_cache sched;
+    std::mutex mutex;
+};
+
+int dint_unit_table_create(const dint_dict* dd, const uint8_t* d_enc, size_t enc_bytes, const dint_unit* d_units, size_t n_units,
+                           size_t out_capacity, void* stream, dint_unit_table** out) {
+    if (!dd || !out || (n_units && (!d_enc || !d_units || enc_bytes < 8))) return DINT_ERR_ARG;
+    *out = nullptr;
+    auto* t = new (std::nothrow) dint_unit_table();
+    if (!t) return DINT_ERR_NOMEM;
+    t->dict = dd;
+    t->d_enc = d_enc;
+    t->enc_bytes = enc_bytes;
+    t->d_units = d_units;
+    t->n_units = n_units;
+    t->out_capacity = out_capacity;
+    if (n_units >= 2 && n_units < 0xFFFFFFFFull && !dd->no_bundles) {
+        int st = build_schedule(dd, d_enc, enc_bytes, d_units, n_units, out_capacity, 0, nullptr, &t->sched, static_cast<hipStream_t>(stream));
+        if (st == DINT_OK && !hip_ok(hipStreamSynchronize(static_cast<hipStream_t>(stream)), "hipStreamSynchronize")) st = DINT_ERR_HIP;
+        if (st != DINT_OK) {
+            dint_unit_table_destroy(t);
+            return st;
+        }
+    }
+    *out = t;
+    return DINT_OK;
+}
+
+void dint_unit_table_destroy(dint_unit_table* t) {
+    if (!t) return;
+    if (t->dict) (void)hipSetDevice(t->dict->device);
+    if (t->sched.d_mem) (void)hipFree(t->sched.d_mem);
+    delete t;
+}
+
+int dint_decode_unit_table(const dint_dict* dd, dint_unit_table* t, uint32_t* d_out, size_t out_capacity, uint64_t* d_end_off,
+                           void* stream) {
+    if (!dd || !t || t->dict != dd || out_capacity < t->out_capacity) return DINT_ERR_ARG;
+    std::lock_guard<std::mutex> lock(t->mutex);  // (the cache may be rebuilt: a dictionary created under DINT_NO_BUNDLES has none)
+    return launch_decode(dd, t->d_enc, t->enc_bytes, t->d_units, t->n_units, d_out, out_capacity, d_end_off, stream, 0, nullptr, 0, nullptr,
+                         nullptr, &t->sched);
 }
 
 int dint_index_posting_lists(const uint8_t* index, size_t index_bytes, const uint64_t* list_offsets,
@@ -859,6 +984,7 @@ struct dint_block_table {
     uint32_t decodes = 0;
     sched_cache docs_sched, freqs_sched;
     bool freqs_units_ready = false;
+    uint64_t max_out_end = 0;           // max over the blocks of out_off + n: a decode whose out_capacity is below it skips blocks
 };
 
 namespace {
@@ -880,6 +1006,7 @@ int block_table_prepare(dint_block_table& t, const dint_block_ref* d_blocks, siz
     t.n_blocks = n_blocks;
     const uint32_t tb = 256, grid = uint32_t((n_blocks + tb - 1) / tb);
     HIP_TRY(hipMemsetAsync(t.d_tails + n_blocks, 0, 4, s));
+    HIP_TRY(hipMemsetAsync(t.d_ends, 0, n_blocks * 8, s));  // (a block a decode skips leaves its end offset untouched)
     hipLaunchKernelGGL(collect_tails_kernel, dim3(grid), dim3(tb), 0, s, d_blocks, uint64_t(n_blocks), t.d_tails, t.d_tails + n_blocks);
     hipLaunchKernelGGL(blocks_to_units_kernel, dim3(grid), dim3(tb), 0, s, d_blocks, static_cast<const uint64_t*>(nullptr),
                        uint64_t(n_blocks), uint64_t(index_bytes), t.d_units, t.d_spans, t.d_bases);
@@ -901,19 +1028,25 @@ int block_table_decode(const dint_dict* docs_dict, const dint_dict* freqs_dict, 
     // docs parts of the full blocks through the DINT kernel (docIDs formed in the expansion); then, where they end,
     // their freqs parts; the short blocks — both parts of a block in one lane — through the interpolative decoder
     dint_block_table& mt = const_cast<dint_block_table&>(t);
-    const bool keep = t.owns_blocks && t.decodes >= 1;  // (a one-shot table never reaches its second decode)
+    // What a decode learns for the next ones (exact spans, the freqs parts' units, the schedules) is kept only when
+    // this call decodes EVERY block: with an out_capacity below some block's end the kernels skip that block and leave
+    // its end offset unwritten — nothing may be derived from it.
+    const bool covers = out_capacity >= t.max_out_end;
+    const bool keep = t.owns_blocks && covers && t.decodes >= 1;  // (a one-shot table never reaches its second decode)
     int st = launch_decode(docs_dict, d_index, index_bytes, t.d_units, n_blocks, d_docids, out_capacity, t.d_ends, s, 1, t.d_spans, 0,
                            t.d_bases, t.d_gaps_left, keep ? &mt.docs_sched : nullptr);
     if (st != DINT_OK) return st;
-    if (!t.spans_exact) {  // (stream-ordered: the next decode on this table finds the exact spans)
+    if (!t.spans_exact && covers) {  // (stream-ordered: the next decode on this table finds the exact spans)
         hipLaunchKernelGGL(exact_spans_kernel, dim3(grid), dim3(tb), 0, s, t.d_units, t.d_ends, uint64_t(n_blocks), t.d_spans);
         mt.spans_exact = true;
     }
     if (d_freqs) {
         if (!t.freqs_units_ready) {
+            // (a skipped block's end offset is zero: its freqs unit then starts at the buffer's first byte and is
+            // skipped in turn — same out_off, same capacity)
             hipLaunchKernelGGL(blocks_to_units_kernel, dim3(grid), dim3(tb), 0, s, t.d_blocks, t.d_ends, uint64_t(n_blocks),
                                uint64_t(index_bytes), t.d_funits, t.d_fspans, static_cast<uint32_t*>(nullptr));
-            mt.freqs_units_ready = t.owns_blocks;
+            mt.freqs_units_ready = t.owns_blocks && covers;
         }
         // (freq = decoded value + 1, dict_posting_list.hpp:164-169: added where the values are stored)
         st = launch_decode(freqs_dict, d_index, index_bytes, t.d_funits, n_blocks, d_freqs, out_capacity, nullptr, s, 1, t.d_fspans, 1,
@@ -930,7 +1063,7 @@ int block_table_decode(const dint_dict* docs_dict, const dint_dict* freqs_dict, 
         hipLaunchKernelGGL(finalize_flagged_kernel, dim3(uint32_t((n_blocks + 63) / 64)), dim3(64), 0, s, t.d_blocks, uint64_t(n_blocks),
                            d_docids, uint64_t(out_capacity), t.d_gaps_left);
     HIP_TRY(hipGetLastError());
-    mt.decodes += 1;
+    if (covers) mt.decodes += 1;
     return DINT_OK;
 }
 }  // namespace
@@ -940,11 +1073,16 @@ int dint_block_table_create(const dint_dict* docs_dict, const dint_block_ref* bl
     if (!docs_dict || !out || (!blocks && n_blocks)) return DINT_ERR_ARG;
     *out = nullptr;
     if (n_blocks >= 0xFFFFFFFFull) return DINT_ERR_ARG;
-    for (size_t b = 0; b != n_blocks; ++b)
+    uint64_t max_out_end = 0;
+    for (size_t b = 0; b != n_blocks; ++b) {
         if (blocks[b].n == 0 || blocks[b].n > kBlock || blocks[b].in_off > index_bytes) return DINT_ERR_FORMAT;
+        if (blocks[b].out_off + blocks[b].n >= blocks[b].out_off) max_out_end = std::max<uint64_t>(max_out_end, blocks[b].out_off + blocks[b].n);
+        else max_out_end = ~uint64_t(0);  // (wraps: no capacity covers it)
+    }
     auto* t = new (std::nothrow) dint_block_table();
     if (!t) return DINT_ERR_NOMEM;
     t->device = docs_dict->device;
+    t->max_out_end = max_out_end;
     if (n_blocks == 0) {
         *out = t;
         return DINT_OK;

@@ -29,7 +29,7 @@ _LIB_PATH = os.environ.get("DINT_HIP_LIB") or os.path.join(_HERE, "libdint_hip.s
 ABI_SYMBOLS = (
     "dint_abi_version", "dint_strerror", "dint_last_hip_error", "dint_device_count",
     "dint_dict_create", "dint_dict_destroy", "dint_dict_info_get", "dint_index_stream", "dint_free",
-    "dint_decode_units", "dint_decode_list_host", "dint_last_kernel_ms", "dint_recent_kernel_ms",
+    "dint_decode_units", "dint_unit_table_create", "dint_unit_table_destroy", "dint_decode_unit_table", "dint_decode_list_host", "dint_last_kernel_ms", "dint_recent_kernel_ms",
     "dint_stream_stats_get",
     "dint_decode_block_host", "dint_index_posting_lists", "dint_decode_posting_blocks",
     "dint_block_table_create", "dint_block_table_destroy", "dint_decode_block_table",
@@ -78,6 +78,10 @@ def _load():
     lib.dint_free.restype = None
     lib.dint_free.argtypes = [vp]
     lib.dint_decode_units.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, vp]
+    lib.dint_unit_table_create.argtypes = [vp, vp, sz, vp, sz, sz, vp, C.POINTER(vp)]
+    lib.dint_unit_table_destroy.restype = None
+    lib.dint_unit_table_destroy.argtypes = [vp]
+    lib.dint_decode_unit_table.argtypes = [vp, vp, vp, sz, vp, vp]
     lib.dint_decode_list_host.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
     lib.dint_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.dint_last_kernel_clock_mhz.argtypes = [vp, C.POINTER(C.c_float)]
@@ -220,6 +224,40 @@ class Dictionary:
         _check(_lib.dint_decode_list_host(self._h, enc.ctypes.data + offset, enc.size - offset, out.ctypes.data, n,
                                           C.byref(consumed)), "dint_decode_list_host")
         return out, consumed.value
+
+
+class UnitTable:
+    """A unit table prepared once for repeated decodes of one resident stream (dint_unit_table): the bundle schedule —
+    a property of the stream and its sidecar — is computed here, a decode is then one kernel launch. Borrows the
+    dictionary and the two device tensors (kept alive here)."""
+
+    def __init__(self, dictionary: "Dictionary", enc_dev, units_dev, n_units: int, out_capacity: int, stream=None):
+        import torch
+
+        if stream is None:
+            stream = torch.cuda.current_stream(enc_dev.device).cuda_stream
+        self._dict, self._enc, self._units = dictionary, enc_dev, units_dev
+        self._h = C.c_void_p()
+        _check(_lib.dint_unit_table_create(dictionary._h, enc_dev.data_ptr(), enc_dev.numel() * enc_dev.element_size(),
+                                           units_dev.data_ptr(), n_units, out_capacity, stream, C.byref(self._h)),
+               "dint_unit_table_create")
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.dint_unit_table_destroy(h)
+
+    __del__ = close
+
+    def decode(self, out_dev, end_off_dev=None, stream=None) -> None:
+        """Enqueue the decode of every unit (asynchronous)."""
+        import torch
+
+        if stream is None:
+            stream = torch.cuda.current_stream(out_dev.device).cuda_stream
+        _check(_lib.dint_decode_unit_table(self._dict._h, self._h, out_dev.data_ptr(), out_dev.numel(),
+                                           end_off_dev.data_ptr() if end_off_dev is not None else None, stream),
+               "dint_decode_unit_table")
 
 
 def decode_block(dictionary: "Dictionary", buf: np.ndarray, offset: int, sum_of_values: int, n: int):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DINT_ABI_VERSION 2
+#define DINT_ABI_VERSION 3
 
 /* A unit decodes to at most this many integers (the kernels address a unit's output with 32-bit byte
  * offsets); dint_index_stream never cuts larger ones, dint_decode_units skips them. */
@@ -116,6 +116,24 @@ void dint_free(void* p);
 int dint_decode_units(const dint_dict* dict, const uint8_t* d_enc, size_t enc_bytes,
                       const dint_unit* d_units, size_t n_units, uint32_t* d_out,
                       size_t out_capacity, uint64_t* d_end_off, void* stream);
+
+/* A unit table prepared for decoding. What depends on the unit table and the stream alone — which tiny units
+ * share a wavefront tile, the work items of the unit queue, the selector bytes of a multi-dictionary stream's
+ * blocks (the "bundle schedule": three small kernels and a read of 22 bytes per unit that dint_decode_units
+ * runs before EVERY launch) — is computed once, here, like the sidecar itself (it is a property of the encoded
+ * collection, not of a decode). The handle borrows `dict`, `d_enc` and `d_units`: they must outlive it and keep
+ * their contents. `out_capacity` is the smallest output capacity later decodes may pass (the schedule's bounds
+ * checks are made against it). Synchronises `stream`.
+ * Replaces: nothing in the reference (its decode loop is sequential); it is the set-up half of
+ * dint_decode_units, i.e. of vroom_env/decode.cpp:139-150. */
+typedef struct dint_unit_table dint_unit_table;
+int dint_unit_table_create(const dint_dict* dict, const uint8_t* d_enc, size_t enc_bytes, const dint_unit* d_units,
+                           size_t n_units, size_t out_capacity, void* stream, dint_unit_table** out);
+void dint_unit_table_destroy(dint_unit_table* table);
+/* dint_decode_units over a prepared table: one kernel launch, asynchronous. out_capacity must be at least the
+ * table's (DINT_ERR_ARG otherwise). Results are identical to dint_decode_units'. */
+int dint_decode_unit_table(const dint_dict* dict, dint_unit_table* table, uint32_t* d_out, size_t out_capacity,
+                           uint64_t* d_end_off, void* stream);
 
 /* Host-pointer convenience with the reference's call shape: decode ONE
  * sequence of n integers starting at in[0]; *consumed = bytes read. Uploads,

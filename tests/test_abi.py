@@ -28,7 +28,7 @@ def test_python_binding_lists_the_same_symbols():
     from dint_amd import device
 
     assert sorted(device.ABI_SYMBOLS) == declared_functions("dint_hip.h")
-    assert device.abi_version() == 2
+    assert device.abi_version() == 3
 
 
 def test_errors_are_status_codes_not_exceptions():

@@ -94,3 +94,50 @@ def test_prepared_block_table_decodes_asynchronously(device, small_corpus, kind)
     table.decode(dd, None, index_dev, padded.size, docids_dev, None)
     torch.cuda.synchronize()
     assert np.array_equal(docids_dev.cpu().numpy().view(np.uint32), ix.docids)
+
+
+@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
+def test_block_table_keeps_nothing_from_a_decode_that_skipped_blocks(device, small_corpus, kind):
+    """A prepared table keeps what its decodes learn (exact spans, the freqs parts' units, both bundle schedules). A
+    decode whose out_capacity is too small for some blocks skips them — nothing may be learnt from it — and a schedule
+    built under one capacity must not serve a smaller one: first call too small, then four docs + freqs decodes
+    (the cached freqs schedule is in use from the third), then a too-small one again with canaries behind it."""
+    import torch
+
+    ix = get_index(small_corpus, kind)
+    blocks, total = device.index_posting_lists(ix.bytes, ix.offsets)
+    dd, fd = device.Dictionary(kind, ix.docs_dict), device.Dictionary(kind, ix.freqs_dict)
+    dev = torch.device("cuda", 0)
+    padded = np.concatenate([ix.bytes, np.zeros(16, np.uint8)])
+    index_dev = torch.from_numpy(padded).to(dev)
+    table = device.BlockTable(dd, blocks, padded.size)
+    cut = total - 3 * 256 - 17   # the last blocks do not fit
+
+    def run(capacity):
+        docids_dev = torch.full((total + 1024,), -5, dtype=torch.int32, device=dev)
+        freqs_dev = torch.full((total + 1024,), -5, dtype=torch.int32, device=dev)
+        table.decode(dd, fd, index_dev, padded.size, docids_dev[:capacity], freqs_dev[:capacity])
+        torch.cuda.synchronize()
+        return docids_dev.cpu().numpy(), freqs_dev.cpu().numpy()
+
+    def check_short(docids, freqs):
+        fits = (blocks["out_off"] + blocks["n"]).astype(np.int64) <= cut
+        for b in np.flatnonzero(~fits):
+            lo, n = int(blocks["out_off"][b]), int(blocks["n"][b])
+            assert (docids[lo:lo + n] == -5).all() and (freqs[lo:lo + n] == -5).all()
+        assert (docids[cut:] == -5).all() and (freqs[cut:] == -5).all(), "written past the capacity"
+        keep = np.zeros(total, bool)
+        for b in np.flatnonzero(fits):
+            keep[int(blocks["out_off"][b]):int(blocks["out_off"][b]) + int(blocks["n"][b])] = True
+        assert np.array_equal(docids[:total].view(np.uint32)[keep], ix.docids[keep])
+        assert np.array_equal(freqs[:total].view(np.uint32)[keep], ix.freqs[keep])
+
+    check_short(*run(cut))
+    for _ in range(4):
+        docids, freqs = run(total)
+        assert np.array_equal(docids[:total].view(np.uint32), ix.docids)
+        assert np.array_equal(freqs[:total].view(np.uint32), ix.freqs)
+        assert (docids[total:] == -5).all() and (freqs[total:] == -5).all()
+    check_short(*run(cut))
+    docids, freqs = run(total)
+    assert np.array_equal(docids[:total].view(np.uint32), ix.docids) and np.array_equal(freqs[:total].view(np.uint32), ix.freqs)

@@ -337,3 +337,42 @@ def test_ngram_counts_of_a_tiny_collection(device):
     assert got == want
     none, _ = device.count_ngrams(torch.from_numpy(gaps.view(np.int32)).cuda(), starts, multi=True)   # no whole 256-block
     assert none.size == 0
+
+
+@pytest.mark.parametrize("kind,unit_ints", [(host.SINGLE_PACKED, 2048), (host.RECTANGULAR, 64), (host.MULTI_PACKED, 256),
+                                            (host.MULTI_PACKED, 4096)])
+def test_prepared_unit_table_decodes_like_decode_units(device, small_corpus, kind, unit_ints):
+    """dint_unit_table_create + dint_decode_unit_table: the bundle schedule built once, then one launch per decode —
+    the same integers and end offsets as dint_decode_units, launch after launch, on a side stream too; a smaller
+    output than the table was prepared for is refused."""
+    import torch
+
+    d = device.Dictionary(kind, small_corpus.dict_file(kind))
+    enc, _ = small_corpus.encoded(kind)
+    units, total, _ = d.index_stream(enc, unit_ints)
+    dev = torch.device("cuda", 0)
+    enc_dev = torch.from_numpy(enc).to(dev)
+    units_dev = device.units_to_device(units, dev)
+    want, want_ends, _ = device.decode_stream(d, enc, units, total)
+    assert np.array_equal(want, small_corpus.coll.gaps)
+    table = device.UnitTable(d, enc_dev, units_dev, len(units), total)
+    side = torch.cuda.Stream(dev)
+    for rep in range(3):
+        out_dev = torch.full((total + 512,), -7, dtype=torch.int32, device=dev)
+        end_dev = torch.zeros(len(units), dtype=torch.int64, device=dev)
+        if rep == 1:
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                table.decode(out_dev, end_dev, stream=side.cuda_stream)
+            side.synchronize()
+        else:
+            table.decode(out_dev, end_dev)
+            torch.cuda.synchronize()
+        got = out_dev.cpu().numpy()
+        assert np.array_equal(got[:total].view(np.uint32), want)
+        assert (got[total:] == -7).all()
+        assert np.array_equal(end_dev.cpu().numpy().view(np.uint64), want_ends)
+    small = torch.empty(total - 1, dtype=torch.int32, device=dev)
+    with pytest.raises(device.DintError):
+        table.decode(small)
+    table.close()
