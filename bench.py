@@ -164,6 +164,22 @@ def physical_cores() -> int:
         return len(os.sched_getaffinity(0))
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use per period (cgroup v2 cpu.max, v1 cfs quota), or None: no limit."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()[:2]
+        return None if q == "max" else float(q) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+            q, period = float(f.read()), float(g.read())
+        return None if q <= 0 else q / period
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(kind, dict_file, enc, list_byte_starts, seconds):
     """The oracle's restatement of the reference decode, timed on this host: (i) one thread, per-list timing
     summed exactly like vroom_env/decode.cpp:139-150; (ii) every core, the lists statically partitioned by
@@ -181,16 +197,21 @@ def cpu_baseline(kind, dict_file, enc, list_byte_starts, seconds):
     one = {"value": round(ints / sec / 1e6, 2), "unit": "M ints/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
            "sample": f"{passes} pass(es) over the same encoded stream, {lists} list decodes ({ints} postings), per-list "
                      f"timing summed as in vroom_env/decode.cpp:139-150, {sec:.1f}s of decode time"}
-    threads = len(os.sched_getaffinity(0))
-    phys = physical_cores()
+    # "every core" = every CPU this process may use: its affinity mask, cut down to the container's CPU-time quota
+    # (cgroup cpu.max) — more runnable threads than that are throttled, which measures the throttle, not the host
+    affinity, quota = len(os.sched_getaffinity(0)), cpu_quota()
+    threads = affinity if quota is None else max(1, min(affinity, int(quota)))
+    phys = min(physical_cores(), threads)
     # thread k takes the lists that begin in [k, k + 1) / threads of the stream's bytes (a thread may get none): one
     # pthread each inside liboracle, a persistent decode buffer per thread, all looping until `seconds` have passed
     cut = np.searchsorted(list_byte_starts, [enc.size * k // threads for k in range(1, threads)])
     starts = [0] + [int(list_byte_starts[i]) if i < len(list_byte_starts) else enc.size for i in cut]
     wall, tot, nlists = od.time_stream_parallel(enc, starts, seconds)
     one["all_cores"] = {"value": round(tot / wall / 1e6, 2), "unit": "M ints/s", "cores": phys, "threads": threads,
+                        "host_logical_cpus": affinity, "host_physical_cores": physical_cores(), "cgroup_cpu_quota": quota,
                         "speedup_over_one_core": round(tot / wall / (ints / sec), 1),
-                        "sample": f"{threads} pthreads ({phys} physical cores), contiguous list ranges of equal stream bytes, "
+                        "sample": f"{threads} pthreads (the container's CPU quota: {quota if quota is not None else 'none'}; the host has "
+                                  f"{physical_cores()} physical cores / {affinity} threads), contiguous list ranges of equal stream bytes, "
                                   f"each looping over its range with its own reused buffer for {seconds:.0f}s: {nlists} list "
                                   f"decodes, {tot} postings in {wall:.2f}s wall (first thread start to last thread end)"}
     return one
@@ -266,6 +287,9 @@ def main():
     gaps = host.synth_gaps(p, lens, first_list_id=lo, threads=threads)
     coll = host.Collection(gaps, lens)
     log(rank, f"rank shard: lists [{lo},{hi}) = {coll.num_postings} postings, generated in {time.time() - t0:.1f}s")
+    if coll.num_postings == 0:
+        raise SystemExit(f"shard {shard_rank} of {shard_world} is empty: {postings * shard_world} postings are too few for "
+                         f"{shard_world} ranks (the longest list alone holds {int(lens_all.max())})")
 
     t0 = time.time()
     if rank == 0 and shard_rank != 0:
@@ -321,13 +345,13 @@ def main():
     # The unit table is prepared once (set-up, untimed — like the sidecar it is a property of the encoded collection,
     # SURVEY H3): which tiny units share a tile, the work items of the unit queue. A step is then ONE launch.
     # --per-launch-schedule: dint_decode_units instead, which rebuilds that schedule before every launch.
-    table = None
+    unit_table = None
     if not args.per_launch_schedule and hasattr(device, "UnitTable"):
-        table = device.UnitTable(d, enc_dev, units_dev, n_units, n_ints)
+        unit_table = device.UnitTable(d, enc_dev, units_dev, n_units, n_ints)
 
     def step():
-        if table is not None:
-            table.decode(out_dev, end_dev)
+        if unit_table is not None:
+            unit_table.decode(out_dev, end_dev)
         else:
             d.decode_units(enc_dev, units_dev, n_units, out_dev, end_dev)
 
@@ -475,7 +499,7 @@ def main():
                 "lists_per_gpu": int(np.count_nonzero(lens)) * R,
                 "units_per_gpu": n_units,
                 "unit_ints": args.unit_ints,
-                "schedule": "prepared unit table (set-up)" if table is not None else "per launch (timed)",
+                "schedule": "prepared unit table (set-up)" if unit_table is not None else "per launch (timed)",
                 "bits_per_int": round(bpi, 3),
                 **stream,
                 "hot_codewords_in_lds": int(info.hot_entries),
@@ -502,11 +526,15 @@ def main():
             },
             "cpu_baseline": cpu,
         }
-        print(json.dumps(line), flush=True)
+        result = json.dumps(line)
 
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # (printed last: RCCL writes a line of its own to stdout when it is first used)
+        sys.stdout.flush()
+        print(result, flush=True)
 
 
 if __name__ == "__main__":

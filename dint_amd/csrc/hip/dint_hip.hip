@@ -501,28 +501,22 @@ int dint_dict_create(int kind, const void* file_bytes, size_t len, int device, d
         dint_dict_destroy(dd);
         return st;
     }
-    // the kernel needs the whole 160 KiB of LDS
-    if (!hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_single_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsWords * 4)),
-                "hipFuncSetAttribute") ||
-        !hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_multi_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsWords * 4)),
-                "hipFuncSetAttribute") ||
-        !hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_single_index_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsWords * 4)),
-                "hipFuncSetAttribute") ||
-        !hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_multi_index_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsWords * 4)),
-                "hipFuncSetAttribute") ||
-        !hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_single_query_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsWords * 4)),
-                "hipFuncSetAttribute") ||
-        !hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_multi_query_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsWords * 4)),
-                "hipFuncSetAttribute") ||
-        !hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(&interpolative_tails_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(kTailLdsBytes)),
-                "hipFuncSetAttribute")) {
+    // the kernels need the whole 160 KiB of LDS: dynamic = what their static __shared__ variables leave of it
+    // (the query kernels carry a few static words for their round tail)
+    auto all_lds = [](const void* f, size_t want) {
+        hipFuncAttributes fa{};
+        if (!hip_ok(hipFuncGetAttributes(&fa, f), "hipFuncGetAttributes")) return false;
+        const size_t room = size_t(kLdsWords) * 4 - std::min<size_t>(fa.sharedSizeBytes, size_t(kLdsWords) * 4);
+        return hip_ok(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, int(std::min(want, room))), "hipFuncSetAttribute");
+    };
+    const size_t full = size_t(kLdsWords) * 4;
+    if (!all_lds(reinterpret_cast<const void*>(&decode_single_kernel), full) ||
+        !all_lds(reinterpret_cast<const void*>(&decode_multi_kernel), full) ||
+        !all_lds(reinterpret_cast<const void*>(&decode_single_index_kernel), full) ||
+        !all_lds(reinterpret_cast<const void*>(&decode_multi_index_kernel), full) ||
+        !all_lds(reinterpret_cast<const void*>(&decode_single_query_kernel), full) ||
+        !all_lds(reinterpret_cast<const void*>(&decode_multi_query_kernel), full) ||
+        !all_lds(reinterpret_cast<const void*>(&interpolative_tails_kernel), kTailLdsBytes)) {
         dint_dict_destroy(dd);
         return DINT_ERR_HIP;
     }
