@@ -455,6 +455,17 @@ __device__ __forceinline__ uint32_t allocate_cells(const tile_slots& t, uint32_t
     return readlane(incl, 63);
 }
 
+// A codeword's entry in the delta table: (its source - its first output position), both in u16 units, so that an output at
+// position p of the batch reads its integer from LDS byte address 2 (delta + p). `src2` is the source's LDS byte address
+// (even) with bit 0 set for a 32-bit exception literal; that bit travels in bit 31 of the entry (one rotate), the
+// expansion's address arithmetic — (delta + p) << 1 — sheds it, and an OR over a lane's four entries says whether any
+// of them needs its upper half. kDeltaBias keeps the entry non-negative (a source may lie below its position); the
+// expansion's position carries - kDeltaBias.
+constexpr uint32_t kDeltaBias = 4096;
+__device__ __forceinline__ uint32_t delta_word(uint32_t src2, uint32_t rel) {
+    return __builtin_rotateright32(src2, 1) - rel + kDeltaBias;
+}
+
 // ---- the flag / delta / rank-base tables of a batch: one LDS phase, written by the codewords' lanes ----
 // A flag bit at each codeword's first output (the flag words are zero: cleared at the end of the previous
 // batch), `source - position` by ordinal, and the rank base (codewords before the word, minus one) of every
@@ -472,7 +483,7 @@ __device__ __forceinline__ void tables_plain(const tile_slots& t, uint8_t* fw, u
     for (uint32_t k = 0; k != kSPL; ++k) {
         uint32_t* const fword = reinterpret_cast<uint32_t*>(fw + ((rel[k] >> 2) & 0x1F8u));
         __hip_atomic_fetch_or(fword, 1u << (rel[k] & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        d[k] = t.src2[k] - 2 * rel[k];
+        d[k] = delta_word(t.src2[k], rel[k]);
     }
     *reinterpret_cast<u32x4*>(delta + 16 * lane) = d;
     const uint32_t rel_end = t.obase + t.lsum;
@@ -498,7 +509,7 @@ __device__ __forceinline__ void tables_general(const tile_slots& t, uint8_t* fw,
         uint32_t* const fword = reinterpret_cast<uint32_t*>(fw + ((rel >> 2) & 0x1F8u));
         __hip_atomic_fetch_or(fword, lv & (1u << (rel & 31u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         const uint32_t ord = (lv & (ord0 + t.lord(k))) | (~lv & (kTileSlots + k));
-        *reinterpret_cast<uint32_t*>(delta + 4 * ord) = t.src2[k] - 2 * rel;
+        *reinterpret_cast<uint32_t*>(delta + 4 * ord) = delta_word(t.src2[k], rel);
     }
     if (inb) {
         const uint32_t rel_end = rel0 + t.lsum;
@@ -525,15 +536,16 @@ struct group_out {
 // non-temporal store; every source is an LDS byte address by now. Stores are whole 16-byte quads: the
 // descriptor clips what lies past the segment's n integers (range checking is per dword), and what a quad
 // writes past this batch's end inside the segment is rewritten by the batches and tiles that follow (same
-// wave, program order). WIDE: the batch may hold 32-bit exception literals — bit 0 of a delta (sources and
-// positions are even) says the upper half follows the lower one in the staging cell.
-template <uint32_t ROUNDS, uint32_t GROUPS, bool WIDE>
+// wave, program order). The batch may hold 32-bit exception literals — bit 31 of a delta entry (delta_word)
+// says the upper half follows the lower one in the staging cell.
+template <uint32_t ROUNDS, uint32_t GROUPS>
 __device__ __forceinline__ void expand_batch(uint32_t bt, uint32_t out_int, const uint8_t* lds_bytes, const uint8_t* fw,
                                              const uint8_t* delta, const __amdgpu_buffer_rsrc_t rs_out, uint32_t lane,
                                              uint32_t plus_one, const uint32_t* group_base, const group_out* go = nullptr) {
     // lane constants: this lane owns outputs 4*lane .. 4*lane+3 of every group
     const uint32_t sh = (4 * lane) & 31u;                 // bit position of its nibble in its flag word
     const uint32_t pair_byte = (lane >> 3) * 8;           // its {flag, base} pair inside a group's 8 pairs
+    const uint32_t posb = 4 * lane - kDeltaBias;          // its first output's position in a group, minus the entries' bias
     out_int = uniform(out_int);  // (the stores' scalar offset: an SGPR, not a loop over the values a VGPR might hold)
 #pragma unroll
     for (uint32_t rd = 0; rd != ROUNDS; ++rd) {
@@ -552,25 +564,21 @@ __device__ __forceinline__ void expand_batch(uint32_t bt, uint32_t out_int, cons
                     r[1] = base + uint32_t(__builtin_popcount(nib & 3u));
                     r[2] = base + uint32_t(__builtin_popcount(nib & 7u));
                     r[3] = base + uint32_t(__builtin_popcount(nib & 15u));
-                    const uint32_t pos2 = (rd * GROUPS + g) * 8 * kWave + 8 * lane;  // source byte position in the batch
-                    if (!WIDE) {
+                    const uint32_t gbyte = (rd * GROUPS + g) * 8 * kWave;  // the group's source byte position in the batch
+                    uint32_t d[4], ad[4];
+#pragma unroll
+                    for (int k = 0; k != 4; ++k) {
+                        d[k] = *reinterpret_cast<const uint32_t*>(delta + 4 * r[k]);
+                        ad[k] = (d[k] + posb) << 1;  // (bit 31 of the entry — "the upper half follows" — is shifted out)
+                        x[g][k] = *reinterpret_cast<const uint16_t*>(lds_bytes + ad[k] + gbyte + 2 * k);
+                    }
+                    // a 32-bit exception literal among the four (a few per tile): its upper half follows the lower one
+                    if (__builtin_expect(__ballot(int32_t(d[0] | d[1] | d[2] | d[3]) < 0) != 0, 0)) {
 #pragma unroll
                         for (int k = 0; k != 4; ++k) {
-                            const uint32_t ad = *reinterpret_cast<const uint32_t*>(delta + 4 * r[k]) + pos2 + 2 * k;
-                            x[g][k] = *reinterpret_cast<const uint16_t*>(lds_bytes + ad);
+                            const uint32_t hi = *reinterpret_cast<const uint16_t*>(lds_bytes + ad[k] + gbyte + 2 * k + 2);
+                            x[g][k] |= (int32_t(d[k]) < 0 ? hi : 0u) << 16;
                         }
-                    } else {
-                        uint32_t ad[4], wide = 0;
-#pragma unroll
-                        for (int k = 0; k != 4; ++k) {
-                            const uint32_t d = *reinterpret_cast<const uint32_t*>(delta + 4 * r[k]);
-                            wide |= (d & 1u) << k;
-                            ad[k] = (d & ~1u) + pos2 + 2 * k;
-                            x[g][k] = *reinterpret_cast<const uint16_t*>(lds_bytes + ad[k]);
-                        }
-#pragma unroll
-                        for (int k = 0; k != 4; ++k)
-                            if ((wide >> k) & 1u) x[g][k] |= uint32_t(*reinterpret_cast<const uint16_t*>(lds_bytes + ad[k] + 2)) << 16;
                     }
                 }
             }
@@ -630,10 +638,8 @@ __device__ __forceinline__ void expand_tile(const tile_slots& t, bool plain, boo
         SECTION(pf, 7, "7_rows2");
         before_gathers();
         SECTION(pf, 9, "9_expand");
-        if (__builtin_expect(wide, 0))
-            expand_batch<ROUNDS, GROUPS, true>(total, out_int0, lds_bytes, fw, delta, rs_out, lane, plus_one, group_base, go);
-        else
-            expand_batch<ROUNDS, GROUPS, false>(total, out_int0, lds_bytes, fw, delta, rs_out, lane, plus_one, group_base, go);
+        (void)wide;
+        expand_batch<ROUNDS, GROUPS>(total, out_int0, lds_bytes, fw, delta, rs_out, lane, plus_one, group_base, go);
         // the flag words go back to zero for the next batch (this wave's LDS operations execute in order)
         *reinterpret_cast<uint32_t*>(fw + 8 * lane) = 0;
         wave_lds_fence();
@@ -655,7 +661,7 @@ __device__ __forceinline__ void expand_tile(const tile_slots& t, bool plain, boo
         wave_lds_fence();
         if (done == 0) before_gathers();
         // (batches of lanes do not end on block boundaries: no docIDs here — the caller leaves such a tile as gaps)
-        expand_batch<ROUNDS, GROUPS, true>(bend - done, out_int0 + done, lds_bytes, fw, delta, rs_out, lane, plus_one, nullptr);
+        expand_batch<ROUNDS, GROUPS>(bend - done, out_int0 + done, lds_bytes, fw, delta, rs_out, lane, plus_one, nullptr);
         *reinterpret_cast<uint32_t*>(fw + 8 * lane) = 0;
         wave_lds_fence();
         done = bend;
