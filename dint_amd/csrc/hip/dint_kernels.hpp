@@ -62,6 +62,12 @@ namespace dint_dev {
 #ifndef DINT_FF_OPEN
 #define DINT_FF_OPEN 4  // bundles the multi-dictionary schedule keeps open while it packs a chunk (first fit)
 #endif
+#ifndef DINT_LEAN_SEGMENT
+#define DINT_LEAN_SEGMENT 0  // 1: decode_single_kernel's long units through decode_segment_lean (explicit vector-memory waits):
+                             // measured in round 3 — waves wait 27 % less on their counters, but the variant executes 24 %
+                             // more vector instructions and ends 2-3 % slower (profiles/r03_sq_lean.txt); kept as the
+                             // starting point for the next attempt, off by default
+#endif
 #ifndef DINT_GATHER_AUX
 #define DINT_GATHER_AUX 0  // cache policy of the metadata / row gathers (L2-resident tables, no reuse in L1)
 #endif
@@ -1010,16 +1016,417 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const w
     return tile_base + uint64_t(kSlotBytes) * end_slot;
 }
 
+// One dword now: load and wait in one asm statement (the rare paths of decode_segment_lean: a load the compiler keeps
+// books on, even on a path taken once in a million tiles, makes it place waits for "everything in flight" all over the
+// loop — where control flow merges, its books take the rare path's registers for pending).
+__device__ __forceinline__ uint32_t load_b32_now(const __amdgpu_buffer_rsrc_t rs, uint32_t byte_off) {
+    uint32_t v;
+    asm volatile("buffer_load_dword %0, %1, %2, 0 offen\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(byte_off), "s"(rs) : "memory");
+    return v;
+}
+// slow_stores for decode_segment_lean: the slots' values and the exception literals come in registers.
+__device__ __forceinline__ void slow_stores_lean(const wave_ctx& c, const tile_slots& t, uint32_t slowb, uint32_t pos0, uint32_t seg_n,
+                                                 const uint32_t (&sv)[kSPL], const uint32_t (&lit)[kSPL], uint32_t hot_base, uint32_t hot_k,
+                                                 uint32_t meta_base, const __amdgpu_buffer_rsrc_t rs_out) {
+    // the zeros must be in memory first: two stores of one wave to one address are only ordered by the wait
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (uint32_t k = 0; k != kSPL; ++k) {
+        if ((slowb >> k) & 1u) {
+            const uint32_t pos = pos0 + t.obase + t.off[k];
+            if (sv[k] < 2) {  // an exception whose literal found no staging cell
+                __builtin_amdgcn_raw_buffer_store_b32(lit[k], rs_out, 4 * pos, 0, DINT_STORE_AUX);
+            } else {
+                const uint32_t m = sv[k] < hot_k ? c.lds[hot_base + sv[k]] : load_b32_now(c.rs_dict, c.heads_base + 16 * (meta_base + sv[k]));
+                const uint32_t goff = load_b32_now(c.rs_dict, c.goff_base + 4 * (meta_base + sv[k]));
+                const uint32_t size = (m >> 24) + 1u, room = seg_n - pos;
+                const uint32_t cnt = size < room ? size : room;
+#pragma nounroll
+                for (uint32_t j = 0; j < cnt; ++j) {
+                    const uint32_t v = load_b32_now(c.rs_dict, c.gtable_base + 4 * (goff + j));
+                    __builtin_amdgcn_raw_buffer_store_b32(v, rs_out, 4 * (pos + j), 0, DINT_STORE_AUX);
+                }
+            }
+        }
+    }
+}
+
+// ---- the vroom kernel's segment: the same tile, its vector-memory traffic under EXPLICIT waits ---------------------
+// decode_segment above leaves the waits to the compiler, and every one it places is a wait for everything the wave
+// has in flight — the previous tile's stores, the far prefetch issued a moment ago (profiles/r03: a fifth of a wave's
+// cycles). gfx950 completes a wave's buffer loads and stores in issue order and s_waitcnt vmcnt(N) waits for all but
+// the N youngest (MI355X_MICROARCH.md), so here every load whose result outlives a phase is ISSUED in inline asm (the
+// compiler does not know its destination is pending and adds no wait of its own) and waited for by a counted
+// s_waitcnt, also in asm:
+//   C  heads of tile t+1 (L2), slots of tile t+3 (HBM)                 issued behind the previous tile's last wait
+//   A  expansion of tile t: gathers, S = ceil(total / 256) stores
+//   B  front end of tile t+1: vmcnt(S + 1) — the heads are there, the slots and the stores stay in flight —
+//      classification, sizes, cells, heads land, TAILS issued, flag / delta tables, vmcnt(0): the tails are there (and,
+//      in order, everything older: the slots have had a whole tile, the stores most of one), tails land
+// One loop iteration is C A B: nothing is in flight across the back-edge, no register that a load is writing is
+// live into a phi (a copy of such a register would read it too early; tools/check_inflight.py looks for any). A tile
+// that cannot be expanded in one batch, or holds a slow codeword, is finished inside B the old way.
+// Single-dictionary streams of 16-bit slots, plain d-gaps (no docIDs, no + 1): decode_single_kernel's long units.
+__device__ __forceinline__ void issue_b128(u32x4& q, const __amdgpu_buffer_rsrc_t rs, uint32_t byte_off) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(q) : "v"(byte_off), "s"(rs) : "memory");
+}
+__device__ __forceinline__ void reissue_b128(u32x4& q, const __amdgpu_buffer_rsrc_t rs, uint32_t byte_off) {  // into a register that holds a value
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "+v"(q) : "v"(byte_off), "s"(rs) : "memory");
+}
+__device__ __forceinline__ void issue_b64(u32x2& q, const __amdgpu_buffer_rsrc_t rs, uint32_t byte_off) {
+    asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(q) : "v"(byte_off), "s"(rs) : "memory");
+}
+__device__ __forceinline__ void issue_b32(uint32_t& q, const __amdgpu_buffer_rsrc_t rs, uint32_t byte_off, uint32_t) {
+    asm volatile("buffer_load_dword %0, %1, %2, 0 offen offset:16" : "=v"(q) : "v"(byte_off), "s"(rs) : "memory");
+}
+// "all but the N youngest are done", N = stores + 1 (1..5; more stores than four: the oldest are waited for too). ONE asm
+// statement, so that the four head registers are the same physical registers on every path to it (an asm per case
+// made the compiler copy them — in flight — into each case's own).
+__device__ __forceinline__ void wait_for_heads(head_regs& hr, uint32_t stores) {
+    asm volatile(
+        "s_cmp_ge_u32 %4, 4\n\t"
+        "s_cbranch_scc0 .Ldint_w3_%=\n\t"
+        "s_waitcnt vmcnt(5)\n\t"
+        "s_branch .Ldint_we_%=\n"
+        ".Ldint_w3_%=:\n\t"
+        "s_cmp_eq_u32 %4, 3\n\t"
+        "s_cbranch_scc0 .Ldint_w2_%=\n\t"
+        "s_waitcnt vmcnt(4)\n\t"
+        "s_branch .Ldint_we_%=\n"
+        ".Ldint_w2_%=:\n\t"
+        "s_cmp_eq_u32 %4, 2\n\t"
+        "s_cbranch_scc0 .Ldint_w1_%=\n\t"
+        "s_waitcnt vmcnt(3)\n\t"
+        "s_branch .Ldint_we_%=\n"
+        ".Ldint_w1_%=:\n\t"
+        "s_cmp_eq_u32 %4, 1\n\t"
+        "s_cbranch_scc0 .Ldint_w0_%=\n\t"
+        "s_waitcnt vmcnt(2)\n\t"
+        "s_branch .Ldint_we_%=\n"
+        ".Ldint_w0_%=:\n\t"
+        "s_waitcnt vmcnt(1)\n"
+        ".Ldint_we_%=:"
+        : "+v"(hr.q[0]), "+v"(hr.q[1]), "+v"(hr.q[2]), "+v"(hr.q[3])
+        : "s"(stores)
+        : "scc", "memory");
+}
+
+template <uint32_t ROUNDS, uint32_t GROUPS>
+__device__ __forceinline__ uint64_t decode_segment_lean(const decode_args& a, const wave_ctx& c, const dict_desc& dd, uint64_t in_off,
+                                                        uint32_t n, uint32_t* const out, prof_t& pf) {
+    SECTION(pf, 11, "segment_prologue");
+    constexpr uint32_t kCap = ROUNDS * GROUPS * 256;
+    constexpr uint32_t kTileBytes = 2 * kTileSlots;
+    n = uniform(n);
+    const uint16_t* const rows = c.cls;
+    const uint32_t lane = c.lane;
+    const uint32_t hot_k = dd.hot_k, hot_base = dd.hot_base, meta_base = dd.meta_base;
+    uint32_t* const out_u = reinterpret_cast<uint32_t*>(uniform64(reinterpret_cast<uint64_t>(out)));
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out_u, 0, int(n * 4), 0x00020000);
+    uint8_t* const lds_rw = reinterpret_cast<uint8_t*>(const_cast<uint32_t*>(c.lds));
+    const uint8_t* const lds_bytes = lds_rw;
+    uint8_t* const fw = reinterpret_cast<uint8_t*>(fw_of(c.scratch));
+    uint8_t* const delta = reinterpret_cast<uint8_t*>(delta_of(c.scratch));
+    const uint32_t stage_byte0 = uint32_t(reinterpret_cast<const uint8_t*>(stage_of(c.scratch)) - lds_rw);
+    const uint64_t in_off_u = uniform64(in_off);
+    // the stream from this segment's first byte on (a segment's bytes are far below 2 GB: at most 6 per integer)
+    const uint64_t seg_room = in_off_u <= a.enc_bytes ? a.enc_bytes - in_off_u : 0;
+    const __amdgpu_buffer_rsrc_t rs_seg = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(a.enc) + (in_off_u <= a.enc_bytes ? in_off_u : a.enc_bytes), 0,
+        int(seg_room < 0x7FFFFFF0ull ? uint32_t(seg_room) : 0x7FFFFFF0u), 0x00020000);
+    // a tile's slots, 8 bytes a lane: ONE buffer load whose result nobody looks at until a counted wait says so. A tile
+    // that is not wholly inside the buffer (the stream's last ones) reads zeros for the dwords past the end — the
+    // descriptor clips per dword — and is loaded again, exactly, behind that wait (fix_slots: load_lane_slots, which
+    // waits on the spot; one definition in flight, the other after it: no copy of a register a load is writing)
+    auto whole = [&](uint64_t tile_byte) { return tile_byte <= a.enc_bytes && a.enc_bytes - tile_byte >= kTileBytes; };  // wave-uniform
+    auto issue_slots = [&](u32x2& raw, uint64_t tile_byte) { issue_b64(raw, rs_seg, uint32_t(tile_byte - in_off_u) + 8 * lane); };
+    auto fix_slots = [&](u32x2& raw, uint64_t tile_byte) {
+        if (__builtin_expect(!whole(tile_byte), 0)) {
+            // (three ALIGNED dwords around the lane's 8 bytes — a buffer load's offset must be dword-aligned — from a
+            // descriptor that starts on a dword boundary at or below the buffer's last 2 GB and ends on the one at or above
+            // its end: a dword that holds a valid byte is read whole (it cannot cross a page), what lies past the
+            // buffer's end is masked off, a dword wholly past it reads as zero. Loads and their wait in ONE asm: a load
+            // the compiler keeps books on would make it wait for "everything" at unrelated places of the loop. Only the
+            // stream's last tiles come here.)
+            const uint64_t enc_addr = reinterpret_cast<uint64_t>(a.enc);
+            const uint64_t tail0 = a.enc_bytes > 0x7FFFF000ull ? a.enc_bytes - 0x7FFFF000ull : 0;
+            const uint64_t base_al = (enc_addr + tail0) & ~3ull;                      // descriptor base, dword-aligned
+            const uint32_t lead = uint32_t((enc_addr + tail0) - base_al);             // 0..3 bytes in front of the window
+            const uint32_t span = (lead + uint32_t(a.enc_bytes - tail0) + 3u) & ~3u;  // window bytes, whole dwords
+            const __amdgpu_buffer_rsrc_t rs_tail = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(base_al), 0, int(span), 0x00020000);
+            const uint64_t byte_off = tile_byte + 8ull * lane;  // (a tile starts at most 3 tiles past the end)
+            const uint64_t rel64 = byte_off - tail0 + lead;
+            const uint32_t rel = rel64 < 0x7FFFFFE0ull ? uint32_t(rel64) : 0x7FFFFFE0u;
+            const uint32_t dw = rel & ~3u;
+            uint32_t w0, w1, w2;
+            asm volatile(
+                "buffer_load_dword %0, %3, %4, 0 offen\n\t"
+                "buffer_load_dword %1, %3, %4, 0 offen offset:4\n\t"
+                "buffer_load_dword %2, %3, %4, 0 offen offset:8\n\t"
+                "s_waitcnt vmcnt(0)"
+                : "=&v"(w0), "=&v"(w1), "=&v"(w2)
+                : "v"(dw), "s"(rs_tail)
+                : "memory");
+            const uint32_t sh = rel & 3u;
+            uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, sh), hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
+            // bytes of this lane that lie inside the buffer: 0..8
+            const uint64_t left = byte_off < a.enc_bytes ? a.enc_bytes - byte_off : 0;
+            const uint32_t vb = left < 8 ? uint32_t(left) : 8u;
+            lo = vb >= 4 ? lo : (vb == 0 ? 0u : lo & ((1u << (8 * vb)) - 1u));
+            hi = vb >= 8 ? hi : (vb <= 4 ? 0u : hi & ((1u << (8 * (vb - 4))) - 1u));
+            raw.x = lo, raw.y = hi;
+        }
+    };
+    auto issue_heads = [&](const u32x2& raw, head_regs& hr) {
+#pragma unroll
+        for (uint32_t k = 0; k != kSPL; ++k) {
+            const uint32_t sv = ((k < 2 ? raw.x : raw.y) >> (16 * (k & 1))) & 0xFFFFu;
+            if (sv >= hot_k) issue_b128(hr.q[k], c.rs_dict, c.heads_base + 16 * (meta_base + sv));
+        }
+    };
+
+    // slots of the tile whose front end runs next (A), of the one after (B), of the one after that (C: in flight
+    // from phase C of an iteration to the vmcnt(0) of the next one's phase B)
+    u32x2 rawA, rawB;
+    uint64_t slot_byte = in_off_u;  // first byte of the tile whose slots were requested last (wave-uniform)
+    issue_slots(rawA, slot_byte);
+    slot_byte += kTileBytes;
+    issue_slots(rawB, slot_byte);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(rawA), "+v"(rawB) : : "memory");
+    fix_slots(rawA, in_off_u);
+    fix_slots(rawB, slot_byte);
+
+    uint32_t produced = 0, carry = 0, end_slot = 0;
+    uint64_t tile_base = in_off_u;  // byte offset of slot 0 of the tile in the front end (wave-uniform)
+    bool pending = false;           // a tile's tables are built, its expansion is due
+    uint32_t pend_total = 0, pend_out = 0;
+    bool more = true;
+    MARK("loop_top");
+    for (;;) {
+        // ---- C: behind the previous tile's last wait — this tile's heads (its slots: rawA), the slots two tiles on ----
+        head_regs hr;   // (deliberately uninitialised: each register is written and read under the same lane predicate)
+        uint32_t t3[kSPL];
+        u32x2 rawC;
+        if (more) {
+            SECTION(pf, 3, "3_prefetch");
+            issue_heads(rawA, hr);
+            slot_byte += kTileBytes;
+            issue_slots(rawC, slot_byte);
+        }
+        // ---- A: expansion of the tile whose tables phase B built -------------------------------------------------
+        uint32_t stores = 0;
+        if (pending) {
+            SECTION(pf, 9, "9_expand");
+            expand_batch<ROUNDS, GROUPS>(pend_total, pend_out, lds_bytes, fw, delta, rs_out, lane, 0u, nullptr);
+            *reinterpret_cast<uint32_t*>(fw + 8 * lane) = 0;  // the flag words go back to zero for the next tile
+            wave_lds_fence();
+            stores = (pend_total + 255u) >> 8;
+            pending = false;
+        }
+        if (!more) break;
+
+        // ---- B: front end of the next tile ---------------------------------------------------------------------
+        SECTION(pf, 1, "1_classify");
+        tile_regs cur;
+        cur.s[0] = rawA.x & 0xFFFFu, cur.s[1] = rawA.x >> 16, cur.s[2] = rawA.y & 0xFFFFu, cur.s[3] = rawA.y >> 16;
+        meta_regs mr;
+#pragma unroll
+        for (uint32_t k = 0; k != kSPL; ++k) mr.h[k] = c.lds[hot_base + (cur.s[k] < hot_k ? cur.s[k] : hot_k)];
+        // the heads are there: all but the slots requested behind them and this iteration's stores may stay in flight
+        // (fewer than counted is only a longer wait)
+        wait_for_heads(hr, uniform(stores));
+#pragma unroll
+        for (uint32_t k = 0; k != kSPL; ++k) cur.m[k] = cur.s[k] < hot_k ? mr.h[k] : hr.q[k].x;
+        // ---- classification: table lookup, repeated until the lane-to-lane carries agree (decode_segment, step 1) ----
+        const bool tile_slow_dict = __ballot(((cur.m[0] | cur.m[1] | cur.m[2] | cur.m[3]) & kMetaSlow) != 0) != 0;
+        uint32_t row;
+        {
+            uint32_t lo = 0;
+#pragma unroll
+            for (uint32_t k = kSPL; k-- != 0;) lo = 3 * lo + (2u - (cur.s[k] < 2 ? cur.s[k] : 2u));
+            uint32_t st_in = lane == 0 ? carry : 0u;
+            for (;;) {
+                row = rows[st_in * 81 + lo];
+                uint32_t prev = from_lane_below((row >> 8) & 7u);
+                if (lane == 0) prev = carry;
+                if (__ballot(prev != st_in) == 0) break;
+                st_in = prev;
+            }
+        }
+        const uint32_t carry_out = readlane((row >> 8) & 7u, 63);
+
+        SECTION(pf, 2, "2_sizes");
+        tile_slots t;
+        uint32_t e[kSPL];  // size - 1
+        uint32_t excval[kSPL];
+        {
+            // the literal behind an exception header: the next slot, or the next two (the lane's own, the next lane's
+            // first two, the next tile's first two for lane 63 — read with every lane enabled)
+            const uint32_t next0 = readlane(rawB.x, 0);
+            uint32_t nlo = from_lane_above(rawA.x);
+            if (lane == 63) nlo = next0;
+            uint32_t v[kSPL + 2];
+#pragma unroll
+            for (uint32_t k = 0; k != kSPL; ++k) v[k] = cur.s[k];
+            v[kSPL] = nlo & 0xFFFFu;
+            v[kSPL + 1] = nlo >> 16;
+#pragma unroll
+            for (uint32_t k = 0; k != kSPL; ++k) excval[k] = v[k] == 0 ? v[k + 1] : (v[k + 1] | (v[k + 2] << 16));
+        }
+#pragma unroll
+        for (uint32_t k = 0; k != kSPL; ++k) {
+            const bool pay = ((row >> k) & 1u) != 0, exc = ((row >> (4 + k)) & 1u) != 0;
+            e[k] = pay ? ~0u : (exc ? 0u : cur.m[k] >> 24);  // payload slots decode to nothing and take nothing
+            t.need[k] = pay ? 0u : (exc ? 1u : __builtin_amdgcn_ubfe(cur.m[k], 20, 2));
+            t.src2[k] = cur.m[k] & kMetaOffMask;  // hot: the image (runs: the zeros); cold, slow: zero for now
+        }
+        t.off[0] = 0;
+        t.off[1] = e[0] + 1u;
+        t.off[2] = t.off[1] + e[1] + 1u;
+        t.off[3] = t.off[2] + e[2] + 1u;
+        t.lsum = t.off[3] + e[3] + 1u;
+        const uint32_t hdrcnt = uint32_t(__builtin_popcount(~row & 15u));
+        const uint32_t mine = (hdrcnt << 24) | t.lsum;
+        const uint32_t pincl = wave_inclusive_sum(mine);
+        t.obase = (pincl & 0xFFFFFFu) - t.lsum;  // first output of this lane's codewords
+        const uint32_t remaining = n - produced;
+        t.total = readlane(pincl, 63) & 0xFFFFFFu;
+        const bool last_tile = t.total >= remaining;
+        t.row = row;
+        t.liveb = ~row & 15u;
+        t.rbase = (pincl - mine) >> 24;  // ordinal of this lane's first codeword (exclusive before the shift: the inclusive count can be 256)
+        t.nlive = hdrcnt;
+        uint32_t slowb = 0;  // bit k: slot k goes through slow_stores
+        if (last_tile) {     // last tile of the segment: clamp, and find where the stream ends (decode_segment)
+            t.total = remaining;
+            uint32_t cand = 0, lb = 0;
+            t.nlive = 0;
+#pragma unroll
+            for (uint32_t k = 0; k != kSPL; ++k) {
+                const uint32_t pos = t.obase + t.off[k];
+                const bool act = ((t.liveb >> k) & 1u) != 0 && pos < remaining;
+                if (act) {
+                    const bool exc = ((row >> (4 + k)) & 1u) != 0;
+                    cand = kSPL * lane + k + 1 + (exc ? cur.s[k] + 1 : 0u);
+                    ++t.nlive;
+                    lb |= 1u << k;
+                } else {
+                    t.need[k] = 0;
+                }
+            }
+            t.liveb = lb;
+            t.lsum = t.obase < remaining ? (t.obase + t.lsum < remaining ? t.lsum : remaining - t.obase) : 0u;
+            const uint64_t am = __ballot(cand != 0);
+            end_slot = readlane(cand, 63u - uint32_t(__builtin_clzll(am | 1ull)));
+        }
+        if (tile_slow_dict) {
+#pragma unroll
+            for (uint32_t k = 0; k != kSPL; ++k) slowb |= ((cur.m[k] >> 22) & (t.liveb >> k) & ~(row >> (4 + k)) & 1u) << k;
+        }
+        // ---- staging cells: exception literals and cold codewords ----------------------------------------------
+        uint32_t cell_addr[kSPL];
+        const uint32_t cells = allocate_cells(t, stage_byte0, cell_addr);
+        if (cells > kStageCells) {  // wave-uniform; what lies past the staging area turns slow: zeros, then slow_stores
+#pragma unroll
+            for (uint32_t k = 0; k != kSPL; ++k)
+                if (t.need[k] != 0 && cell_addr[k] + 16 * t.need[k] > stage_byte0 + 16 * kStageCells) {
+                    t.need[k] = 0;
+                    slowb |= 1u << k;
+                }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k != kSPL; ++k) t.src2[k] = t.need[k] != 0 ? cell_addr[k] : t.src2[k];
+#pragma unroll
+        for (uint32_t k = 0; k != kSPL; ++k)
+            if (((row >> (4 + k)) & 1u) != 0 && t.need[k] != 0) {  // an exception's literal into its cell, 32 bits
+                *reinterpret_cast<uint32_t*>(lds_rw + cell_addr[k]) = excval[k];
+                t.src2[k] |= excval[k] > 0xFFFFu ? 1u : 0u;
+                t.need[k] = 0;  // (no row lands there)
+            }
+        const bool tile_slow = __ballot(slowb != 0) != 0;
+        const bool tile_big = __ballot((t.need[0] | t.need[1] | t.need[2] | t.need[3]) > 1u) != 0;
+        SECTION(pf, 8, "8_wait");
+        // the heads of this tile's cold codewords into their cells (the integers start 4 bytes in); the tails of the
+        // large ones requested: integers 6..13 into the same registers, 14 and 15 into one more each
+#pragma unroll
+        for (uint32_t k = 0; k != kSPL; ++k)
+            if (t.need[k] != 0) {
+                *reinterpret_cast<u32x4*>(lds_rw + t.src2[k]) = hr.q[k];
+                t.src2[k] += 4;
+            }
+        if (tile_big) {
+#pragma unroll
+            for (uint32_t k = 0; k != kSPL; ++k) {
+                const uint32_t tail = c.tails_base + 32 * (meta_base + cur.s[k]);
+                if (t.need[k] > 1u) reissue_b128(hr.q[k], c.rs_dict, tail);
+                if (t.need[k] > 2u) issue_b32(t3[k], c.rs_dict, tail, 16);
+            }
+        }
+        auto land_tails = [&]() {
+            // everything in flight is there: the tails, and — older — the far slots and the previous tile's stores
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(hr.q[0]), "+v"(hr.q[1]), "+v"(hr.q[2]), "+v"(hr.q[3]), "+v"(t3[0]), "+v"(t3[1]), "+v"(t3[2]), "+v"(t3[3]), "+v"(rawC)
+                         :
+                         : "memory");
+            if (tile_big) {
+#pragma unroll
+                for (uint32_t k = 0; k != kSPL; ++k) {
+                    if (t.need[k] > 1u) *reinterpret_cast<u32x4*>(lds_rw + t.src2[k] + 12) = hr.q[k];
+                    if (t.need[k] > 2u) *reinterpret_cast<uint32_t*>(lds_rw + t.src2[k] + 28) = t3[k];
+                }
+            }
+            wave_lds_fence();
+        };
+        SECTION(pf, 4, "4_tables");
+        const bool one_batch = !tile_slow && t.total <= kCap;  // wave-uniform
+        if (__builtin_expect(one_batch, 1)) {
+            tables_general(t, fw, delta, t.lsum != 0, 0u, 0u);
+            wave_lds_fence();
+        }
+        SECTION(pf, 7, "7_rows2");
+        land_tails();
+        if (__builtin_expect(one_batch, 1)) {
+            pending = true;
+            pend_total = t.total;
+            pend_out = produced;
+        } else {
+            // more than one expansion batch (a tile full of long runs), or a slow codeword: finished here, the old way
+            expand_tile<ROUNDS, GROUPS>(t, false, true, 0u, nullptr, produced, c.lds, c.scratch, rs_out, lane, pf, []() {});
+            SECTION(pf, 10, "10_tail");
+            if (tile_slow) slow_stores_lean(c, t, slowb, produced, n, cur.s, excval, hot_base, hot_k, meta_base, rs_out);
+        }
+        SECTION(pf, 5, "10_rotate");
+        produced += t.total;
+        carry = carry_out;
+        more = produced < n;
+        if (more) tile_base += kTileBytes;
+
+        if (more) {  // (phase C's slots are there: land_tails waited for everything)
+            fix_slots(rawC, slot_byte);
+            rawA = rawB;
+            rawB = rawC;
+        }
+    }
+    SECTION(pf, 13, "epilogue");
+    return tile_base + 2ull * end_slot;
+}
+
 // A single-dictionary unit (rectangular or packed: the streams are byte-identical,
 // only the dictionary source layout differed on the host) is one 16-bit segment.
 // (Chaining such units like the blocks of a multi-dictionary unit — the next unit's first tiles
 // requested while the current one is expanded — was measured in round 1: 5 % slower.)
+template <bool LEAN>
 __device__ __forceinline__ void decode_unit_single(const decode_args& a, const wave_ctx& c, uint64_t unit_index, prof_t& pf) {
     const dint_unit* up = a.units + unit_index;
     const uint64_t out_off = up->out_off;
     const uint32_t n = up->n;
     if (n == 0 || n > kMaxUnitInts || out_off > a.out_capacity || a.out_capacity - out_off < n || (a.only_full && n != 256)) return;
     const uint64_t in_off = uniform64(up->in_off);
+    if (LEAN) {  // (the vroom kernel: plain d-gaps)
+        const uint64_t end = decode_segment_lean<kRounds, kGroups>(a, c, a.dict.first, in_off, n, a.out + out_off, pf);
+        if (a.end_off && c.lane == 0) a.end_off[unit_index] = end;
+        return;
+    }
     chain_io ch{};
     const uint64_t end = decode_segment<16, kRounds, kGroups, 0>(a, c, a.dict.first, in_off, n, a.out + out_off, ch, pf, false, false,
                                                                  a.unit_base ? a.unit_base + unit_index : nullptr,
@@ -1790,6 +2197,35 @@ __device__ __forceinline__ void decode_query_page(const decode_args& a, const wa
 // The kernel arguments arrive as one 16-register scalar load; left like that, the compiler keeps (and under
 // pressure spills and reloads) the whole tuple whenever one field is live — 66 v_readlane per tile in
 // round 1. Passing every field through an empty asm makes each its own 32- or 64-bit scalar.
+// Every pointer of the arguments is to GLOBAL memory, which own_scalars' empty asm hides from the compiler: said again,
+// what goes through them is global_load / global_store / global_atomic. As FLAT operations — "LDS or memory, may return
+// out of order" — each makes the compiler's next wait for anything a wait for everything in flight, and the work
+// queue's ticket (an atomic asked for before a unit is decoded, looked at after) is in flight all through a unit.
+// (The vroom single-dictionary kernel only: its segment counts its own waits. The others leave their waits to the
+// compiler, which places them worse with typed pointers: measured, -3 %.)
+template <class T>
+__device__ __forceinline__ T* known_global(T* p) {
+    typedef __attribute__((address_space(1))) T global_T;
+    return (T*)(global_T*)(uintptr_t)p;
+}
+__device__ __forceinline__ void all_global(decode_args& a) {
+    a.dict.tables = known_global(a.dict.tables);
+    a.dict.lds_image = known_global(a.dict.lds_image);
+    a.dict.descs = known_global(a.dict.descs);
+    a.enc = known_global(a.enc);
+    a.units = known_global(a.units);
+    a.out = known_global(a.out);
+    a.end_off = known_global(a.end_off);
+    a.queue = known_global(a.queue);
+    a.sched = known_global(a.sched);
+    a.items = known_global(a.items);
+    a.item_cnt = known_global(a.item_cnt);
+    a.n_items = known_global(a.n_items);
+    a.urec = known_global(a.urec);
+    a.cbase = known_global(a.cbase);
+    a.chunk_queue = known_global(a.chunk_queue);
+    a.spans = known_global(a.spans);
+}
 __device__ __forceinline__ decode_args own_scalars(const decode_args& k) {
     decode_args a = k;
     asm volatile("" : "+s"(a.dict.tables), "+s"(a.dict.lds_image), "+s"(a.dict.descs), "+s"(a.dict.tables_bytes),
@@ -1809,6 +2245,7 @@ template <bool MULTI, bool INDEX, bool QUERY = false>
 __device__ __forceinline__ void decode_kernel_body(const decode_args& kernarg, const query_pages* qp = nullptr,
                                                    const round_tail* tail = nullptr) {
     decode_args a_ = own_scalars(kernarg);
+    if (DINT_LEAN_SEGMENT && !INDEX && !MULTI && !QUERY) all_global(a_);
     if (!INDEX) {
         a_.unit_base = nullptr;
         a_.gaps_left = nullptr;
@@ -1921,7 +2358,7 @@ __device__ __forceinline__ void decode_kernel_body(const decode_args& kernarg, c
         } else {
             const uint32_t cc = uniform(a.sched ? uint32_t(a.item_cnt[w]) : 1u);
             if (__builtin_expect(cc > 1, 0)) decode_bundle_listed<false>(a, c, uu, cc, pf);
-            else decode_unit_single(a, c, uu, pf);
+            else decode_unit_single<DINT_LEAN_SEGMENT && !INDEX && !QUERY>(a, c, uu, pf);
         }
         asm volatile("" : "+v"(ticket));
         w = take(ticket);
