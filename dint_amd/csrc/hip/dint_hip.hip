@@ -31,6 +31,20 @@ constexpr uint32_t kBlock = 256;       // util.hpp:35
 
 thread_local std::string g_hip_error;
 
+// Every device / pinned allocation of the library goes through these: dint_debug_alloc_count says how many were made
+// (the host-pointer calls — one block, one list at a time — must make none once their workspace is warm).
+std::atomic<uint64_t> g_alloc_count{0};
+template <class T>
+hipError_t counted_malloc(T** p, size_t bytes) {
+    g_alloc_count.fetch_add(1, std::memory_order_relaxed);
+    return hipMalloc(reinterpret_cast<void**>(p), bytes);
+}
+template <class T>
+hipError_t counted_host_malloc(T** p, size_t bytes) {
+    g_alloc_count.fetch_add(1, std::memory_order_relaxed);
+    return hipHostMalloc(reinterpret_cast<void**>(p), bytes, hipHostMallocDefault);
+}
+
 bool hip_ok(hipError_t e, const char* what) {
     if (e == hipSuccess) return true;
     g_hip_error = std::string(what) + ": " + hipGetErrorString(e);
@@ -136,6 +150,28 @@ bool parse_packed(reader r, bool multi, parsed_dict& d) {
 
 }  // namespace
 
+// A bundle schedule kept by its owner (a prepared block table: the same units launch after launch) instead of
+// being rebuilt, three small kernels, before every launch.
+struct sched_cache {
+    void* d_mem = nullptr;  // (the layout launch_decode gives a slot's schedule workspace)
+    size_t mem_bytes = 0;
+    bool valid = false;
+    // What the schedule was built from. bundle_schedule_kernel bakes this launch's bounds checks (stream bytes, output
+    // capacity) and, multi-dictionary streams, the blocks' selector bytes into the unit records: a later launch with
+    // another dictionary, stream, unit table, span table or a SMALLER capacity must not reuse them — it rebuilds.
+    const void* dict = nullptr;
+    const void* d_enc = nullptr;
+    const void* d_units = nullptr;
+    const void* d_spans = nullptr;
+    size_t enc_bytes = 0, n_units = 0, out_capacity = 0;
+    uint32_t only_full = 0;
+    bool matches(const void* dd, const void* enc, size_t eb, const void* units, size_t n, const void* spans, size_t cap,
+                 uint32_t full) const {
+        return valid && dict == dd && d_enc == enc && enc_bytes == eb && d_units == units && n_units == n && d_spans == spans &&
+               cap >= out_capacity && only_full == full;
+    }
+};
+
 struct dint_dict {
     int kind = 0;
     int device = 0;
@@ -175,6 +211,15 @@ struct dint_dict {
     bool slot_used[kQueueSlots] = {};
     std::atomic<uint32_t> next_slot{0};
     std::mutex launch_mutex;
+    // The host-pointer calls (dint_decode_list_host, dint_decode_block_host, dint_list_cache_create): a stream of their
+    // own, one pinned and one device buffer that only grow — after the first call of a size no allocation, no
+    // device-wide synchronisation, one wait for the stream per call. One call at a time per dictionary (host_mutex).
+    std::mutex host_mutex;
+    hipStream_t host_stream = nullptr;
+    uint8_t* h_pin = nullptr;
+    uint8_t* d_host = nullptr;
+    size_t h_pin_cap = 0, d_host_cap = 0;
+    sched_cache host_sched;  // (memory only: the schedule of a host-pointer call is rebuilt every time — other list, same addresses)
 };
 
 namespace {
@@ -338,7 +383,7 @@ int stage_dictionary(dint_dict& dd, parsed_dict const& pd) {
     const size_t b_tables = b_heads + b_tails + b_goff + b_table;
     const size_t total = (b_tables + b_image + b_descs + two_mb - 1) / two_mb * two_mb;
     if (b_tables >= (size_t(1) << 31)) return DINT_ERR_FORMAT;
-    HIP_TRY(hipMalloc(&dd.d_block, total));
+    HIP_TRY(counted_malloc(&dd.d_block, total));
     uint8_t* base = static_cast<uint8_t*>(dd.d_block);
     dd.d_image = reinterpret_cast<uint32_t*>(base + b_tables);
     dd.d_descs = reinterpret_cast<dint_dev::dict_desc*>(base + b_tables + b_image);
@@ -346,7 +391,7 @@ int stage_dictionary(dint_dict& dd, parsed_dict const& pd) {
     HIP_TRY(hipMemcpy(base + b_heads, tails.data(), tails.size() * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(base + b_heads + b_tails, goff.data(), goff.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(base + b_heads + b_tails + b_goff, gtable.data(), gtable.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&dd.d_queues, size_t(dint_dict::kQueueSlots) * (kQueueShards + 1) * kQueueStride * 4));
+    HIP_TRY(counted_malloc(&dd.d_queues, size_t(dint_dict::kQueueSlots) * (kQueueShards + 1) * kQueueStride * 4));
     for (uint32_t i = 0; i != dint_dict::kQueueSlots; ++i) {
         HIP_TRY(hipEventCreateWithFlags(&dd.slot_done[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreate(&dd.slot_start[i]));
@@ -396,7 +441,7 @@ struct device_buffer {  // grow-only workspace
         p = nullptr;
         cap = 0;
         const size_t want = std::max<size_t>(need + need / 2, 1024);
-        if (!hip_ok(hipMalloc(&p, want * sizeof(T)), "hipMalloc(workspace)")) return false;
+        if (!hip_ok(counted_malloc(&p, want * sizeof(T)), "counted_malloc(workspace)")) return false;
         cap = want;
         return true;
     }
@@ -533,6 +578,10 @@ void dint_dict_destroy(dint_dict* dd) {
     for (auto e : dd->slot_stop)
         if (e) (void)hipEventDestroy(e);
     if (dd->d_queues) (void)hipFree(dd->d_queues);
+    if (dd->host_stream) (void)hipStreamDestroy(dd->host_stream);
+    if (dd->h_pin) (void)hipHostFree(dd->h_pin);
+    if (dd->d_host) (void)hipFree(dd->d_host);
+    if (dd->host_sched.d_mem) (void)hipFree(dd->host_sched.d_mem);
     for (auto p : dd->d_sched)
         if (p) (void)hipFree(p);
     for (auto e : dd->slot_done)
@@ -649,28 +698,6 @@ int dint_index_stream(const dint_dict* dd, const uint8_t* enc, size_t enc_bytes,
     return DINT_OK;
 }
 
-// A bundle schedule kept by its owner (a prepared block table: the same units launch after launch) instead of
-// being rebuilt, three small kernels, before every launch.
-struct sched_cache {
-    void* d_mem = nullptr;  // (the layout launch_decode gives a slot's schedule workspace)
-    size_t mem_bytes = 0;
-    bool valid = false;
-    // What the schedule was built from. bundle_schedule_kernel bakes this launch's bounds checks (stream bytes, output
-    // capacity) and, multi-dictionary streams, the blocks' selector bytes into the unit records: a later launch with
-    // another dictionary, stream, unit table, span table or a SMALLER capacity must not reuse them — it rebuilds.
-    const void* dict = nullptr;
-    const void* d_enc = nullptr;
-    const void* d_units = nullptr;
-    const void* d_spans = nullptr;
-    size_t enc_bytes = 0, n_units = 0, out_capacity = 0;
-    uint32_t only_full = 0;
-    bool matches(const void* dd, const void* enc, size_t eb, const void* units, size_t n, const void* spans, size_t cap,
-                 uint32_t full) const {
-        return valid && dict == dd && d_enc == enc && enc_bytes == eb && d_units == units && n_units == n && d_spans == spans &&
-               cap >= out_capacity && only_full == full;
-    }
-};
-
 // workspace of a schedule: [unit records 16 B x n][chunk bases 16 B x chunks][items u32 x n][block counts/offsets u32 x blocks]
 // [n_items u32][sched u8 x n][item counts u8 x n]
 struct sched_layout {
@@ -715,7 +742,7 @@ static int build_schedule(const dint_dict* dd, const uint8_t* d_enc, size_t enc_
         if (cache->d_mem) HIP_TRY(hipFree(cache->d_mem));  // (hipFree waits for the launches that read it)
         cache->d_mem = nullptr;
         cache->mem_bytes = 0;
-        HIP_TRY(hipMalloc(&cache->d_mem, L.need));
+        HIP_TRY(counted_malloc(&cache->d_mem, L.need));
         cache->mem_bytes = L.need;
     }
     L.place(cache->d_mem);
@@ -822,7 +849,7 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
                 mut->d_sched[ss] = nullptr;
                 mut->sched_cap[ss] = 0;
                 const size_t want = L.need + L.need / 4 + 4096;
-                HIP_TRY(hipMalloc(&mut->d_sched[ss], want));
+                HIP_TRY(counted_malloc(&mut->d_sched[ss], want));
                 mut->sched_cap[ss] = want;
             }
             L.place(mut->d_sched[ss]);
@@ -986,7 +1013,7 @@ int block_table_prepare(dint_block_table& t, const dint_block_ref* d_blocks, siz
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
     const size_t b_units = up(n_blocks * sizeof(dint_unit)), b_u32 = up((n_blocks + 1) * 4), b_u64 = up(n_blocks * 8),
                  b_u8 = up(n_blocks);
-    HIP_TRY(hipMalloc(&t.d_ws, 2 * b_units + 4 * b_u32 + b_u64 + b_u8));
+    HIP_TRY(counted_malloc(&t.d_ws, 2 * b_units + 4 * b_u32 + b_u64 + b_u8));
     uint8_t* p = static_cast<uint8_t*>(t.d_ws);
     t.d_units = reinterpret_cast<dint_unit*>(p), p += b_units;
     t.d_funits = reinterpret_cast<dint_unit*>(p), p += b_units;
@@ -1083,7 +1110,7 @@ int dint_block_table_create(const dint_dict* docs_dict, const dint_block_ref* bl
     }
     dint_block_ref* d_blocks = nullptr;
     int st = DINT_ERR_HIP;
-    if (hip_ok(hipSetDevice(t->device), "hipSetDevice") && hip_ok(hipMalloc(&d_blocks, n_blocks * sizeof(dint_block_ref)), "hipMalloc(blocks)") &&
+    if (hip_ok(hipSetDevice(t->device), "hipSetDevice") && hip_ok(counted_malloc(&d_blocks, n_blocks * sizeof(dint_block_ref)), "counted_malloc(blocks)") &&
         hip_ok(hipMemcpy(d_blocks, blocks, n_blocks * sizeof(dint_block_ref), hipMemcpyHostToDevice), "hipMemcpy(blocks)")) {
         t->owns_blocks = true;
         st = block_table_prepare(*t, d_blocks, n_blocks, index_bytes, nullptr);
@@ -1195,12 +1222,12 @@ int dint_query_index_create(const dint_dict* docs_dict, const uint8_t* d_index, 
     for (size_t l = 0; l != n_lists; ++l) qi->list_first[l + 1] += qi->list_first[l];
     const size_t nb = std::max<size_t>(1, n_blocks);
     bool ok = hip_ok(hipSetDevice(docs_dict->device), "hipSetDevice") &&
-              hip_ok(hipMalloc(&qi->d_blocks, nb * sizeof(dint_block_ref)), "hipMalloc(blocks)") &&
-              hip_ok(hipMalloc(&qi->d_block_max, nb * 4), "hipMalloc(block_max)") &&
-              hip_ok(hipMalloc(&qi->d_needed, 2 * nb * 4), "hipMalloc(needed)") &&  // (two sets of each: round_tail)
-              hip_ok(hipMalloc(&qi->d_rank, 2 * nb * 4), "hipMalloc(rank)") &&
-              hip_ok(hipMalloc(&qi->d_touched, 2 * nb * 4), "hipMalloc(touched)") &&
-              hip_ok(hipMalloc(&qi->d_n_touched, 8), "hipMalloc(n_touched)") &&  // {touched blocks, short pages} of a round
+              hip_ok(counted_malloc(&qi->d_blocks, nb * sizeof(dint_block_ref)), "counted_malloc(blocks)") &&
+              hip_ok(counted_malloc(&qi->d_block_max, nb * 4), "counted_malloc(block_max)") &&
+              hip_ok(counted_malloc(&qi->d_needed, 2 * nb * 4), "counted_malloc(needed)") &&  // (two sets of each: round_tail)
+              hip_ok(counted_malloc(&qi->d_rank, 2 * nb * 4), "counted_malloc(rank)") &&
+              hip_ok(counted_malloc(&qi->d_touched, 2 * nb * 4), "counted_malloc(touched)") &&
+              hip_ok(counted_malloc(&qi->d_n_touched, 8), "counted_malloc(n_touched)") &&  // {touched blocks, short pages} of a round
               hip_ok(hipMemset(qi->d_needed, 0, 2 * nb * 4), "hipMemset(needed)");
     if (ok && n_blocks)
         ok = hip_ok(hipMemcpy(qi->d_blocks, blocks, n_blocks * sizeof(dint_block_ref), hipMemcpyHostToDevice), "hipMemcpy(blocks)") &&
@@ -1416,7 +1443,7 @@ static int and_queries_impl(dint_query_index* qi, const dint_dict* freqs_dict, c
         qi->h_stage = nullptr;
         qi->h_stage_cap = 0;
         const size_t want = stage_bytes + stage_bytes / 2 + 4096;
-        HIP_TRY(hipHostMalloc(&qi->h_stage, want, hipHostMallocDefault));
+        HIP_TRY(counted_host_malloc(&qi->h_stage, want));
         qi->h_stage_cap = want;
         qi->d_stage = nullptr;  // the same memory as the kernels see it (the last probe writes the results there)
         if (hipHostGetDevicePointer(&qi->d_stage, qi->h_stage, 0) != hipSuccess) qi->d_stage = nullptr;
@@ -1680,10 +1707,10 @@ int dint_count_ngrams(int device, int multi, const uint32_t* d_gaps, uint64_t n_
         cleanup();
         return st;
     };
-    if (!hip_ok(hipMalloc(&d_keys, slots * 8), "hipMalloc(ngram keys)") || !hip_ok(hipMalloc(&d_info, slots * 8), "hipMalloc(ngram info)") ||
-        !hip_ok(hipMalloc(&d_freq, slots * 4), "hipMalloc(ngram freq)") || !hip_ok(hipMalloc(&d_n_out, 8), "hipMalloc") ||
-        !hip_ok(hipMalloc(&d_overflow, 4), "hipMalloc") || !hip_ok(hipMalloc(&d_chunk_start, n_chunks * 8), "hipMalloc(chunks)") ||
-        !hip_ok(hipMalloc(&d_chunk_n, n_chunks * 4), "hipMalloc(chunks)"))
+    if (!hip_ok(counted_malloc(&d_keys, slots * 8), "counted_malloc(ngram keys)") || !hip_ok(counted_malloc(&d_info, slots * 8), "counted_malloc(ngram info)") ||
+        !hip_ok(counted_malloc(&d_freq, slots * 4), "counted_malloc(ngram freq)") || !hip_ok(counted_malloc(&d_n_out, 8), "hipMalloc") ||
+        !hip_ok(counted_malloc(&d_overflow, 4), "hipMalloc") || !hip_ok(counted_malloc(&d_chunk_start, n_chunks * 8), "counted_malloc(chunks)") ||
+        !hip_ok(counted_malloc(&d_chunk_n, n_chunks * 4), "counted_malloc(chunks)"))
         return fail(DINT_ERR_HIP);
     if (!hip_ok(hipMemset(d_keys, 0, slots * 8), "hipMemset") || !hip_ok(hipMemset(d_info, 0xFF, slots * 8), "hipMemset") ||
         !hip_ok(hipMemset(d_freq, 0, slots * 4), "hipMemset") || !hip_ok(hipMemset(d_n_out, 0, 8), "hipMemset") ||
@@ -1705,7 +1732,7 @@ int dint_count_ngrams(int device, int multi, const uint32_t* d_gaps, uint64_t n_
     if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, e0, e1);
     // the occupied slots, compacted (first a count, then the entries)
     const uint64_t cap = std::min<uint64_t>(ngrams, slots);
-    if (!hip_ok(hipMalloc(&d_out, cap * sizeof(dint_ngram)), "hipMalloc(ngram entries)")) return fail(DINT_ERR_HIP);
+    if (!hip_ok(counted_malloc(&d_out, cap * sizeof(dint_ngram)), "counted_malloc(ngram entries)")) return fail(DINT_ERR_HIP);
     hipLaunchKernelGGL(collect_ngrams_kernel, dim3(uint32_t((slots + 255) / 256)), dim3(256), 0, nullptr, t, d_out, d_n_out, cap);
     unsigned long long n_out = 0;
     if (!hip_ok(hipGetLastError(), "collect_ngrams_kernel") || !hip_ok(hipMemcpy(&n_out, d_n_out, 8, hipMemcpyDeviceToHost), "hipMemcpy"))
@@ -1721,7 +1748,7 @@ int dint_count_ngrams(int device, int multi, const uint32_t* d_gaps, uint64_t n_
                 if (p) (void)hipFree(p);
             return fail(st);
         };
-        if (!hip_ok(hipMalloc(&d_at_least, 32), "hipMalloc") || !hip_ok(hipMalloc(&d_counts, 64), "hipMalloc")) return fail2(DINT_ERR_HIP);
+        if (!hip_ok(counted_malloc(&d_at_least, 32), "hipMalloc") || !hip_ok(counted_malloc(&d_counts, 64), "hipMalloc")) return fail2(DINT_ERR_HIP);
         uint32_t lo[8], hi[8], mid[8];
         for (int c = 0; c != 8; ++c) lo[c] = 1, hi[c] = 0xFFFFFFFFu;  // invariant: count(>= lo) >= top_k or lo == 1
         const uint32_t grid = uint32_t((n_out + 255) / 256);
@@ -1745,7 +1772,7 @@ int dint_count_ngrams(int device, int multi, const uint32_t* d_gaps, uint64_t n_
             }
         }
         if (!hip_ok(hipMemcpy(d_at_least, lo, 32, hipMemcpyHostToDevice), "hipMemcpy") || !hip_ok(hipMemset(d_n_out, 0, 8), "hipMemset") ||
-            !hip_ok(hipMalloc(&d_sel, n_out * sizeof(dint_ngram)), "hipMalloc(selected ngrams)"))
+            !hip_ok(counted_malloc(&d_sel, n_out * sizeof(dint_ngram)), "counted_malloc(selected ngrams)"))
             return fail2(DINT_ERR_HIP);
         hipLaunchKernelGGL(keep_at_least_kernel, dim3(grid), dim3(256), 0, nullptr, d_out, uint64_t(n_out), d_at_least, d_sel, d_n_out);
         unsigned long long n_sel = 0;
@@ -1784,61 +1811,78 @@ int dint_last_kernel_ms(const dint_dict* dd, float* ms) {
     return DINT_OK;
 }
 
-int dint_decode_block_host(const dint_dict* dd, const uint8_t* in, size_t in_bytes, uint32_t* out, uint32_t sum_of_values,
+// The host-pointer calls' workspace: `pin_bytes` of pinned and `dev_bytes` of device memory, grown when too small
+// (the caller holds host_mutex).
+static int host_workspace(dint_dict* dd, size_t pin_bytes, size_t dev_bytes) {
+    HIP_TRY(hipSetDevice(dd->device));
+    if (!dd->host_stream) HIP_TRY(hipStreamCreateWithFlags(&dd->host_stream, hipStreamNonBlocking));
+    if (dd->h_pin_cap < pin_bytes) {
+        HIP_TRY(hipStreamSynchronize(dd->host_stream));
+        if (dd->h_pin) HIP_TRY(hipHostFree(dd->h_pin));
+        dd->h_pin = nullptr, dd->h_pin_cap = 0;
+        const size_t want = std::max<size_t>(pin_bytes + pin_bytes / 2, 64 << 10);
+        HIP_TRY(counted_host_malloc(&dd->h_pin, want));
+        dd->h_pin_cap = want;
+    }
+    if (dd->d_host_cap < dev_bytes) {
+        HIP_TRY(hipStreamSynchronize(dd->host_stream));
+        if (dd->d_host) HIP_TRY(hipFree(dd->d_host));
+        dd->d_host = nullptr, dd->d_host_cap = 0;
+        const size_t want = std::max<size_t>(dev_bytes + dev_bytes / 2, 64 << 10);
+        HIP_TRY(counted_malloc(&dd->d_host, want));
+        dd->d_host_cap = want;
+    }
+    return DINT_OK;
+}
+
+static size_t up256(size_t b) { return (b + 255) / 256 * 256; }
+
+int dint_decode_block_host(const dint_dict* dd_c, const uint8_t* in, size_t in_bytes, uint32_t* out, uint32_t sum_of_values,
                            size_t n, size_t* consumed) {
-    if (!dd || (!in && in_bytes) || (!out && n)) return DINT_ERR_ARG;
+    if (!dd_c || (!in && in_bytes) || (!out && n)) return DINT_ERR_ARG;
     if (consumed) *consumed = 0;
     if (n == 0) return DINT_OK;
     if (n > kBlock || in_bytes < 1) return DINT_ERR_ARG;
-    if (n == kBlock) return dint_decode_list_host(dd, in, in_bytes, out, n, consumed);  // one unit of one block
+    if (n == kBlock) return dint_decode_list_host(dd_c, in, in_bytes, out, n, consumed);  // one unit of one block
     // a short block: binary interpolative, one lane of the tails kernel
-    const size_t padded = in_bytes + 8;  // the bit reader fetches whole words
-    HIP_TRY(hipSetDevice(dd->device));
-    uint8_t* d_in = nullptr;
-    uint8_t* d_ws = nullptr;  // [block_ref][docs_end u64][end u64][tails u32][n_tails u32][out u32 x 256]
-    int st = DINT_OK;
-    auto cleanup = [&] {
-        if (d_in) (void)hipFree(d_in);
-        if (d_ws) (void)hipFree(d_ws);
-    };
-#define TRY_OR_CLEAN(call)            \
-    do {                              \
-        if (!hip_ok((call), #call)) { \
-            cleanup();                \
-            return DINT_ERR_HIP;      \
-        }                             \
-    } while (0)
-    TRY_OR_CLEAN(hipMalloc(&d_in, padded));
-    TRY_OR_CLEAN(hipMemset(d_in, 0, padded));
-    TRY_OR_CLEAN(hipMemcpy(d_in, in, in_bytes, hipMemcpyHostToDevice));
-    struct {
+    dint_dict* dd = const_cast<dint_dict*>(dd_c);
+    std::lock_guard<std::mutex> lock(dd->host_mutex);
+    struct head {
         dint_block_ref ref;
         uint64_t docs_end, end;
         uint32_t tail, n_tails;
-    } h{};
+    };
+    const size_t padded = in_bytes + 8;  // the bit reader fetches whole words
+    const size_t b_head = up256(sizeof(head)), b_in = up256(padded), b_out = up256(kBlock * 4);
+    int st = host_workspace(dd, b_head + b_in + b_out, b_head + b_in + b_out);
+    if (st != DINT_OK) return st;
+    hipStream_t s = dd->host_stream;
+    // pinned: [head][block bytes, zero padded] -> device (one copy); device -> pinned: [head (the end offset)][integers]
+    head* h = reinterpret_cast<head*>(dd->h_pin);
+    *h = head{};
     const bool vbyte_sum = sum_of_values == 0xFFFFFFFFu;
-    h.ref = dint_block_ref{0, 0, uint32_t(n), 0, uint32_t(sum_of_values + uint32_t(n - 1)), 0};  // max - base - (n - 1) = the sum
-    h.n_tails = 1;
-    TRY_OR_CLEAN(hipMalloc(&d_ws, sizeof h + kBlock * 4));
-    TRY_OR_CLEAN(hipMemcpy(d_ws, &h, sizeof h, hipMemcpyHostToDevice));
-    auto* d_ref = reinterpret_cast<dint_block_ref*>(d_ws);
-    auto* d_docs_end = reinterpret_cast<uint64_t*>(d_ws + offsetof(decltype(h), docs_end));
-    auto* d_end = reinterpret_cast<uint64_t*>(d_ws + offsetof(decltype(h), end));
-    auto* d_tail = reinterpret_cast<uint32_t*>(d_ws + offsetof(decltype(h), tail));
-    auto* d_n_tails = reinterpret_cast<uint32_t*>(d_ws + offsetof(decltype(h), n_tails));
-    auto* d_out = reinterpret_cast<uint32_t*>(d_ws + sizeof h);
-    hipLaunchKernelGGL(interpolative_tails_kernel, dim3(1), dim3(64), kTailLdsBytes, nullptr, d_in, uint64_t(padded), d_ref,
+    h->ref = dint_block_ref{0, 0, uint32_t(n), 0, uint32_t(sum_of_values + uint32_t(n - 1)), 0};  // max - base - (n - 1) = the sum
+    h->n_tails = 1;
+    std::memcpy(dd->h_pin + b_head, in, in_bytes);
+    std::memset(dd->h_pin + b_head + in_bytes, 0, b_in - in_bytes);
+    HIP_TRY(hipMemcpyAsync(dd->d_host, dd->h_pin, b_head + b_in, hipMemcpyHostToDevice, s));
+    uint8_t* const d_in = dd->d_host + b_head;
+    auto* d_ref = reinterpret_cast<dint_block_ref*>(dd->d_host);
+    auto* d_docs_end = reinterpret_cast<uint64_t*>(dd->d_host + offsetof(head, docs_end));
+    auto* d_end = reinterpret_cast<uint64_t*>(dd->d_host + offsetof(head, end));
+    auto* d_tail = reinterpret_cast<uint32_t*>(dd->d_host + offsetof(head, tail));
+    auto* d_n_tails = reinterpret_cast<uint32_t*>(dd->d_host + offsetof(head, n_tails));
+    auto* d_out = reinterpret_cast<uint32_t*>(dd->d_host + b_head + b_in);
+    hipLaunchKernelGGL(interpolative_tails_kernel, dim3(1), dim3(64), kTailLdsBytes, s, d_in, uint64_t(padded), d_ref,
                        vbyte_sum ? d_docs_end : static_cast<uint64_t*>(nullptr), d_tail, d_n_tails, d_out, uint64_t(kBlock),
                        d_end, 0u);
-    TRY_OR_CLEAN(hipGetLastError());
-    TRY_OR_CLEAN(hipDeviceSynchronize());
-    uint64_t end_off = 0;
-    TRY_OR_CLEAN(hipMemcpy(out, d_out, n * 4, hipMemcpyDeviceToHost));
-    TRY_OR_CLEAN(hipMemcpy(&end_off, d_end, 8, hipMemcpyDeviceToHost));
-    if (consumed) *consumed = size_t(end_off);
-#undef TRY_OR_CLEAN
-    cleanup();
-    return st;
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(dd->h_pin, dd->d_host, b_head, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(dd->h_pin + b_head, d_out, n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::memcpy(out, dd->h_pin + b_head, n * 4);
+    if (consumed) *consumed = size_t(h->end);
+    return DINT_OK;
 }
 
 int dint_last_kernel_clock_mhz(const dint_dict* dd, float* mhz) {
@@ -1943,51 +1987,190 @@ int dint_stream_stats_get(const dint_dict* dd, const uint8_t* enc, size_t enc_by
     return DINT_OK;
 }
 
-int dint_decode_list_host(const dint_dict* dd, const uint8_t* in, size_t in_bytes, uint32_t* out, size_t n,
+int dint_decode_list_host(const dint_dict* dd_c, const uint8_t* in, size_t in_bytes, uint32_t* out, size_t n,
                           size_t* consumed) {
-    if (!dd || (!in && in_bytes) || (!out && n)) return DINT_ERR_ARG;
+    if (!dd_c || (!in && in_bytes) || (!out && n)) return DINT_ERR_ARG;
     if (consumed) *consumed = 0;
     if (n == 0) return DINT_OK;
     if (in_bytes < 2 || n > DINT_MAX_UNIT_INTS) return DINT_ERR_ARG;
+    dint_dict* dd = const_cast<dint_dict*>(dd_c);
+    std::lock_guard<std::mutex> lock(dd->host_mutex);
     const size_t padded = in_bytes < 8 ? 8 : in_bytes;
-    HIP_TRY(hipSetDevice(dd->device));
-    uint8_t* d_enc = nullptr;
-    uint32_t* d_out = nullptr;
-    dint_unit* d_unit = nullptr;
-    uint64_t* d_end = nullptr;
-    int st = DINT_OK;
-    auto cleanup = [&] {
-        if (d_enc) (void)hipFree(d_enc);
-        if (d_out) (void)hipFree(d_out);
-        if (d_unit) (void)hipFree(d_unit);
-        if (d_end) (void)hipFree(d_end);
-    };
-#define TRY_OR_CLEAN(call)                 \
-    do {                                   \
-        if (!hip_ok((call), #call)) {      \
-            cleanup();                     \
-            return DINT_ERR_HIP;           \
-        }                                  \
-    } while (0)
-    TRY_OR_CLEAN(hipMalloc(&d_enc, padded));
-    TRY_OR_CLEAN(hipMemset(d_enc, 0, padded));
-    TRY_OR_CLEAN(hipMalloc(&d_out, n * 4));
-    TRY_OR_CLEAN(hipMalloc(&d_unit, sizeof(dint_unit)));
-    TRY_OR_CLEAN(hipMalloc(&d_end, 8));
+    // pinned / device: [unit 24 B | end offset 8 B][stream, zero padded][integers]
+    const size_t b_head = 256, b_in = up256(padded), b_out = up256(n * 4);
+    int st = host_workspace(dd, b_head + std::max(b_in, b_out), b_head + b_in + b_out);
+    if (st != DINT_OK) return st;
+    hipStream_t s = dd->host_stream;
     dint_unit u{0, 0, uint32_t(n), 0};
-    TRY_OR_CLEAN(hipMemcpy(d_enc, in, in_bytes, hipMemcpyHostToDevice));
-    TRY_OR_CLEAN(hipMemcpy(d_unit, &u, sizeof u, hipMemcpyHostToDevice));
-    st = dint_decode_units(dd, d_enc, padded, d_unit, 1, d_out, n, d_end, nullptr);
-    if (st == DINT_OK) {
-        TRY_OR_CLEAN(hipDeviceSynchronize());
-        uint64_t end_off = 0;
-        TRY_OR_CLEAN(hipMemcpy(out, d_out, n * 4, hipMemcpyDeviceToHost));
-        TRY_OR_CLEAN(hipMemcpy(&end_off, d_end, 8, hipMemcpyDeviceToHost));
-        if (consumed) *consumed = size_t(end_off);
+    std::memcpy(dd->h_pin, &u, sizeof u);
+    std::memset(dd->h_pin + sizeof u, 0, 8);
+    std::memcpy(dd->h_pin + b_head, in, in_bytes);
+    std::memset(dd->h_pin + b_head + in_bytes, 0, b_in - in_bytes);
+    HIP_TRY(hipMemcpyAsync(dd->d_host, dd->h_pin, b_head + b_in, hipMemcpyHostToDevice, s));
+    auto* d_unit = reinterpret_cast<dint_unit*>(dd->d_host);
+    auto* d_end = reinterpret_cast<uint64_t*>(dd->d_host + sizeof(dint_unit));
+    uint8_t* const d_enc = dd->d_host + b_head;
+    auto* d_out = reinterpret_cast<uint32_t*>(dd->d_host + b_head + b_in);
+    st = dint_decode_units(dd, d_enc, padded, d_unit, 1, d_out, n, d_end, s);
+    if (st != DINT_OK) return st;
+    HIP_TRY(hipMemcpyAsync(dd->h_pin, dd->d_host, b_head, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(dd->h_pin + b_head, d_out, n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::memcpy(out, dd->h_pin + b_head, n * 4);
+    uint64_t end_off = 0;
+    std::memcpy(&end_off, dd->h_pin + sizeof(dint_unit), 8);
+    if (consumed) *consumed = size_t(end_off);
+    return DINT_OK;
+}
+
+// ---- a posting list decoded once, its blocks then served from host memory ---------------------------------------
+struct dint_list_cache {
+    size_t n_blocks = 0, list_bytes = 0;
+    bool with_freqs = false;
+    std::vector<dint_block_ref> blocks;   // in_off: the docs part's offset inside the list
+    std::vector<uint64_t> docs_end, freqs_end;
+    std::vector<uint32_t> gaps, freqs;    // what Coder::decode returns for the docs / freqs parts, blocks back to back
+};
+
+int dint_list_cache_create(const dint_dict* docs_c, const dint_dict* freqs_dict, const uint8_t* list, size_t list_bytes,
+                           dint_list_cache** out) {
+    if (!docs_c || !list || !out || list_bytes < 2) return DINT_ERR_ARG;
+    *out = nullptr;
+    if (freqs_dict && (freqs_dict->device != docs_c->device || freqs_dict->kind != docs_c->kind)) return DINT_ERR_ARG;
+    dint_block_ref* blocks = nullptr;
+    size_t n_blocks = 0;
+    uint64_t total = 0;
+    const uint64_t zero = 0;
+    int st = dint_index_posting_lists(list, list_bytes, &zero, 1, &blocks, &n_blocks, &total);
+    if (st != DINT_OK) return st;
+    auto* c = new (std::nothrow) dint_list_cache();
+    if (!c) {
+        dint_free(blocks);
+        return DINT_ERR_NOMEM;
     }
-#undef TRY_OR_CLEAN
-    cleanup();
-    return st;
+    c->n_blocks = n_blocks;
+    c->list_bytes = list_bytes;
+    c->with_freqs = freqs_dict != nullptr;
+    c->blocks.assign(blocks, blocks + n_blocks);
+    dint_free(blocks);
+    c->docs_end.assign(n_blocks, 0);
+    c->freqs_end.assign(n_blocks, 0);
+    c->gaps.assign(total, 0);
+    if (freqs_dict) c->freqs.assign(total, 0);
+    dint_dict* dd = const_cast<dint_dict*>(docs_c);
+    dint_dict* fdd = const_cast<dint_dict*>(freqs_dict);
+    // (the docs dictionary's workspace and both dictionaries' schedule memory: one call at a time on either)
+    std::unique_lock<std::mutex> lock(dd->host_mutex, std::defer_lock), flock;
+    if (fdd && fdd != dd) {
+        flock = std::unique_lock<std::mutex>(fdd->host_mutex, std::defer_lock);
+        std::lock(lock, flock);
+    } else {
+        lock.lock();
+    }
+    // device: [index, padded][blocks][units][funits][docs ends][freqs ends][spans][fspans][tails + count][docs out][freqs out]
+    const size_t padded = list_bytes + 16;
+    const size_t b_index = up256(padded), b_blocks = up256(n_blocks * sizeof(dint_block_ref)), b_units = up256(n_blocks * sizeof(dint_unit)),
+                 b_u64 = up256(n_blocks * 8), b_u32 = up256((n_blocks + 1) * 4), b_out = up256(size_t(total) * 4);
+    const size_t dev_bytes = b_index + b_blocks + 2 * b_units + 2 * b_u64 + 3 * b_u32 + 2 * b_out;
+    const size_t pin_bytes = std::max(b_index + b_blocks, 2 * b_u64 + 2 * b_out);
+    auto fail = [&](int code) {
+        delete c;
+        return code;
+    };
+    st = host_workspace(dd, pin_bytes, dev_bytes);
+    if (st != DINT_OK) return fail(st);
+    hipStream_t s = dd->host_stream;
+    uint8_t* p = dd->d_host;
+    uint8_t* const d_index = p;
+    p += b_index;
+    auto* d_blocks = reinterpret_cast<dint_block_ref*>(p);
+    p += b_blocks;
+    auto* d_units = reinterpret_cast<dint_unit*>(p);
+    p += b_units;
+    auto* d_funits = reinterpret_cast<dint_unit*>(p);
+    p += b_units;
+    auto* d_dends = reinterpret_cast<uint64_t*>(p);
+    p += b_u64;
+    auto* d_fends = reinterpret_cast<uint64_t*>(p);
+    p += b_u64;
+    auto* d_spans = reinterpret_cast<uint32_t*>(p);
+    p += b_u32;
+    auto* d_fspans = reinterpret_cast<uint32_t*>(p);
+    p += b_u32;
+    auto* d_tails = reinterpret_cast<uint32_t*>(p);
+    p += b_u32;
+    auto* d_gaps = reinterpret_cast<uint32_t*>(p);
+    p += b_out;
+    auto* d_freqs = reinterpret_cast<uint32_t*>(p);
+    std::memcpy(dd->h_pin, list, list_bytes);
+    std::memset(dd->h_pin + list_bytes, 0, b_index - list_bytes);
+    std::memcpy(dd->h_pin + b_index, c->blocks.data(), n_blocks * sizeof(dint_block_ref));
+    auto hip = [&](hipError_t e, const char* what) { return hip_ok(e, what) ? DINT_OK : DINT_ERR_HIP; };
+    if ((st = hip(hipMemcpyAsync(dd->d_host, dd->h_pin, b_index + b_blocks, hipMemcpyHostToDevice, s), "hipMemcpyAsync(list)")) != DINT_OK) return fail(st);
+    if ((st = hip(hipMemsetAsync(d_dends, 0, 2 * b_u64, s), "hipMemsetAsync")) != DINT_OK) return fail(st);
+    if ((st = hip(hipMemsetAsync(d_tails + n_blocks, 0, 4, s), "hipMemsetAsync")) != DINT_OK) return fail(st);
+    const uint32_t tb = 256, grid = uint32_t((n_blocks + tb - 1) / tb);
+    const uint32_t tgrid = uint32_t((n_blocks + kTailLanes - 1) / kTailLanes);  // (sized for "every block is short": at most one is)
+    hipLaunchKernelGGL(collect_tails_kernel, dim3(grid), dim3(tb), 0, s, d_blocks, uint64_t(n_blocks), d_tails, d_tails + n_blocks);
+    hipLaunchKernelGGL(blocks_to_units_kernel, dim3(grid), dim3(tb), 0, s, d_blocks, static_cast<const uint64_t*>(nullptr), uint64_t(n_blocks),
+                       uint64_t(padded), d_units, d_spans, static_cast<uint32_t*>(nullptr));
+    // docs parts as the Coder returns them (gaps), where they end; then the freqs parts from there
+    dd->host_sched.valid = false;
+    st = launch_decode(docs_c, d_index, padded, d_units, n_blocks, d_gaps, total, d_dends, s, 1, d_spans, 0, nullptr, nullptr, &dd->host_sched);
+    if (st != DINT_OK) return fail(st);
+    hipLaunchKernelGGL(interpolative_tails_kernel, dim3(tgrid), dim3(64), kTailLdsBytes, s, d_index, uint64_t(padded), d_blocks,
+                       static_cast<const uint64_t*>(nullptr), d_tails, d_tails + n_blocks, d_gaps, uint64_t(total), d_dends, 0u);
+    if (freqs_dict) {
+        hipLaunchKernelGGL(blocks_to_units_kernel, dim3(grid), dim3(tb), 0, s, d_blocks, d_dends, uint64_t(n_blocks), uint64_t(padded), d_funits,
+                           d_fspans, static_cast<uint32_t*>(nullptr));
+        fdd->host_sched.valid = false;  // (the freqs dictionary's own schedule memory)
+        st = launch_decode(freqs_dict, d_index, padded, d_funits, n_blocks, d_freqs, total, d_fends, s, 1, d_fspans, 0, nullptr, nullptr,
+                           &fdd->host_sched);
+        if (st != DINT_OK) return fail(st);
+        hipLaunchKernelGGL(interpolative_tails_kernel, dim3(tgrid), dim3(64), kTailLdsBytes, s, d_index, uint64_t(padded), d_blocks, d_dends, d_tails,
+                           d_tails + n_blocks, d_freqs, uint64_t(total), d_fends, 0u);
+    }
+    if ((st = hip(hipGetLastError(), "launch")) != DINT_OK) return fail(st);
+    uint8_t* hp = dd->h_pin;
+    if ((st = hip(hipMemcpyAsync(hp, d_dends, 2 * b_u64, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(ends)")) != DINT_OK) return fail(st);
+    if ((st = hip(hipMemcpyAsync(hp + 2 * b_u64, d_gaps, (freqs_dict ? 2 : 1) * b_out, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(out)")) != DINT_OK)
+        return fail(st);
+    if ((st = hip(hipStreamSynchronize(s), "hipStreamSynchronize")) != DINT_OK) return fail(st);
+    std::memcpy(c->docs_end.data(), hp, n_blocks * 8);
+    std::memcpy(c->freqs_end.data(), hp + b_u64, n_blocks * 8);
+    std::memcpy(c->gaps.data(), hp + 2 * b_u64, size_t(total) * 4);
+    if (freqs_dict) std::memcpy(c->freqs.data(), hp + 2 * b_u64 + b_out, size_t(total) * 4);
+    *out = c;
+    return DINT_OK;
+}
+
+void dint_list_cache_destroy(dint_list_cache* c) { delete c; }
+
+int dint_list_cache_decode(const dint_list_cache* c, size_t in_offset, uint32_t* out, size_t n, size_t* consumed) {
+    if (!c || (!out && n)) return DINT_ERR_ARG;
+    if (consumed) *consumed = 0;
+    // the block whose docs part starts at in_offset, else the one whose freqs part does (where its docs part ended)
+    auto it = std::lower_bound(c->blocks.begin(), c->blocks.end(), in_offset,
+                               [](const dint_block_ref& b, size_t off) { return b.in_off < off; });
+    size_t b = size_t(it - c->blocks.begin());
+    if (b < c->n_blocks && c->blocks[b].in_off == in_offset) {
+        if (n != c->blocks[b].n) return DINT_ERR_ARG;
+        std::memcpy(out, c->gaps.data() + c->blocks[b].out_off, n * 4);
+        if (consumed) *consumed = size_t(c->docs_end[b] - in_offset);
+        return DINT_OK;
+    }
+    if (!c->with_freqs || b == 0) return DINT_ERR_ARG;
+    b -= 1;  // the last block that starts before in_offset
+    if (c->docs_end[b] != in_offset || n != c->blocks[b].n) return DINT_ERR_ARG;
+    std::memcpy(out, c->freqs.data() + c->blocks[b].out_off, n * 4);
+    if (consumed) *consumed = size_t(c->freqs_end[b] - in_offset);
+    return DINT_OK;
+}
+
+int dint_debug_alloc_count(uint64_t* count) {
+    if (!count) return DINT_ERR_ARG;
+    *count = g_alloc_count.load();
+    return DINT_OK;
 }
 
 #ifdef DINT_PROFILE
@@ -2000,8 +2183,8 @@ extern "C" {
 int dint_debug_wave_scan(const uint32_t* in64, uint32_t* out64) {
     if (!in64 || !out64) return DINT_ERR_ARG;
     uint32_t *d_in = nullptr, *d_out = nullptr;
-    HIP_TRY(hipMalloc(&d_in, 256));
-    HIP_TRY(hipMalloc(&d_out, 256));
+    HIP_TRY(counted_malloc(&d_in, 256));
+    HIP_TRY(counted_malloc(&d_out, 256));
     HIP_TRY(hipMemcpy(d_in, in64, 256, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(debug_wave_scan_kernel, dim3(1), dim3(64), 0, nullptr, d_in, d_out);
     HIP_TRY(hipGetLastError());

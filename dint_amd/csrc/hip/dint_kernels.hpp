@@ -752,11 +752,14 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const w
         raw1 = chain_tile(narrow, ch.data, 1, lane);
         slot_byte += kTileBytes;  // the pipeline is one tile shorter: tile t+2's slots are requested in tile t
     } else {
-        unpack_slots(narrow, load_lane_slots(narrow, a.enc, slot_byte, lane, a.enc_bytes), cur);
+        // (all three requested before the first is looked at: one trip to memory, not two)
+        uint64_t raw0 = load_lane_slots(narrow, a.enc, slot_byte, lane, a.enc_bytes);
         slot_byte += kTileBytes;
         raw1 = load_lane_slots(narrow, a.enc, slot_byte, lane, a.enc_bytes);
         slot_byte += kTileBytes;
         raw2 = load_lane_slots(narrow, a.enc, slot_byte, lane, a.enc_bytes);
+        asm volatile("" : "+v"(raw0), "+v"(raw1), "+v"(raw2));
+        unpack_slots(narrow, raw0, cur);
     }
     ch.valid = false;
     request_metas(c, dd.hot_base, hot_k, dd.meta_base, cur, mr, hr);

@@ -158,19 +158,81 @@ uint8_t const* decode_block(Dictionary const& dict, uint8_t const* in, uint8_t c
 }
 }  // namespace detail
 
+// A posting list decoded ONCE on the device, for the lifetime of a scope object: every Coder::decode call of this thread
+// whose `in` lies inside the list is then a memcpy from host memory (dint_list_cache, include/dint_hip.h). The
+// reference's document_enumerator decodes lazily, one 256-posting block per Coder::decode call
+// (dict_posting_list.hpp:126-147 next_geq, :298-301, :313-315): per call the device path costs a launch sequence and
+// a stream wait, tens of microseconds — a cursor that skips through a list pays that per touched block, or this once.
+// Where the reference constructs an enumerator over a list (dict_posting_list.hpp:90-107) the binding adds one line:
+//     typename Coder::list_scope scope(docs_dict, &freqs_dict, list_begin, list_end);
+// Scopes nest (a query holds one per term); the innermost list that contains `in` serves the call.
+class list_scope_base {
+public:
+    list_scope_base(list_scope_base const&) = delete;
+    list_scope_base& operator=(list_scope_base const&) = delete;
+    ~list_scope_base() {
+        head() = m_prev;
+        dint_list_cache_destroy(m_cache);
+    }
+    // the scope of this thread whose list holds `in`, or null
+    static list_scope_base const* find(uint8_t const* in) {
+        for (list_scope_base const* s = head(); s; s = s->m_prev)
+            if (in >= s->m_begin && in < s->m_end) return s;
+        return nullptr;
+    }
+    uint8_t const* decode(uint8_t const* in, uint32_t* out, size_t n) const {
+        size_t consumed = 0;
+        check(dint_list_cache_decode(m_cache, size_t(in - m_begin), out, n, &consumed), "dint_list_cache_decode");
+        return in + consumed;
+    }
+    uint8_t const* end() const { return m_end; }
+
+protected:
+    list_scope_base(dint_dict const* docs, dint_dict const* freqs, uint8_t const* begin, uint8_t const* end) : m_begin(begin), m_end(end) {
+        check(dint_list_cache_create(docs, freqs, begin, size_t(end - begin), &m_cache), "dint_list_cache_create");
+        m_prev = head();
+        head() = this;
+    }
+
+private:
+    static list_scope_base const*& head() {
+        thread_local list_scope_base const* h = nullptr;
+        return h;
+    }
+    uint8_t const* m_begin;
+    uint8_t const* m_end;
+    dint_list_cache* m_cache = nullptr;
+    list_scope_base const* m_prev = nullptr;
+};
+
 template <typename HostBlockCoder>
 struct dint_block_device : HostBlockCoder {
     static const uint64_t block_size = kBlockSize;
     static const uint64_t overflow = 256;  // dint_block::overflow
-    // the reference's shape: assumes the bytes a block can occupy are readable behind `in` (true inside an
-    // index buffer; for the last block of a mapped file use the bounded overload)
+    struct list_scope : list_scope_base {
+        template <typename Dictionary>
+        list_scope(Dictionary const& docs_dict, Dictionary const* freqs_dict, uint8_t const* list_begin, uint8_t const* list_end)
+            : list_scope_base(docs_dict.handle(), freqs_dict ? freqs_dict->handle() : nullptr, list_begin, list_end) {}
+    };
+    // The reference's shape (no end pointer). Inside a list_scope: served from the decoded list, nothing is read. Outside
+    // one, what is uploaded is bounded by readable_end() when the caller has set it (the end of the mapped index), else
+    // by the bytes a block can occupy — readable for any block but the last ones of a mapped file: set the end, or use
+    // the bounded overload, there.
+    static uint8_t const*& readable_end() {
+        thread_local uint8_t const* end = nullptr;
+        return end;
+    }
     template <typename Dictionary>
     static uint8_t const* decode(Dictionary const& dict, uint8_t const* in, uint32_t* out, uint32_t sum_of_values, size_t n) {
-        return detail::decode_block(dict, in, in + detail::worst_case_bytes(n), out, sum_of_values, n);
+        if (list_scope_base const* s = list_scope_base::find(in)) return s->decode(in, out, n);
+        uint8_t const* end = in + detail::worst_case_bytes(n);
+        if (readable_end() && readable_end() > in && readable_end() < end) end = readable_end();
+        return detail::decode_block(dict, in, end, out, sum_of_values, n);
     }
     template <typename Dictionary>
     static uint8_t const* decode(Dictionary const& dict, uint8_t const* in, uint8_t const* in_end, uint32_t* out,
                                  uint32_t sum_of_values, size_t n) {
+        if (list_scope_base const* s = list_scope_base::find(in)) return s->decode(in, out, n);
         return detail::decode_block(dict, in, in_end, out, sum_of_values, n);
     }
 };

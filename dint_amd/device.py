@@ -32,6 +32,7 @@ ABI_SYMBOLS = (
     "dint_decode_units", "dint_unit_table_create", "dint_unit_table_destroy", "dint_decode_unit_table", "dint_decode_list_host", "dint_last_kernel_ms", "dint_recent_kernel_ms",
     "dint_stream_stats_get",
     "dint_decode_block_host", "dint_index_posting_lists", "dint_decode_posting_blocks",
+    "dint_list_cache_create", "dint_list_cache_decode", "dint_list_cache_destroy",
     "dint_block_table_create", "dint_block_table_destroy", "dint_decode_block_table",
     "dint_query_index_create", "dint_query_index_destroy", "dint_and_queries", "dint_and_queries_freqs", "dint_count_ngrams", "dint_last_kernel_clock_mhz",
 )
@@ -89,6 +90,11 @@ def _load():
     lib.dint_stream_stats_get.argtypes = [vp, vp, sz, C.POINTER(StreamStats)]
     lib.dint_decode_block_host.argtypes = [vp, vp, sz, vp, u32, sz, C.POINTER(sz)]
     lib.dint_index_posting_lists.argtypes = [vp, sz, vp, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(u64)]
+    lib.dint_list_cache_create.argtypes = [vp, vp, vp, sz, C.POINTER(vp)]
+    lib.dint_list_cache_decode.argtypes = [vp, sz, vp, sz, C.POINTER(sz)]
+    lib.dint_list_cache_destroy.restype = None
+    lib.dint_list_cache_destroy.argtypes = [vp]
+    lib.dint_debug_alloc_count.argtypes = [C.POINTER(u64)]
     lib.dint_decode_posting_blocks.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp, sz, vp]
     lib.dint_block_table_create.argtypes = [vp, vp, sz, sz, C.POINTER(vp)]
     lib.dint_block_table_destroy.restype = None
@@ -269,6 +275,37 @@ def decode_block(dictionary: "Dictionary", buf: np.ndarray, offset: int, sum_of_
     _check(_lib.dint_decode_block_host(dictionary._h, buf.ctypes.data + offset, buf.size - offset, out.ctypes.data,
                                        sum_of_values & 0xFFFFFFFF, n, C.byref(consumed)), "dint_decode_block_host")
     return out, consumed.value
+
+
+class ListCache:
+    """One posting list (host bytes, dict_posting_list layout) decoded once on the device; `decode(offset, n)` is then the
+    block Coder's call for the docs or freqs part that starts `offset` bytes into the list, served from host memory."""
+
+    def __init__(self, docs_dict: "Dictionary", freqs_dict, list_bytes: np.ndarray):
+        self._list = np.ascontiguousarray(list_bytes, dtype=np.uint8)
+        self._h = C.c_void_p()
+        _check(_lib.dint_list_cache_create(docs_dict._h, freqs_dict._h if freqs_dict is not None else None,
+                                           self._list.ctypes.data, self._list.size, C.byref(self._h)), "dint_list_cache_create")
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.dint_list_cache_destroy(h)
+
+    __del__ = close
+
+    def decode(self, offset: int, n: int):
+        out = np.empty(n, dtype=np.uint32)
+        consumed = C.c_size_t()
+        _check(_lib.dint_list_cache_decode(self._h, offset, out.ctypes.data, n, C.byref(consumed)), "dint_list_cache_decode")
+        return out, consumed.value
+
+
+def alloc_count() -> int:
+    """Device / pinned allocations the library has made so far in this process (test hook)."""
+    n = C.c_uint64()
+    _check(_lib.dint_debug_alloc_count(C.byref(n)), "dint_debug_alloc_count")
+    return n.value
 
 
 def index_posting_lists(index: np.ndarray, list_offsets: np.ndarray):

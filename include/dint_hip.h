@@ -151,9 +151,11 @@ int dint_decode_list_host(const dint_dict* dict, const uint8_t* in, size_t in_by
  * (single dictionaries), or a selector byte and 16- / 8-bit codewords (multi) — through the DINT
  * kernels; n < 256: binary interpolative, `sum_of_values` being the sum of the block's integers or
  * 0xFFFFFFFF for "a vbyte of it comes first" (what the reference passes for freqs blocks), through
- * the interpolative kernel. Uploads, runs one block on the device, downloads, synchronises: the
- * reference's granularity, one block per call — batch through dint_decode_posting_blocks for
- * throughput. Nothing past out[n - 1] is written and `out` need not be zeroed (the reference needs
+ * the interpolative kernel. Uploads, runs one block on the device, downloads, waits for the
+ * dictionary's own stream (pinned staging and a device workspace kept by the dictionary: no
+ * allocation after the first call of a size, no device-wide synchronisation): the reference's
+ * granularity, one block per call — dint_list_cache_* decodes a list's blocks at once,
+ * dint_decode_posting_blocks many lists'. Nothing past out[n - 1] is written and `out` need not be zeroed (the reference needs
  * both: block_size + overflow zeroed words, dict_posting_list.hpp:104-105, :296).
  * Replaces: dint_block::decode / opt_dint_single_dict_block::decode /
  *           opt_dint_multi_dict_block::decode (include/dint/dint_codecs.hpp:13-49, :269-274,
@@ -161,6 +163,21 @@ int dint_decode_list_host(const dint_dict* dict, const uint8_t* in, size_t in_by
  *           called from dict_posting_list.hpp:298-301 and :313-315. */
 int dint_decode_block_host(const dint_dict* dict, const uint8_t* in, size_t in_bytes, uint32_t* out,
                            uint32_t sum_of_values, size_t n, size_t* consumed);
+
+/* A whole posting list (host pointer, the dict_posting_list layout below) decoded ONCE, its blocks then served from host
+ * memory: what makes the block Coder usable under a document_enumerator, which calls Coder::decode per touched block
+ * (dict_posting_list.hpp:298-301, :313-315) — one launch sequence per 256 postings otherwise. `create` uploads the
+ * list, decodes every block's docs part (as the Coder returns it: d-gaps) and — freqs_dict not NULL — freqs part (as
+ * stored: freq - 1) through the batched kernels on the dictionary's own stream, and downloads; it synchronises that
+ * stream only. `decode` = the Coder call for the block part that starts `in_offset` bytes into the list: a memcpy;
+ * *consumed = the part's bytes. DINT_ERR_ARG if no part of n integers starts there.
+ * Replaces: dint_block::decode / interpolative_block::decode as called from dict_posting_list.hpp:298-301, :313-315,
+ *           for a list at a time. */
+typedef struct dint_list_cache dint_list_cache;
+int dint_list_cache_create(const dint_dict* docs_dict, const dint_dict* freqs_dict, const uint8_t* list, size_t list_bytes,
+                           dint_list_cache** out);
+int dint_list_cache_decode(const dint_list_cache* cache, size_t in_offset, uint32_t* out, size_t n, size_t* consumed);
+void dint_list_cache_destroy(dint_list_cache* cache);
 
 /* One 256-posting block (the last block of a list may be shorter) of a posting list laid out as
  * reference include/dint/dict_posting_list.hpp:10-56:

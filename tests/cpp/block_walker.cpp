@@ -4,11 +4,16 @@
 // to cut the blocks, Coder::decode(*docs_dict, block_data, buf, max - base - (size - 1), size) returning where
 // the freqs part begins, Coder::decode(*freqs_dict, ...) with sum_of_values = -1 — and compares every
 // (docid, freq) with the expected arrays. Own code: only the call sequence is the reference's.
-// usage: block_walker <kind 1|2> <docs dict> <freqs dict> <list bytes> <docids u32> <freqs u32>
+// usage: block_walker <kind 1|2> <docs dict> <freqs dict> <list bytes> <docids u32> <freqs u32> [scope|noend]
+//   scope: the walk runs inside a Coder::list_scope (the list decoded once, every Coder::decode a memcpy) and uses the
+//          reference's end-less decode(dict, in, out, sum, n); prints the walk's wall time and how many device / pinned
+//          allocations the library made during it.   noend: the end-less overload per block, bounded by readable_end().
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <memory>
 #include <vector>
 
 #include "dint/coders.hpp"
@@ -26,8 +31,8 @@ std::vector<T> slurp(const char* path) {
 template <typename Dictionary, typename Coder>
 class enumerator {
 public:
-    enumerator(Dictionary const* docs_dict, Dictionary const* freqs_dict, uint8_t const* data, uint8_t const* data_end)
-        : m_end(data_end), m_docs_dict(docs_dict), m_freqs_dict(freqs_dict) {
+    enumerator(Dictionary const* docs_dict, Dictionary const* freqs_dict, uint8_t const* data, uint8_t const* data_end, bool endless = false)
+        : m_end(data_end), m_docs_dict(docs_dict), m_freqs_dict(freqs_dict), m_endless(endless) {
         m_base = dint::vbyte::read(data, data_end, &m_n);
         m_blocks = (m_n + Coder::block_size - 1) / Coder::block_size;
         m_block_maxs = m_base;
@@ -72,8 +77,10 @@ private:
         m_cur_block_size = ((block + 1) * Coder::block_size <= m_n) ? uint32_t(Coder::block_size) : uint32_t(m_n % Coder::block_size);
         const uint32_t cur_base = (block ? u32_at(m_block_maxs, block - 1) : uint32_t(-1)) + 1;
         const uint32_t cur_max = u32_at(m_block_maxs, block);
-        m_freqs_block_data = Coder::decode(*m_docs_dict, block_data, m_end, m_docs_buf.data(),
-                                           cur_max - cur_base - (m_cur_block_size - 1), m_cur_block_size);
+        m_freqs_block_data = m_endless ? Coder::decode(*m_docs_dict, block_data, m_docs_buf.data(),  // (dict_posting_list.hpp:298-301)
+                                                       cur_max - cur_base - (m_cur_block_size - 1), m_cur_block_size)
+                                       : Coder::decode(*m_docs_dict, block_data, m_end, m_docs_buf.data(),
+                                                       cur_max - cur_base - (m_cur_block_size - 1), m_cur_block_size);
         m_docs_buf[0] += cur_base;
         m_cur_block = block;
         m_pos_in_block = 0;
@@ -81,7 +88,8 @@ private:
         m_freqs_decoded = false;
     }
     void decode_freqs_block() {
-        Coder::decode(*m_freqs_dict, m_freqs_block_data, m_end, m_freqs_buf.data(), uint32_t(-1), m_cur_block_size);
+        if (m_endless) Coder::decode(*m_freqs_dict, m_freqs_block_data, m_freqs_buf.data(), uint32_t(-1), m_cur_block_size);  // (:313-315)
+        else Coder::decode(*m_freqs_dict, m_freqs_block_data, m_end, m_freqs_buf.data(), uint32_t(-1), m_cur_block_size);
         m_freqs_decoded = true;
     }
 
@@ -94,6 +102,7 @@ private:
     uint8_t const* m_blocks_data;
     Dictionary const* m_docs_dict;
     Dictionary const* m_freqs_dict;
+    bool m_endless = false;
     uint64_t m_cur_block = 0;
     uint32_t m_pos_in_block = 0, m_cur_block_size = 0;
     uint64_t m_cur_docid = 0;
@@ -102,8 +111,10 @@ private:
     std::vector<uint32_t> m_docs_buf, m_freqs_buf;
 };
 
+extern "C" int dint_debug_alloc_count(uint64_t* count);  // test hook of libdint_hip.so
+
 template <typename Dictionary, typename Coder>
-int run(char** argv) {
+int run(char** argv, const char* mode) {
     auto docs_file = slurp<uint8_t>(argv[2]), freqs_file = slurp<uint8_t>(argv[3]), list = slurp<uint8_t>(argv[4]);
     auto want_docs = slurp<uint32_t>(argv[5]), want_freqs = slurp<uint32_t>(argv[6]);
     static_assert(Coder::block_size == 256 && Coder::overflow == 256, "the reference's statics");
@@ -113,8 +124,19 @@ int run(char** argv) {
     Dictionary docs_dict, freqs_dict;
     db.build(docs_dict);
     fb.build(freqs_dict);
+    const size_t list_bytes = list.size();
     list.resize(list.size() + 16, 0);
-    enumerator<Dictionary, Coder> e(&docs_dict, &freqs_dict, list.data(), list.data() + list.size());
+    const bool scoped = std::strcmp(mode, "scope") == 0, noend = std::strcmp(mode, "noend") == 0;
+    if (scoped) {  // warm the dictionaries' host-call workspaces (their first use allocates): a scope over the same list
+        typename Coder::list_scope warm(docs_dict, &freqs_dict, list.data(), list.data() + list_bytes);
+    }
+    if (noend) Coder::readable_end() = list.data() + list.size();
+    uint64_t allocs0 = 0, allocs1 = 0;
+    dint_debug_alloc_count(&allocs0);
+    const auto t0 = std::chrono::steady_clock::now();
+    std::unique_ptr<typename Coder::list_scope> scope;
+    if (scoped) scope.reset(new typename Coder::list_scope(docs_dict, &freqs_dict, list.data(), list.data() + list_bytes));
+    enumerator<Dictionary, Coder> e(&docs_dict, &freqs_dict, list.data(), list.data() + list.size(), scoped || noend);
     if (e.size() != want_docs.size()) {
         std::cerr << "list holds " << e.size() << " postings, expected " << want_docs.size() << "\n";
         return 1;
@@ -125,7 +147,7 @@ int run(char** argv) {
                       << want_freqs[i] << ")\n";
             return 1;
         }
-        if (!e.poisoned()) {
+        if ((!scoped || i % 256 == 0) && !e.poisoned()) {  // (a timed walk looks once per block)
             std::cerr << "posting " << i << ": the decoder wrote past the block\n";
             return 1;
         }
@@ -135,16 +157,20 @@ int run(char** argv) {
             return 1;
         }
     }
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    dint_debug_alloc_count(&allocs1);
     std::cout << "ok\n";
+    if (scoped) std::cout << "walk_ms " << ms << " allocations " << (allocs1 - allocs0) << " postings " << want_docs.size() << "\n";
     return 0;
 }
 
 int main(int argc, char** argv) {
-    if (argc != 7) return 2;
+    if (argc != 7 && argc != 8) return 2;
+    const char* mode = argc == 8 ? argv[7] : "";
     try {
         switch (std::atoi(argv[1])) {
-            case 1: return run<dint::single_dictionary_packed_type, dint::opt_dint_single_dict_block_device>(argv);
-            case 2: return run<dint::multi_dictionary_packed_type, dint::opt_dint_multi_dict_block_device>(argv);
+            case 1: return run<dint::single_dictionary_packed_type, dint::opt_dint_single_dict_block_device>(argv, mode);
+            case 2: return run<dint::multi_dictionary_packed_type, dint::opt_dint_multi_dict_block_device>(argv, mode);
         }
     } catch (std::exception const& ex) {
         std::cerr << "exception: " << ex.what() << "\n";

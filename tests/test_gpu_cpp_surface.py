@@ -149,3 +149,80 @@ def test_decode_block_host_call_shape(small_corpus):
         nxt = int(blocks["in_off"][b + 1]) if b + 1 < len(blocks) and blocks["list"][b + 1] == blocks["list"][b] else None
         if nxt is not None:
             assert at + used + used_f == nxt
+
+
+@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
+def test_block_coder_under_a_list_scope(walker_binary, tmp_path, kind):
+    """A usable per-block drop-in (SURVEY H7): inside a Coder::list_scope the list is decoded ONCE on the device and every
+    Coder::decode of the walker — the reference's end-less call shape — is a memcpy. A 10^5-posting list (390 full blocks
+    and an interpolative tail): every posting right, the walk takes milliseconds, and the library makes no device or
+    pinned allocation during it (the dictionaries' workspaces are warm). The same walk with one launch sequence per block
+    (mode noend: bounded by Coder::readable_end()) is checked for equality too."""
+    import oracle
+
+    r = np.random.default_rng(5)
+    n = 100_123
+    docids = np.cumsum(r.geometric(0.02, n).astype(np.uint64)).astype(np.uint32)
+    freqs = r.geometric(0.6, n).astype(np.uint32)
+    gaps = host.docids_to_gaps(docids)
+    coll = host.Collection(gaps, np.array([n], dtype=np.uint32))
+    fcoll = host.Collection(freqs - 1, np.array([n], dtype=np.uint32))
+    docs_dict, freqs_dict = host.build_dictionary(kind, coll), host.build_dictionary(kind, fcoll)
+    index, offsets = host.build_index(kind, docs_dict, freqs_dict, docids, freqs, np.array([n], dtype=np.uint32))
+    d, f = oracle.posting_list_decode(oracle.OracleDict(kind, docs_dict), oracle.OracleDict(kind, freqs_dict), index, 0)
+    assert np.array_equal(d, docids) and np.array_equal(f, freqs)
+    (tmp_path / "docs.dict").write_bytes(docs_dict)
+    (tmp_path / "freqs.dict").write_bytes(freqs_dict)
+    index[int(offsets[0]):int(offsets[1])].tofile(tmp_path / "list.bin")
+    docids.tofile(tmp_path / "docids.bin")
+    freqs.tofile(tmp_path / "freqs.bin")
+    args = [walker_binary, str(kind), str(tmp_path / "docs.dict"), str(tmp_path / "freqs.dict"), str(tmp_path / "list.bin"),
+            str(tmp_path / "docids.bin"), str(tmp_path / "freqs.bin")]
+    best = None
+    for _ in range(3):
+        res = subprocess.run(args + ["scope"], capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0 and res.stdout.splitlines()[0] == "ok", res.stdout + res.stderr
+        fields = res.stdout.splitlines()[1].split()
+        ms, allocations = float(fields[1]), int(fields[3])
+        assert allocations == 0 and int(fields[5]) == n
+        best = ms if best is None else min(best, ms)
+    print(f"walk of {n} postings inside a list_scope: {best:.2f} ms")
+    assert best < 5.0   # (about 1 ms on an idle box; one launch sequence per block takes 40 times that)
+    res = subprocess.run(args + ["noend"], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and res.stdout.strip() == "ok", res.stdout + res.stderr
+
+
+def test_list_cache_serves_the_block_coder_call(small_corpus):
+    """dint_list_cache_*: for every block of a list, the docs part and the freqs part equal dint_decode_block_host's and
+    the consumed bytes chain through the list; an offset where no part starts is an error."""
+    from dint_amd import device
+    from test_index_cpu import get_index
+
+    kind = host.SINGLE_PACKED
+    ix = get_index(small_corpus, kind)
+    blocks, _ = device.index_posting_lists(ix.bytes, ix.offsets)
+    dd, fd = device.Dictionary(kind, ix.docs_dict), device.Dictionary(kind, ix.freqs_dict)
+    lens = np.asarray(ix.lens)
+    for i in (int(np.argmax(lens)), int(np.flatnonzero((lens > 3) & (lens < 256))[0])):
+        lo, hi = int(ix.offsets[i]), int(ix.offsets[i + 1])
+        cache = device.ListCache(dd, fd, ix.bytes[lo:hi])
+        mine = blocks[blocks["list"] == i]
+        padded = np.concatenate([ix.bytes, np.zeros(16, np.uint8)])
+        before = None
+        for b in mine[:: max(1, len(mine) // 12)]:
+            n, at = int(b["n"]), int(b["in_off"])
+            docs, used = cache.decode(at - lo, n)
+            gaps_sum = (int(b["max"]) - int(b["base"]) - (n - 1)) & 0xFFFFFFFF
+            want, want_used = device.decode_block(dd, padded, at, gaps_sum, n)
+            assert np.array_equal(docs, want) and used == want_used
+            fr, used_f = cache.decode(at - lo + used, n)
+            want_f, want_used_f = device.decode_block(fd, padded, at + used, 0xFFFFFFFF, n)
+            assert np.array_equal(fr, want_f) and used_f == want_used_f
+            a = int(b["out_off"])
+            assert np.array_equal(fr + 1, ix.freqs[a:a + n])
+            if before is None:
+                before = device.alloc_count()   # (both dictionaries' host-call workspaces are warm from here on)
+        assert device.alloc_count() == before   # no allocation per call: one block at a time or from the cache
+        with pytest.raises(device.DintError):
+            cache.decode(1, 3)
+        cache.close()
