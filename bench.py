@@ -51,7 +51,8 @@ def parse_args(argv=None):
     ap.add_argument("--replicate", type=int, default=None,
                     help="device-side copies of the encoded shard at distinct addresses, all decoded in one step")
     ap.add_argument("--universe", type=int, default=None, help="documents")
-    ap.add_argument("--unit-ints", type=int, default=8192)
+    ap.add_argument("--unit-ints", type=int, default=16384,
+                    help="the sidecar's granularity: integers per unit (16384: 1.6 % faster than 8192 at 5e9 integers per launch, profiles/r03_unit_sweep.txt)")
     ap.add_argument("--dict-sample", type=float, default=2.0e7,
                     help="postings the DSF dictionary statistics are collected from")
     ap.add_argument("--seed", type=int, default=12345)
@@ -291,6 +292,12 @@ def main():
         raise SystemExit(f"shard {shard_rank} of {shard_world} is empty: {postings * shard_world} postings are too few for "
                          f"{shard_world} ranks (the longest list alone holds {int(lens_all.max())})")
 
+    def build_dictionary(sample_of):
+        # n-gram counting and selection on the device (byte-identical to the host construction, 7 s -> 0.2 s of set-up)
+        if hasattr(device, "build_dictionary"):
+            return device.build_dictionary(kind, sample_of, max_sample_ints=int(args.dict_sample), device=local_rank)[0]
+        return host.build_dictionary(kind, sample_of, max_sample_ints=int(args.dict_sample), threads=threads)
+
     t0 = time.time()
     if rank == 0 and shard_rank != 0:
         # --as-rank K/W, K != 0: the job's dictionary comes from RANK 0's first lists, not from this shard's —
@@ -299,11 +306,11 @@ def main():
         cum = np.cumsum(lens_all[:hi0], dtype=np.uint64)
         j = max(1, int(np.searchsorted(cum, int(args.dict_sample), side="right"))) if args.dict_sample else hi0
         sample = host.Collection(host.synth_gaps(p, lens_all[:j], first_list_id=0, threads=threads), lens_all[:j])
-        dict_file = host.build_dictionary(kind, sample, max_sample_ints=int(args.dict_sample), threads=threads)
+        dict_file = build_dictionary(sample)
         del sample
     elif rank == 0:
         # dictionary statistics from a prefix sample of the collection (rank 0's first lists)
-        dict_file = host.build_dictionary(kind, coll, max_sample_ints=int(args.dict_sample), threads=threads)
+        dict_file = build_dictionary(coll)
     else:
         dict_file = None
     if distributed:

@@ -4,6 +4,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstring>  // (before rocPRIM: one of its headers calls the host memset without including it)
+#include <rocprim/device/device_merge_sort.hpp>
+
 #include <algorithm>
 #include <atomic>
 #include <mutex>
@@ -1795,6 +1798,78 @@ int dint_count_ngrams(int device, int multi, const uint32_t* d_gaps, uint64_t n_
     cleanup();
     *entries = mem;
     *n_entries = size_t(n_out);
+    return DINT_OK;
+}
+
+int dint_select_ngrams(int device, const uint32_t* d_gaps, uint64_t n_ints, uint64_t total_ints, dint_ngram* entries, size_t n_entries,
+                       uint32_t top_k, size_t* n_selected) {
+    if (!n_selected || (n_entries && (!entries || !d_gaps)) || top_k == 0) return DINT_ERR_ARG;
+    *n_selected = 0;
+    if (n_entries == 0) return DINT_OK;
+    int count = 0;
+    if (!hip_ok(hipGetDeviceCount(&count), "hipGetDeviceCount") || device < 0 || device >= count) return DINT_ERR_NO_DEVICE;
+    for (size_t i = 0; i != n_entries; ++i)  // (the comparator reads the integers: they must lie inside d_gaps)
+        if (entries[i].len == 0 || entries[i].len > kMaxEntry || entries[i].pos > n_ints || n_ints - entries[i].pos < entries[i].len ||
+            entries[i].ctx >= 8)
+            return DINT_ERR_ARG;
+    HIP_TRY(hipSetDevice(device));
+    dint_ngram *d_in = nullptr, *d_kept = nullptr, *d_sorted = nullptr;
+    unsigned long long* d_ctl = nullptr;  // [0] kept count, [1..8] first index per context, [9..16] output base per context
+    void* d_tmp = nullptr;
+    auto cleanup = [&]() {
+        for (void* p : {static_cast<void*>(d_in), static_cast<void*>(d_kept), static_cast<void*>(d_sorted), static_cast<void*>(d_ctl), d_tmp})
+            if (p) (void)hipFree(p);
+    };
+    auto fail = [&](int st) {
+        cleanup();
+        return st;
+    };
+    const size_t bytes = n_entries * sizeof(dint_ngram);
+    if (!hip_ok(counted_malloc(&d_in, bytes), "hipMalloc") || !hip_ok(counted_malloc(&d_kept, bytes), "hipMalloc") ||
+        !hip_ok(counted_malloc(&d_sorted, bytes), "hipMalloc") || !hip_ok(counted_malloc(&d_ctl, 17 * 8), "hipMalloc") ||
+        !hip_ok(hipMemcpy(d_in, entries, bytes, hipMemcpyHostToDevice), "hipMemcpy") || !hip_ok(hipMemset(d_ctl, 0, 8), "hipMemset"))
+        return fail(DINT_ERR_HIP);
+    const uint32_t grid = uint32_t((n_entries + 255) / 256);
+    hipLaunchKernelGGL(keep_filtered_kernel, dim3(grid), dim3(256), 0, nullptr, d_in, uint64_t(n_entries), double(total_ints), d_kept, d_ctl);
+    unsigned long long n_kept = 0;
+    if (!hip_ok(hipGetLastError(), "keep_filtered_kernel") || !hip_ok(hipMemcpy(&n_kept, d_ctl, 8, hipMemcpyDeviceToHost), "hipMemcpy") ||
+        n_kept > n_entries)
+        return fail(DINT_ERR_HIP);
+    if (n_kept == 0) {
+        cleanup();
+        return DINT_OK;
+    }
+    ngram_dictionary_order order{d_gaps};
+    size_t tmp_bytes = 0;
+    if (!hip_ok(rocprim::merge_sort(nullptr, tmp_bytes, d_kept, d_sorted, size_t(n_kept), order, nullptr), "rocprim::merge_sort(size)") ||
+        !hip_ok(counted_malloc(&d_tmp, std::max<size_t>(tmp_bytes, 16)), "hipMalloc") ||
+        !hip_ok(rocprim::merge_sort(d_tmp, tmp_bytes, d_kept, d_sorted, size_t(n_kept), order, nullptr), "rocprim::merge_sort"))
+        return fail(DINT_ERR_HIP);
+    // the first top_k of every context: where its run starts, how many it gives, where they go
+    unsigned long long ctl[17];
+    for (int c = 0; c != 8; ++c) ctl[1 + c] = n_kept;
+    if (!hip_ok(hipMemcpy(d_ctl + 1, ctl + 1, 64, hipMemcpyHostToDevice), "hipMemcpy")) return fail(DINT_ERR_HIP);
+    const uint32_t kgrid = uint32_t((n_kept + 255) / 256);
+    hipLaunchKernelGGL(context_starts_kernel, dim3(kgrid), dim3(256), 0, nullptr, d_sorted, uint64_t(n_kept), d_ctl + 1);
+    if (!hip_ok(hipMemcpy(ctl + 1, d_ctl + 1, 64, hipMemcpyDeviceToHost), "hipMemcpy")) return fail(DINT_ERR_HIP);
+    unsigned long long out_n = 0;
+    for (int c = 0; c != 8; ++c) {
+        unsigned long long end = n_kept;  // the run ends where the next context that has entries begins
+        for (int d = c + 1; d != 8; ++d)
+            if (ctl[1 + d] < n_kept) {
+                end = ctl[1 + d];
+                break;
+            }
+        const unsigned long long have = ctl[1 + c] < n_kept ? end - ctl[1 + c] : 0;
+        ctl[9 + c] = out_n;
+        out_n += std::min<unsigned long long>(have, top_k);
+    }
+    if (!hip_ok(hipMemcpy(d_ctl + 9, ctl + 9, 64, hipMemcpyHostToDevice), "hipMemcpy")) return fail(DINT_ERR_HIP);
+    hipLaunchKernelGGL(take_top_kernel, dim3(kgrid), dim3(256), 0, nullptr, d_sorted, uint64_t(n_kept), d_ctl + 1, d_ctl + 9, top_k, d_in);
+    if (!hip_ok(hipGetLastError(), "take_top_kernel") || !hip_ok(hipMemcpy(entries, d_in, out_n * sizeof(dint_ngram), hipMemcpyDeviceToHost), "hipMemcpy"))
+        return fail(DINT_ERR_HIP);
+    cleanup();
+    *n_selected = size_t(out_n);
     return DINT_OK;
 }
 

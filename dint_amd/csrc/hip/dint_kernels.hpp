@@ -2485,25 +2485,26 @@ struct tail_bits {
 // (interpolative_coding.hpp:128-146); here an explicit stack (frames of 4 words in LDS) is walked in that order.
 // (A variant with the bit reader one word ahead and the left child taken without a trip through the stack was
 // measured: a third slower — the kernel lives on how many of these lanes are in flight, not on their length.)
+// (ONE word per stack frame — the subrange's offset and length: its bounds are the values next to it in the row, decoded
+// before the recursion descends into it (the element left of the range, zero before the first; the element right of it,
+// the sum behind the last) — so that a block takes 268 words of LDS, not 298, and the 8 blocks of a wave 8.4 KB: the
+// short blocks of a 10^8-posting index, 4 591 waves, are then all resident at once: 18 waves to a CU. `o[-1]` must be zero.)
 __device__ __forceinline__ uint64_t interpolative_prefix_sums(const uint8_t* p, uint64_t limit, uint32_t n, uint32_t sum, uint32_t* o,
                                                             uint32_t* stack) {
     o[n - 1] = sum;
     if (n <= 1) return 0;
     tail_bits br{p, limit, 0, 0, 0, 0};
     uint32_t top = 0;
-    auto push = [&](uint32_t off, uint32_t cnt, uint32_t low, uint32_t high) {
-        uint32_t* f = stack + 4 * top++;
-        f[0] = off, f[1] = cnt, f[2] = low, f[3] = high;
-    };
-    push(0, n - 1, 0, sum);
+    stack[top++] = (n - 1) << 8;  // frame: offset | length << 8
     while (top) {
-        const uint32_t* f = stack + 4 * --top;
-        const uint32_t f_off = f[0], f_n = f[1], f_low = f[2], f_high = f[3];
+        const uint32_t f = stack[--top];
+        const uint32_t f_off = f & 255u, f_n = f >> 8;
+        const uint32_t f_low = o[int32_t(f_off) - 1], f_high = o[f_off + f_n];
         const uint32_t h = f_n / 2;
         const uint32_t val = f_low + br.read_int(f_high - f_low + 1);
         o[f_off + h] = val;
-        if (f_n - h - 1) push(f_off + h + 1, f_n - h - 1, val, f_high);
-        if (h) push(f_off, h, f_low, val);
+        if (f_n - h - 1) stack[top++] = (f_off + h + 1) | ((f_n - h - 1) << 8);
+        if (h) stack[top++] = f_off | (h << 8);
     }
     return (br.pos + 7) / 8;
 }
@@ -2530,8 +2531,8 @@ __global__ void collect_tails_kernel(const dint_block_ref* blocks, uint64_t n_bl
 #define DINT_TAIL_LANES 8
 #endif
 constexpr uint32_t kTailLanes = DINT_TAIL_LANES;
-constexpr uint32_t kTailRow = 257;     // words per lane and row: up to 255 values
-constexpr uint32_t kTailStack = 41;    // words per lane: 10 frames of 4 (depth <= log2(256) + 1)
+constexpr uint32_t kTailRow = 257;     // words per lane and row: a zero in front of up to 255 values (odd stride: conflict-free)
+constexpr uint32_t kTailStack = 11;    // words per lane: 10 one-word frames (depth <= log2(256) + 1)
 constexpr uint32_t kTailLdsBytes = kTailLanes * (kTailRow + kTailStack) * 4;
 
 __device__ __forceinline__ void interpolative_tails_wave(const uint8_t* index, uint64_t index_bytes,
@@ -2544,8 +2545,9 @@ __device__ __forceinline__ void interpolative_tails_wave(const uint8_t* index, u
     __shared__ uint64_t row_out[kTailLanes];
     const uint32_t lane = threadIdx.x;
     const uint64_t t = uint64_t(blockIdx.x) * kTailLanes + lane;
-    uint32_t* const o = tail_lds + (lane % kTailLanes) * kTailRow;
+    uint32_t* const o = tail_lds + (lane % kTailLanes) * kTailRow + 1;  // (o[-1]: the zero the first range's lower bound reads)
     uint32_t* const stack = tail_lds + kTailLanes * kTailRow + (lane % kTailLanes) * kTailStack;
+    if (lane < kTailLanes) o[-1] = 0;
     uint32_t n = 0;
     uint64_t b = 0;
     if (lane < kTailLanes && t < *n_tails) {
@@ -2582,7 +2584,7 @@ __device__ __forceinline__ void interpolative_tails_wave(const uint8_t* index, u
         const uint32_t nj = row_n[j];
         uint32_t* const dst = out + row_out[j];
         const uint32_t add = as_docids ? row_base[j] : plus_one;
-        for (uint32_t i = lane; i < nj; i += 64) dst[i] = tail_lds[j * kTailRow + i] + add + (as_docids ? i : 0u);
+        for (uint32_t i = lane; i < nj; i += 64) dst[i] = tail_lds[j * kTailRow + 1 + i] + add + (as_docids ? i : 0u);
     }
     if (!freqs_out) return;
     __syncthreads();  // the rows are free again: the freqs parts, right behind the docs parts
@@ -2594,7 +2596,7 @@ __device__ __forceinline__ void interpolative_tails_wave(const uint8_t* index, u
     __syncthreads();
     for (uint32_t j = 0; j != kTailLanes; ++j) {
         const uint32_t nj = row_n[j];
-        for (uint32_t i = lane; i < nj; i += 64) freqs_out[row_out[j] + i] = tail_lds[j * kTailRow + i] + 1u;
+        for (uint32_t i = lane; i < nj; i += 64) freqs_out[row_out[j] + i] = tail_lds[j * kTailRow + 1 + i] + 1u;
     }
 }
 

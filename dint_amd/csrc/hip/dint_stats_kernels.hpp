@@ -162,6 +162,44 @@ __global__ void keep_at_least_kernel(const dint_ngram* e, uint64_t n, const uint
     if (x.freq >= at_least[x.ctx & 7]) out[atomicAdd(n_out, 1ull)] = x;
 }
 
+// ---- the selection itself (decreasing_static_frequencies::build, dictionary_builders.hpp:55-75; the order:
+// block_statistics.hpp:246-276 freq_length sorter, ties by the integers — the deterministic tie-break of
+// dint/statistics.hpp): the kept n-grams of every context in dictionary order, the first top_k of each.
+__global__ void keep_filtered_kernel(const dint_ngram* e, uint64_t n, double total_ints, dint_ngram* out, unsigned long long* n_out) {
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const dint_ngram x = e[i];
+    if (ngram_kept(x, total_ints)) out[atomicAdd(n_out, 1ull)] = x;
+}
+struct ngram_dictionary_order {
+    const uint32_t* gaps;
+    __device__ bool operator()(const dint_ngram& a, const dint_ngram& b) const {
+        if (a.ctx != b.ctx) return a.ctx < b.ctx;
+        if (a.freq != b.freq) return a.freq > b.freq;  // most frequent first
+        if (a.len != b.len) return a.len > b.len;      // then the longer
+        for (uint32_t i = 0; i != a.len; ++i) {        // then by their integers
+            const uint32_t x = gaps[a.pos + i], y = gaps[b.pos + i];
+            if (x != y) return x < y;
+        }
+        return false;
+    }
+};
+// first index of every context's run in the sorted entries (first[c] = n where the context has none: preset by the host)
+__global__ void context_starts_kernel(const dint_ngram* e, uint64_t n, unsigned long long* first /*[8]*/) {
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (i == 0 || e[i - 1].ctx != e[i].ctx) first[e[i].ctx & 7] = i;
+}
+// the first top_k of every context, in order: entry i of context c goes to base[c] + (i - first[c])
+__global__ void take_top_kernel(const dint_ngram* e, uint64_t n, const unsigned long long* first, const unsigned long long* base, uint32_t top_k,
+                                dint_ngram* out) {
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = e[i].ctx & 7;
+    const uint64_t rank = i - first[c];
+    if (rank < top_k) out[base[c] + rank] = e[i];
+}
+
 __global__ void collect_ngrams_kernel(ngram_table t, dint_ngram* out, unsigned long long* n_out, uint64_t capacity) {
     const uint64_t slot = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (slot > t.mask || t.keys[slot] == 0) return;

@@ -117,6 +117,28 @@ int dictionary_from_ngrams(bool multi, uint32_t const* gaps, uint64_t n_ints, ui
     return DINT_OK;
 }
 
+template <typename Builder>
+int pack_dictionary(bool multi, uint32_t const* gaps, uint64_t n_ints, dinth_ngram const* entries, uint64_t n_entries, dinth_blob** out) {
+    using namespace dint;
+    const uint32_t contexts = multi ? kNumSelectors : 1;
+    Builder builder;
+    builder.init();
+    uint32_t prev_ctx = 0;
+    for (uint64_t i = 0; i != n_entries; ++i) {
+        dinth_ngram const& e = entries[i];
+        if (e.len == 0 || e.len > kMaxEntrySize || (e.len & (e.len - 1)) != 0 || e.pos > n_ints || n_ints - e.pos < e.len ||
+            e.ctx >= contexts || e.ctx < prev_ctx)
+            return int(DINT_ERR_ARG);
+        prev_ctx = e.ctx;
+        builder.append(gaps + e.pos, e.len, e.ctx);
+    }
+    builder.build();
+    auto b = new dinth_blob;
+    builder.write(b->bytes);
+    *out = b;
+    return DINT_OK;
+}
+
 template <typename Encoder, typename Builder>
 int encode_with(void const* dict_file, size_t dict_len, uint32_t const* gaps, uint32_t const* lens,
                 uint64_t n_lists, uint32_t unit_ints, int threads, dinth_blob** enc, dinth_blob** units) {
@@ -249,6 +271,19 @@ int dinth_build_dictionary_from_ngrams(int kind, const uint32_t* gaps, uint64_t 
                 return dictionary_from_ngrams<dint::multi_packed_builder>(true, gaps, n_ints, total_ints, entries, n_entries, dict_file);
             default:
                 return int(DINT_ERR_ARG);
+        }
+    });
+}
+
+int dinth_pack_dictionary(int kind, const uint32_t* gaps, uint64_t n_ints, const dinth_ngram* entries, uint64_t n_entries,
+                          dinth_blob** dict_file) {
+    if (!dict_file || (n_entries && (!gaps || !entries))) return DINT_ERR_ARG;
+    return guarded([&] {
+        switch (kind) {
+            case DINT_DICT_RECTANGULAR: return pack_dictionary<dint::rectangular_builder>(false, gaps, n_ints, entries, n_entries, dict_file);
+            case DINT_DICT_SINGLE_PACKED: return pack_dictionary<dint::single_packed_builder>(false, gaps, n_ints, entries, n_entries, dict_file);
+            case DINT_DICT_MULTI_PACKED: return pack_dictionary<dint::multi_packed_builder>(true, gaps, n_ints, entries, n_entries, dict_file);
+            default: return int(DINT_ERR_ARG);
         }
     });
 }

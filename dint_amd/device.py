@@ -34,7 +34,7 @@ ABI_SYMBOLS = (
     "dint_decode_block_host", "dint_index_posting_lists", "dint_decode_posting_blocks",
     "dint_list_cache_create", "dint_list_cache_decode", "dint_list_cache_destroy",
     "dint_block_table_create", "dint_block_table_destroy", "dint_decode_block_table",
-    "dint_query_index_create", "dint_query_index_destroy", "dint_and_queries", "dint_and_queries_freqs", "dint_count_ngrams", "dint_last_kernel_clock_mhz",
+    "dint_query_index_create", "dint_query_index_destroy", "dint_and_queries", "dint_and_queries_freqs", "dint_count_ngrams", "dint_select_ngrams", "dint_last_kernel_clock_mhz",
 )
 
 #: dint_block_ref (include/dint_hip.h)
@@ -106,6 +106,7 @@ def _load():
     lib.dint_and_queries.argtypes = [vp, vp, vp, sz, vp, vp]
     lib.dint_and_queries_freqs.argtypes = [vp, vp, vp, vp, sz, vp, vp, C.POINTER(u64), vp]
     lib.dint_count_ngrams.argtypes = [C.c_int, C.c_int, vp, u64, vp, u64, C.c_uint32, C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_float)]
+    lib.dint_select_ngrams.argtypes = [C.c_int, vp, u64, u64, vp, sz, C.c_uint32, C.POINTER(sz)]
     lib.dint_debug_wave_scan.argtypes = [vp, vp]
     return lib
 
@@ -470,9 +471,20 @@ def count_ngrams(gaps_dev, list_starts: np.ndarray, multi: bool, device: int = 0
     return arr, ms.value
 
 
+def select_ngrams(gaps_dev, entries: np.ndarray, total_ints: int, device: int = 0, top_k: int = 65536) -> np.ndarray:
+    """The selection on the device (dint_select_ngrams): of count_ngrams' entries, the ones the filter keeps, every context's
+    in dictionary order, the first top_k of each."""
+    e = np.ascontiguousarray(entries, dtype=NGRAM_DTYPE).copy()
+    n = C.c_size_t()
+    _check(_lib.dint_select_ngrams(device, gaps_dev.data_ptr(), gaps_dev.numel(), total_ints, e.ctypes.data, e.size, top_k, C.byref(n)),
+           "dint_select_ngrams")
+    return e[: n.value]
+
+
 def build_dictionary(kind: int, coll, max_sample_ints: int = 0, device: int = 0):
-    """host.build_dictionary with the counting on the device: the sampled lists' n-grams counted by dint_count_ngrams,
-    selected and packed by the host library — byte-identical to the host-only path. -> (dictionary file, kernel ms)."""
+    """host.build_dictionary with counting AND selection on the device: the sampled lists' n-grams counted by
+    dint_count_ngrams, filtered / sorted / cut to the first 65536 of every context by dint_select_ngrams, packed by the host
+    library — byte-identical to the host-only path. -> (dictionary file, counting kernel ms)."""
     import torch
 
     from . import host
@@ -489,7 +501,8 @@ def build_dictionary(kind: int, coll, max_sample_ints: int = 0, device: int = 0)
     gaps = np.ascontiguousarray(coll.gaps[:ints], dtype=np.uint32)
     gaps_dev = torch.from_numpy(gaps.view(np.int32)).to(torch.device("cuda", device))
     entries, ms = count_ngrams(gaps_dev, starts, kind == host.MULTI_PACKED, device, top_k=65536)  # DSF-65536-16
-    return host.build_dictionary_from_ngrams(kind, gaps, ints, entries), ms
+    chosen = select_ngrams(gaps_dev, entries, ints, device, top_k=65536)
+    return host.pack_dictionary(kind, gaps, chosen), ms
 
 
 def units_to_device(units: np.ndarray, device):

@@ -66,6 +66,7 @@ def _load():
     lib.dinth_synth_gaps.argtypes = [C.POINTER(SynthParams), vp, u64, u64, vp, i32]
     lib.dinth_build_dictionary.argtypes = [i32, vp, vp, u64, u64, i32, C.POINTER(vp)]
     lib.dinth_build_dictionary_from_ngrams.argtypes = [i32, vp, u64, u64, vp, u64, C.POINTER(vp)]
+    lib.dinth_pack_dictionary.argtypes = [i32, vp, u64, vp, u64, C.POINTER(vp)]
     lib.dinth_encode_vroom.argtypes = [i32, i32, vp, C.c_size_t, vp, vp, u64, u32, i32,
                                        C.POINTER(vp), C.POINTER(vp)]
     lib.dinth_build_index.argtypes = [i32, vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp, u64, i32,
@@ -229,6 +230,16 @@ def build_dictionary_from_ngrams(kind: int, gaps: np.ndarray, total_ints: int, e
     entries = np.ascontiguousarray(entries, dtype=NGRAM_DTYPE)
     _check(_lib.dinth_build_dictionary_from_ngrams(kind, gaps.ctypes.data, gaps.size, total_ints, entries.ctypes.data,
                                                    entries.size, C.byref(h)))
+    return _take_blob(h, np.uint8).tobytes()
+
+
+def pack_dictionary(kind: int, gaps: np.ndarray, entries: np.ndarray) -> bytes:
+    """Packing only: `entries` (NGRAM_DTYPE, pointing into `gaps`) are the dictionary's n-grams already selected and in
+    dictionary order — device.select_ngrams — appended as they come."""
+    h = C.c_void_p()
+    gaps = _u32(gaps)
+    entries = np.ascontiguousarray(entries, dtype=NGRAM_DTYPE)
+    _check(_lib.dinth_pack_dictionary(kind, gaps.ctypes.data, gaps.size, entries.ctypes.data, entries.size, C.byref(h)))
     return _take_blob(h, np.uint8).tobytes()
 
 

@@ -288,6 +288,15 @@ int dint_count_ngrams(int device, int multi, const uint32_t* d_gaps, uint64_t n_
  * included: the dictionary built from them is the same, the host sorts tens of thousands of entries instead of
  * tens of millions. */
 
+/* The selection half on the device too: of `entries` (dint_count_ngrams' output; in place), the n-grams the reference's
+ * filter keeps (dictionary_builders.hpp:15-38), every context's in dictionary order — most frequent first, then the
+ * longer, then by their integers (block_statistics.hpp:246-276 freq_length sorter; ties made deterministic) — and of
+ * those the first top_k (decreasing_static_frequencies::build, dictionary_builders.hpp:55-75: 65536). A filter kernel, one
+ * rocPRIM merge sort whose comparator reads the integers in d_gaps, one scatter. *n_selected entries come back; the
+ * host only packs them (dinth_pack_dictionary, include/dint_host.h). */
+int dint_select_ngrams(int device, const uint32_t* d_gaps, uint64_t n_ints, uint64_t total_ints, dint_ngram* entries,
+                       size_t n_entries, uint32_t top_k, size_t* n_selected);
+
 /* Device time (ms) between the two events the library records around the decode kernel of the most
  * recent dint_decode_units on this dictionary (one event pair per in-flight launch: launches on
  * different streams do not disturb each other's); synchronises that launch. */

@@ -68,6 +68,13 @@ typedef struct dinth_ngram {  /* = dint_ngram of include/dint_hip.h */
 int dinth_build_dictionary_from_ngrams(int kind, const uint32_t* gaps, uint64_t n_ints, uint64_t total_ints,
                                        const dinth_ngram* entries, uint64_t n_entries, dinth_blob** dict_file);
 
+/* Packing only: `entries` are the dictionary's n-grams ALREADY selected and in dictionary order, context by context
+ * (dint_select_ngrams on the device); each is appended as it comes and the table is packed and written
+ * (builder::append / build / write: single_dictionary.hpp:109-160, dictionary_building_utils.hpp:241-292).
+ * Byte-identical to dinth_build_dictionary_from_ngrams over the unselected counts. */
+int dinth_pack_dictionary(int kind, const uint32_t* gaps, uint64_t n_ints, const dinth_ngram* entries, uint64_t n_entries,
+                          dinth_blob** dict_file);
+
 /* Encode lists into one vroom stream (reference vroom_env/encode.cpp:133-191).
  * kind selects the dictionary type of dict_file; greedy != 0 selects
  * single_greedy_dint instead of single_opt_dint (ignored for multi).

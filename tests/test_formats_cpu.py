@@ -158,3 +158,57 @@ def test_dictionary_from_ngram_counts_is_the_same_file(kind):
         bad = entries.copy()
         bad["pos"][0] = coll.num_postings  # points past the integers
         host.build_dictionary_from_ngrams(kind, coll.gaps, coll.num_postings, bad)
+
+
+def _select_in_python(entries, gaps, total_ints, tie_key):
+    """The selection (filter, order, first 65536 per context) with a caller-chosen order among n-grams of equal count and
+    length — what dint_select_ngrams does on the device with the deterministic order."""
+    keep = [e for e in entries if e["len"] == 1 or float(e["freq"]) * (48.0 * int(e["len"]) - 16.0) / total_ints > 1e-7]
+    data = lambda e: tuple(int(x) for x in gaps[int(e["pos"]):int(e["pos"]) + int(e["len"])])
+    keep.sort(key=lambda e: (int(e["ctx"]), -int(e["freq"]), -int(e["len"]), tie_key(data(e))))
+    out, per_ctx = [], {}
+    for e in keep:
+        c = int(e["ctx"])
+        per_ctx[c] = per_ctx.get(c, 0) + 1
+        if per_ctx[c] <= 65536:
+            out.append(e)
+    return np.array(out, dtype=host.NGRAM_DTYPE)
+
+
+@pytest.mark.parametrize("kind", [host.RECTANGULAR, host.SINGLE_PACKED, host.MULTI_PACKED])
+def test_packing_selected_ngrams_is_the_same_file(kind):
+    """dinth_pack_dictionary over the selection in dictionary order (the device's dint_select_ngrams; here in Python) ==
+    the whole host construction, byte for byte."""
+    coll = host.synth_collection(60_000, universe=50_000, seed=21)
+    entries = _python_ngram_entries(coll, kind == host.MULTI_PACKED)
+    chosen = _select_in_python(entries, coll.gaps, coll.num_postings, tie_key=lambda d: d)
+    assert host.pack_dictionary(kind, coll.gaps, chosen) == host.build_dictionary(kind, coll)
+    with pytest.raises(Exception):
+        bad = chosen.copy()
+        bad["len"][3] = 3   # not a power of two
+        host.pack_dictionary(kind, coll.gaps, bad)
+
+
+def test_tie_order_does_not_move_the_compression_ratio():
+    """the reference's order among n-grams of equal count depends on libstdc++ (unordered_map iteration,
+    std::sort), so dictionaries can only be compared by what they achieve: on a sample of the shape of SURVEY Appendix B
+    (clustered gaps, a 5 M-document universe) dictionaries built with the ties in the deterministic order, in the
+    reverse order and in a shuffled order compress the sample to within 1 % of each other."""
+    coll = host.synth_collection(300_000, universe=5_000_000, seed=1459)
+    entries = _python_ngram_entries(coll, False)
+    r = np.random.default_rng(3)
+    salt = {}
+
+    def shuffled(d):
+        return salt.setdefault(d, float(r.random()))
+
+    bpi = {}
+    for name, key in (("deterministic", lambda d: d), ("reversed", lambda d: tuple(-x for x in d)), ("shuffled", shuffled)):
+        chosen = _select_in_python(entries, coll.gaps, coll.num_postings, tie_key=key)
+        dict_file = host.pack_dictionary(host.SINGLE_PACKED, coll.gaps, chosen)
+        enc, _ = host.encode_vroom(host.SINGLE_PACKED, dict_file, coll, unit_ints=8192)
+        bpi[name] = enc.size * 8 / coll.num_postings
+    assert bpi["deterministic"] == pytest.approx(
+        host.encode_vroom(host.SINGLE_PACKED, host.build_dictionary(host.SINGLE_PACKED, coll), coll, unit_ints=8192)[0].size * 8 / coll.num_postings)
+    for name in ("reversed", "shuffled"):
+        assert abs(bpi[name] - bpi["deterministic"]) / bpi["deterministic"] < 0.01, bpi

@@ -326,6 +326,31 @@ def test_block_statistics_on_the_device(device, request, kind, corpus_name):
     assert ms > 0
 
 
+@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
+def test_selection_on_the_device_is_in_dictionary_order(device, small_corpus, kind):
+    """dint_select_ngrams: every context's kept n-grams most frequent first, then the longer, then by their integers; at
+    most 65536 per context; nothing the filter drops; and exactly the entries the host's selection appends."""
+    import torch
+
+    coll = small_corpus.coll
+    gaps = np.ascontiguousarray(coll.gaps, dtype=np.uint32)
+    gaps_dev = torch.from_numpy(gaps.view(np.int32)).cuda()
+    starts = np.zeros(len(coll.lens) + 1, dtype=np.uint64)
+    np.cumsum(coll.lens, out=starts[1:])
+    entries, _ = device.count_ngrams(gaps_dev, starts, kind == host.MULTI_PACKED)
+    chosen = device.select_ngrams(gaps_dev, entries, coll.num_postings, top_k=65536)
+    small = device.select_ngrams(gaps_dev, entries, coll.num_postings, top_k=100)
+    assert 0 < len(chosen) <= len(entries)
+    key = lambda e: (int(e["ctx"]), -int(e["freq"]), -int(e["len"]), tuple(int(x) for x in gaps[int(e["pos"]):int(e["pos"]) + int(e["len"])]))
+    keys = [key(e) for e in chosen]
+    assert keys == sorted(keys) and len(set(keys)) == len(keys)
+    for c in np.unique(chosen["ctx"]):
+        assert int((chosen["ctx"] == c).sum()) <= 65536
+        mine = [k for k in keys if k[0] == int(c)]
+        assert [key(e) for e in small if int(e["ctx"]) == int(c)] == mine[:100]
+    assert host.pack_dictionary(kind, gaps, chosen) == host.build_dictionary(kind, coll)
+
+
 def test_ngram_counts_of_a_tiny_collection(device):
     import torch
 

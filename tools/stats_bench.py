@@ -20,7 +20,7 @@ for typ in ("single_packed_dint", "multi_packed_dint"):
     ngrams = sum(coll.num_postings // k for k in (1, 2, 4, 8, 16))
     res[typ] = {"identical_files": dev_file == host_file, "count_kernel_ms": round(ms, 3),
                 "G_ngrams_per_s": round(ngrams / ms / 1e6, 2),
-                "device_path_s (upload, count, compact, copy back, host selection)": round(t_dev, 3),
+                "device_path_s (upload, count, compact, select + sort on the device, copy back, host packing)": round(t_dev, 3),
                 "host_path_s": round(t_host, 3)}
     print(typ, json.dumps(res[typ]), flush=True)
 if out_path:
