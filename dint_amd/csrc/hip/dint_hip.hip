@@ -168,6 +168,8 @@ struct sched_cache {
     const void* d_spans = nullptr;
     size_t enc_bytes = 0, n_units = 0, out_capacity = 0;
     uint32_t only_full = 0;
+    bool items_known = false;  // n_items has been read back (a prepared unit table does, once)
+    uint32_t n_items = 0;      // work items of the unit queue: 0 = every unit is a bundle member
     bool matches(const void* dd, const void* enc, size_t eb, const void* units, size_t n, const void* spans, size_t cap,
                  uint32_t full) const {
         return valid && dict == dd && d_enc == enc && enc_bytes == eb && d_units == units && n_units == n && d_spans == spans &&
@@ -560,6 +562,7 @@ int dint_dict_create(int kind, const void* file_bytes, size_t len, int device, d
     const size_t full = size_t(kLdsWords) * 4;
     if (!all_lds(reinterpret_cast<const void*>(&decode_single_kernel), full) ||
         !all_lds(reinterpret_cast<const void*>(&decode_multi_kernel), full) ||
+        !all_lds(reinterpret_cast<const void*>(&decode_multi_bundles_kernel), full) ||
         !all_lds(reinterpret_cast<const void*>(&decode_single_index_kernel), full) ||
         !all_lds(reinterpret_cast<const void*>(&decode_multi_index_kernel), full) ||
         !all_lds(reinterpret_cast<const void*>(&decode_single_query_kernel), full) ||
@@ -752,6 +755,7 @@ static int build_schedule(const dint_dict* dd, const uint8_t* d_enc, size_t enc_
     run_schedule_kernels(dd, d_enc, enc_bytes, d_units, n_units, out_capacity, only_full, d_spans, L, s);
     HIP_TRY(hipGetLastError());
     cache->valid = true;
+    cache->items_known = false;
     cache->dict = dd, cache->d_enc = d_enc, cache->enc_bytes = enc_bytes, cache->d_units = d_units, cache->n_units = n_units;
     cache->d_spans = d_spans, cache->out_capacity = out_capacity, cache->only_full = only_full;
     return DINT_OK;
@@ -786,10 +790,13 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
     dint_dict* mut = const_cast<dint_dict*>(dd);
     // (an in-index launch — blocks, docIDs, freqs + 1 — runs the kernels compiled for that; the vroom kernels carry none of it)
     const bool index_launch = only_full != 0 || plus_one != 0 || d_unit_base != nullptr || d_gaps_left != nullptr;
+    bool bundles_only = false;  // (set below: a kept schedule that is known to have left the unit queue empty)
     auto launch_kernel = [&]() {
         const bool multi = dd->kind == DINT_DICT_MULTI_PACKED;
         if (index_launch)
             hipLaunchKernelGGL(multi ? decode_multi_index_kernel : decode_single_index_kernel, dim3(grid), dim3(kBlockThreads), lds_bytes, s, a);
+        else if (multi && bundles_only)
+            hipLaunchKernelGGL(decode_multi_bundles_kernel, dim3(grid), dim3(kBlockThreads), lds_bytes, s, a);
         else
             hipLaunchKernelGGL(multi ? decode_multi_kernel : decode_single_kernel, dim3(grid), dim3(kBlockThreads), lds_bytes, s, a);
     };
@@ -842,6 +849,7 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
                 if (st != DINT_OK) return st;
             }
             L.place(cache->d_mem);
+            bundles_only = !index_launch && cache->items_known && cache->n_items == 0;
         } else {
             const uint32_t ss = uint32_t(mut->launches % dint_dict::kSchedSlots);
             const int prev = mut->sched_user[ss];
@@ -913,7 +921,16 @@ int dint_unit_table_create(const dint_dict* dd, const uint8_t* d_enc, size_t enc
     t->out_capacity = out_capacity;
     if (n_units >= 2 && n_units < 0xFFFFFFFFull && !dd->no_bundles) {
         int st = build_schedule(dd, d_enc, enc_bytes, d_units, n_units, out_capacity, 0, nullptr, &t->sched, static_cast<hipStream_t>(stream));
-        if (st == DINT_OK && !hip_ok(hipStreamSynchronize(static_cast<hipStream_t>(stream)), "hipStreamSynchronize")) st = DINT_ERR_HIP;
+        if (st == DINT_OK) {  // how many work items the unit queue got (none: the bundles-only kernel serves the table)
+            sched_layout L(n_units);
+            L.place(t->sched.d_mem);
+            uint32_t n_items = 0;
+            if (!hip_ok(hipMemcpyAsync(&n_items, L.d_n_items, 4, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)), "hipMemcpyAsync") ||
+                !hip_ok(hipStreamSynchronize(static_cast<hipStream_t>(stream)), "hipStreamSynchronize"))
+                st = DINT_ERR_HIP;
+            t->sched.n_items = n_items;
+            t->sched.items_known = st == DINT_OK;
+        }
         if (st != DINT_OK) {
             dint_unit_table_destroy(t);
             return st;

@@ -10,10 +10,10 @@
 //    output order;
 //  * per slot one metadata word ((size-1) << 24 | source): LDS for the hot codewords (a prefix
 //    of the dictionary), L2 for the cold ones, looked up one tile ahead;
-//  * the integers of a cold codeword come from a table of 16-byte rows (eight u16) addressed by
-//    the slot value alone, fetched by LDS-DMA (buffer_load ... lds) straight into the slot's own
-//    staging cell — cell (k, lane) of the wave's 256 — at the end of the previous tile: no
-//    registers, no allocation, no worklist, one lane request per cold codeword;
+//  * the integers of a cold codeword come from L2, 16-byte HEADS addressed by the slot value alone (the metadata word and
+//    the first six integers in one lane request, requested one tile ahead) and, for the few entries of more than six,
+//    32-byte tails requested when the heads are in; both land in STAGING CELLS of the wave's LDS scratch, allocated in
+//    slot order by one wave scan (a cell per exception literal, one to three per cold codeword);
 //  * header/payload classification: a table-driven per-lane state machine, iterated until the
 //    lane-to-lane carries agree (one or two rounds);
 //  * a local prefix plus ONE DPP wave scan gives every codeword its output offset and ordinal;
@@ -27,11 +27,11 @@
 //    (cold rows, exception literals). Exactly n integers are written per unit, nothing past them
 //    (the reference needs a pre-zeroed buffer and a 256-word overflow area,
 //    include/dint/dint_codecs.hpp:11, dict_posting_list.hpp:296);
-//  * an exception literal sits in its slot's staging cell as 32 bits: the gather takes the low half, and
-//    — told by bit 0 of the source address — the upper half of a literal >= 65536 (one extra
-//    predicated read in the groups that hold one); a dictionary entry holding such a value and a cold
-//    entry of 16 integers (two in a DSF-65536-16 dictionary) are SLOW: expanded as zeros, then written
-//    by the codeword's own lane straight to global memory (slow_stores), behind the tile's stores;
+//  * an exception literal sits in its staging cell as 32 bits: the gather takes the low half, and — told
+//    by bit 31 of its codeword's delta entry (delta_word) — the upper half of a literal >= 65536 (four more
+//    reads in the 256-output groups that hold one); a dictionary entry holding such a value, and whatever
+//    finds no staging cell, are SLOW: expanded as zeros, then written by the codeword's own lane straight
+//    to global memory (slow_stores), behind the tile's stores;
 //  * WAITS: gfx950 counts loads and stores in one in-order counter, so a tile has exactly one
 //    wait point — before its expansion — where everything prefetched is consumed (read-write
 //    asm barriers, so that the compiler never adds a wait behind the stores, which would be a
@@ -40,7 +40,7 @@
 // LDS (160 KB/CU, one 1024-thread workgroup per CU):
 //   [ 256 u16 zeros | hot meta | hot payloads (u16) ]  <= kHotImageWords, shared by 16 waves
 //   [ slot classification table, 1.3 KB ]
-//   16 x [ {flag word, rank base} pairs | per-codeword delta table | 256 staging cells of 16 bytes ]
+//   16 x [ {flag word, rank base} pairs | per-codeword delta table | kStageCells staging cells of 16 bytes ]
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -89,7 +89,14 @@ constexpr uint32_t kMaxCap = 2048;                    // outputs per expansion b
 // entries for codewords that are not live in a batch), staging cells
 constexpr uint32_t kFwWords = 2 * 64 + 4;              // 64 pairs: flag positions are taken mod 2048
 constexpr uint32_t kDeltaWords = kTileSlots + 4;
-constexpr uint32_t kStageWords = 4 * kTileSlots;       // one 16-byte cell per slot: cell (k, lane) = 64 k + lane
+// 16-byte staging cells of a tile: exception literals (one each), cold codewords' integers (one to three each). A tile of the
+// bench stream takes about 105; what finds no cell goes through slow_stores (correct, slow). Every cell less is 64 bytes
+// more of the dictionary in LDS: 256 -> 176 cells = 20 KB = 69 -> 74 % of the codewords on chip, -2.6 % time at 10^9
+// postings (144: -2.9 %, 128: no better — the overflow path begins to show; profiles/r03_cells.txt).
+#ifndef DINT_STAGE_CELLS
+#define DINT_STAGE_CELLS 176
+#endif
+constexpr uint32_t kStageWords = 4 * DINT_STAGE_CELLS;
 #ifdef DINT_PROFILE
 constexpr uint32_t kProfWords = 16;
 #else
@@ -2244,7 +2251,10 @@ __device__ __forceinline__ decode_args own_scalars(const decode_args& k) {
 // INDEX: an in-index launch (256-posting blocks: docIDs formed in the expansion, freqs + 1, full blocks only). The
 // vroom kernels are compiled without any of that: the per-group branches of the expansion, and the masks the compiler
 // puts on every gathered integer because the docID arithmetic might read it, are gone from their loops.
-template <bool MULTI, bool INDEX, bool QUERY = false>
+// BUNDLES_ONLY: a multi-dictionary launch whose schedule left the unit queue empty (a block-granular unit table: every
+// unit fits a tile) — compiled without the unit queue and decode_unit_multi's segment loop, which is the larger half of
+// the general kernel and what its register allocation is shaped by.
+template <bool MULTI, bool INDEX, bool QUERY = false, bool BUNDLES_ONLY = false>
 __device__ __forceinline__ void decode_kernel_body(const decode_args& kernarg, const query_pages* qp = nullptr,
                                                    const round_tail* tail = nullptr) {
     decode_args a_ = own_scalars(kernarg);
@@ -2349,8 +2359,8 @@ __device__ __forceinline__ void decode_kernel_body(const decode_args& kernarg, c
     // the chunks follow the (few) units on their own.
     // (Prefetching the next item's description as well — two items ahead — was measured: no gain; what a wave
     // waits for here is the vector-memory front end, not the round trip.)
-    uint64_t w = take(ask());
-    while (w != ~0ull) {
+    uint64_t w = BUNDLES_ONLY ? ~0ull : take(ask());
+    while (!BUNDLES_ONLY && w != ~0ull) {
         SECTION(pf, 14, "draw");
         uint32_t ticket = ask();
         const uint64_t uu = uniform64(!QUERY && a.sched ? uint64_t(a.items[w]) : w);
@@ -2401,6 +2411,9 @@ __global__ __launch_bounds__(kBlockThreads, DINT_MIN_WAVES) void decode_single_k
 }
 __global__ __launch_bounds__(kBlockThreads, DINT_MIN_WAVES) void decode_multi_kernel(decode_args a) {
     decode_kernel_body<true, false>(a);
+}
+__global__ __launch_bounds__(kBlockThreads, DINT_MIN_WAVES) void decode_multi_bundles_kernel(decode_args a) {
+    decode_kernel_body<true, false, false, true>(a);
 }
 __global__ __launch_bounds__(kBlockThreads, DINT_MIN_WAVES) void decode_single_index_kernel(decode_args a) {
     decode_kernel_body<false, true>(a);
@@ -2845,8 +2858,10 @@ __device__ __forceinline__ void decode_query_page(const decode_args& a, const wa
         }
     } else {
         // a short block: binary interpolative code (block_codecs.hpp:130-150) — the code IS the prefix sums
-        lds_u32* const tmp = (lds_u32*)stage_of(c.scratch);  // (the staging cells are free between two segments)
-        static_assert(3 * 256 + 2 <= kStageWords, "the interpolative decoder's tables live in the staging cells");
+        // (the delta table and the staging cells, one stretch of the wave's scratch, are free between two segments; the
+        // flag words in front of them stay zero)
+        lds_u32* const tmp = (lds_u32*)delta_of(c.scratch);
+        static_assert(3 * 256 + 2 <= kDeltaWords + kStageWords, "the interpolative decoder's tables live in the delta table + staging cells");
         const uint32_t base = uniform(r->base);
         u32x4 ov = {0, 0, 0, 0};
         if (in_off < a.enc_bytes)
