@@ -5,7 +5,7 @@ bench's 5e9-integer launch? The same launch — five replicas of the 1e9-posting
 (identical values), (c) also all reading ONE copy of the stream. Same process, same box, same number of integers.
 usage: tools/footprint_probe.py [postings]"""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from dint_amd import device, host

@@ -1,6 +1,6 @@
 """Development aid: kernel time vs the byte offset of the stream (and of the output) inside one allocation."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT]
 import numpy as np, torch
 from dint_amd import host, device

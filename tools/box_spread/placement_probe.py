@@ -2,7 +2,7 @@
 One process, one collection; re-create the dictionary / the output buffer / the stream buffer in turn
 and time the same decode."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT]
 import numpy as np, torch
 from dint_amd import host, device

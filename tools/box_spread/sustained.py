@@ -2,7 +2,7 @@
 """Development aid (GPU box): the decode kernel's time launch by launch over a long back-to-back run — does it
 hold its speed? usage: tools/sustained.py [postings] [launches] [idle seconds between bursts]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT]
 import numpy as np, torch
 from dint_amd import device, host

@@ -1,8 +1,8 @@
 #!/bin/bash
 # GPU box: the judged artefacts of a round — GPU tests, bench.py (default command), rocprofv3 kernel stats, the
 # FETCH_SIZE / WRITE_SIZE passes and one SQ pass of the same bench command, then the bench line again with the
-# measured traffic attached. usage: [SKIP_TESTS=1] tools/profile_round.sh r02 [extra bench args]
-TAG=${1:-r02}; shift
+# measured traffic attached. usage: [SKIP_TESTS=1] tools/profile_round.sh r03 [extra bench args]
+TAG=${1:-r03}; shift
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd $R
 if [ -z "$SKIP_TESTS" ]; then python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log; fi
