@@ -567,6 +567,8 @@ int dint_dict_create(int kind, const void* file_bytes, size_t len, int device, d
         !all_lds(reinterpret_cast<const void*>(&decode_multi_index_kernel), full) ||
         !all_lds(reinterpret_cast<const void*>(&decode_single_query_kernel), full) ||
         !all_lds(reinterpret_cast<const void*>(&decode_multi_query_kernel), full) ||
+        !all_lds(reinterpret_cast<const void*>(&decode_single_query_fused_kernel), full) ||
+        !all_lds(reinterpret_cast<const void*>(&decode_multi_query_fused_kernel), full) ||
         !all_lds(reinterpret_cast<const void*>(&interpolative_tails_kernel), kTailLdsBytes)) {
         dint_dict_destroy(dd);
         return DINT_ERR_HIP;
@@ -1314,6 +1316,11 @@ static size_t tail_pages() {
     const char* e = std::getenv("DINT_QUERY_TAIL_PAGES");
     return e ? size_t(std::strtoull(e, nullptr, 10)) : size_t(4);
 }
+// (a query of at most this many candidate pages runs as ONE launch of one workgroup: query_fused_body)
+static size_t fused_pages() {
+    const char* e = std::getenv("DINT_QUERY_FUSED_PAGES");
+    return e ? size_t(std::strtoull(e, nullptr, 10)) : size_t(2);
+}
 static int decode_pages_lean(dint_query_index* qi, const uint32_t* d_ids, const uint32_t* d_count, size_t bound, uint32_t* d_docs,
                              uint32_t* ctrl, uint32_t retire, hipStream_t s, const query_pages* search,
                              const round_tail* tail = nullptr);
@@ -1455,8 +1462,9 @@ static int and_queries_impl(dint_query_index* qi, const dint_dict* freqs_dict, c
     // and behind them — zeros, copied in with them: one copy instead of a copy and a clear — every counter the
     // call's launches count in, and the result counters (u64 each)
     const size_t in_words = (2 * n_pages + h_first.size() + h_blocks.size() + 31) / 32 * 32;
-    const size_t ctrl_words = (rounds + 1) * kCtrlWords + 2 * n_queries;
-    const size_t up_words = in_words + ctrl_words;
+    const size_t ctrl_words = ((rounds + 1) * kCtrlWords + 2 * n_queries + 1) / 2 * 2;
+    const size_t step_words = (rounds + 1) * ((sizeof(fused_step) + 7) / 8 * 2);  // (the one-launch form's steps, 8-byte aligned)
+    const size_t up_words = in_words + ctrl_words + step_words;
     const size_t stage_bytes = std::max(up_words * 4, n_queries * sizeof(unsigned long long));
     if (qi->h_stage_cap < stage_bytes) {
         if (qi->h_stage) (void)hipHostFree(qi->h_stage);
@@ -1483,6 +1491,88 @@ static int and_queries_impl(dint_query_index* qi, const dint_dict* freqs_dict, c
     uint32_t* const d_term_blocks = d_term_first + h_first.size();
     uint32_t* const d_ctrl = qi->inputs.p + in_words;
     unsigned long long* const d_counts = reinterpret_cast<unsigned long long*>(d_ctrl + (rounds + 1) * kCtrlWords);
+    // ---- what the host knows of the rounds before anything runs: a bound of the pages each decodes ------------------
+    uint64_t round0_blocks = 0;
+    if (rounds)
+        for (size_t q = 0; q != n_queries; ++q) round0_blocks += h_blocks[q];
+    std::vector<size_t> round_bound(rounds, 0);
+    bool small_rounds = rounds != 0 && round0_blocks != 0 && n_pages < lean_pages() && qi->index_bytes >= 8;
+    for (size_t r = 0; r != rounds; ++r) {
+        uint64_t list_blocks = 0;
+        for (size_t q = 0; q != n_queries; ++q) list_blocks += h_blocks[r * n_queries + q];
+        round_bound[r] = size_t(std::min<uint64_t>(n_slots, list_blocks));
+        small_rounds = small_rounds && list_blocks != 0 && round_bound[r] < lean_pages();
+    }
+    // A query of a page or two of candidates: the whole chain — candidates, then every round's pages and tail — in ONE
+    // launch of one workgroup (query_fused_body; DINT_QUERY_FUSED_PAGES: at most that many candidate pages, 0: never).
+    const bool fused_ok = small_rounds && n_pages <= tail_pages() && n_pages <= fused_pages();
+    fused_step* const d_steps = reinterpret_cast<fused_step*>(qi->inputs.p + in_words + ctrl_words);
+    if (fused_ok) {
+        size_t max_pages = n_pages;
+        for (size_t r = 0; r != rounds; ++r) max_pages = std::max(max_pages, round_bound[r]);
+        if (!qi->probe.ensure(uint64_t(max_pages) * kPageSlots) || !qi->gaps_left.ensure(max_pages)) return DINT_ERR_HIP;
+        fused_step* const h_steps = reinterpret_cast<fused_step*>(static_cast<uint32_t*>(qi->h_stage) + in_words + ctrl_words);
+        const size_t nb = std::max<size_t>(1, qi->n_blocks);
+        const bool to_host = !freqs_dict && qi->d_stage != nullptr;
+        for (size_t k = 0; k != rounds + 1; ++k) {
+            fused_step st{};
+            st.gaps_left = qi->gaps_left.p;
+            st.qp.blocks = qi->d_blocks;
+            if (k == 0) {  // the candidate pages, the first round's search riding along (decode_pages_lean's candidate call)
+                st.out = qi->cand.p;
+                st.out_capacity = uint64_t(n_pages) * kPageSlots;
+                st.qp.page_query = d_page_query;
+                st.qp.term_first = d_term_first;
+                st.qp.term_blocks = d_term_blocks;
+                st.qp.block_max = qi->d_block_max;
+                st.qp.target = qi->target.p;
+                st.qp.needed = qi->d_needed;
+                st.qp.rank = qi->d_rank;
+                st.qp.touched = qi->d_touched;
+                st.qp.n_touched = d_ctrl + kCtrlWords;
+                st.qp.ids = d_page_block;
+                st.qp.count = nullptr;
+                st.qp.bound = n_pages;
+                st.qp.retire = 1u;
+            } else {  // round r: the touched pages, then the tail (the round-per-launch form's round_tail, below)
+                const size_t r = k - 1, set = r & 1, next_set = set ^ 1;
+                uint32_t* const ctrl = d_ctrl + (r + 1) * kCtrlWords;
+                st.out = qi->probe.p;
+                st.out_capacity = uint64_t(round_bound[r]) * kPageSlots;
+                st.qp.ids = qi->d_touched + set * nb;
+                st.qp.count = ctrl;
+                st.qp.bound = round_bound[r];
+                st.qp.retire = 0u;
+                round_tail& t = st.rt;
+                t.done = ctrl + 2;  // (not counted in: non-null says "this step has a tail")
+                t.cand = qi->cand.p;
+                t.n_slots = n_slots;
+                t.page_query = d_page_query;
+                t.blocks = qi->d_blocks;
+                t.target = qi->target.p;
+                t.term_blocks = d_term_blocks + r * n_queries;
+                t.rank = qi->d_rank + set * nb;
+                t.probe = qi->probe.p;
+                t.touched = qi->d_touched + set * nb;
+                t.n_touched = ctrl;
+                t.needed = qi->d_needed + set * nb;
+                if (r + 1 != rounds) {
+                    t.next_first = d_term_first + (r + 1) * n_queries;
+                    t.next_blocks = d_term_blocks + (r + 1) * n_queries;
+                    t.block_max = qi->d_block_max;
+                    t.next_needed = qi->d_needed + next_set * nb;
+                    t.next_rank = qi->d_rank + next_set * nb;
+                    t.next_touched = qi->d_touched + next_set * nb;
+                    t.next_n_touched = d_ctrl + (r + 2) * kCtrlWords;
+                } else {
+                    t.counts = d_counts;
+                    t.host_counts = to_host ? static_cast<unsigned long long*>(qi->d_stage) : nullptr;
+                    t.n_queries = uint32_t(n_queries);
+                }
+            }
+            std::memcpy(h_steps + k, &st, sizeof st);
+        }
+    }
     HIP_TRY(hipMemcpyAsync(qi->inputs.p, qi->h_stage, up_words * 4, hipMemcpyHostToDevice, s));
 
     const uint32_t tb = 256;
@@ -1492,9 +1582,6 @@ static int and_queries_impl(dint_query_index* qi, const dint_dict* freqs_dict, c
         qi->claims_dirty = false;
     }
     // candidates: the rarest list of every query
-    uint64_t round0_blocks = 0;
-    if (rounds)
-        for (size_t q = 0; q != n_queries; ++q) round0_blocks += h_blocks[q];
     query_pages search0{};
     search0.page_query = d_page_query;
     search0.term_first = d_term_first;
@@ -1506,8 +1593,23 @@ static int and_queries_impl(dint_query_index* qi, const dint_dict* freqs_dict, c
     search0.touched = qi->d_touched;
     search0.n_touched = d_ctrl + kCtrlWords;
     bool searched0 = false;
-    int st = decode_pages_counted(qi, d_page_block, nullptr, n_pages, qi->cand.p, d_ctrl, 1u, s, round0_blocks ? &search0 : nullptr,
-                                  &searched0);
+    int st = DINT_OK;
+    if (fused_ok) {
+        const dint_dict* dd = qi->docs;
+        decode_args a{};
+        a.dict = dd->view;
+        a.enc = qi->d_index;
+        a.enc_bytes = qi->index_bytes;
+        const size_t lds_bytes = (size_t(dd->view.hot_words) + kClassTableWords + kWavesPerBlock * kScratchWords) * 4;
+        if (dd->kind == DINT_DICT_MULTI_PACKED)
+            hipLaunchKernelGGL(decode_multi_query_fused_kernel, dim3(1), dim3(kBlockThreads), lds_bytes, s, a, d_steps, uint32_t(rounds + 1));
+        else
+            hipLaunchKernelGGL(decode_single_query_fused_kernel, dim3(1), dim3(kBlockThreads), lds_bytes, s, a, d_steps, uint32_t(rounds + 1));
+        HIP_TRY(hipGetLastError());
+        searched0 = true;
+    } else {
+        st = decode_pages_counted(qi, d_page_block, nullptr, n_pages, qi->cand.p, d_ctrl, 1u, s, round0_blocks ? &search0 : nullptr, &searched0);
+    }
     if (st != DINT_OK) {
         (void)hipStreamSynchronize(s);
         return st;
@@ -1534,15 +1636,12 @@ static int and_queries_impl(dint_query_index* qi, const dint_dict* freqs_dict, c
     // the last probe hands the results over itself (a few pages: every workgroup of it passes through one counter)
     bool results_to_host = !freqs_dict && qi->d_stage != nullptr && n_pages <= 4096;
     // Few candidates, few pages in every round (a single query): one launch per round — round_tail.
-    bool tail_form = searched0 && n_pages <= tail_pages();
-    std::vector<size_t> round_bound(rounds, 0);
-    for (size_t r = 0; r != rounds; ++r) {
-        uint64_t list_blocks = 0;
-        for (size_t q = 0; q != n_queries; ++q) list_blocks += h_blocks[r * n_queries + q];
-        round_bound[r] = size_t(std::min<uint64_t>(n_slots, list_blocks));
-        tail_form = tail_form && list_blocks != 0 && round_bound[r] < lean_pages();
+    const bool tail_form = searched0 && small_rounds && n_pages <= tail_pages();
+    if (fused_ok) {
+        counted = true;  // (the launch above was the whole query)
+        results_to_host = results_to_host && qi->d_stage != nullptr;
     }
-    if (tail_form) {
+    if (tail_form && !fused_ok) {
         const size_t nb = std::max<size_t>(1, qi->n_blocks);
         for (size_t r = 0; r != rounds; ++r) {
             const size_t set = r & 1, next_set = set ^ 1;
@@ -1585,7 +1684,7 @@ static int and_queries_impl(dint_query_index* qi, const dint_dict* freqs_dict, c
         }
         counted = true;
     }
-    for (size_t r = 0; r != rounds && !tail_form; ++r) {
+    for (size_t r = 0; r != rounds && !tail_form && !fused_ok; ++r) {
         const uint32_t* first = d_term_first + r * n_queries;
         const uint32_t* nblk = d_term_blocks + r * n_queries;
         uint32_t* const ctrl = d_ctrl + (r + 1) * kCtrlWords;

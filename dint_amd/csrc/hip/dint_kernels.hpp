@@ -2930,6 +2930,113 @@ __device__ __forceinline__ void decode_query_page(const decode_args& a, const wa
     }
 }
 
+// ---- a whole small query in ONE launch ------------------------------------------------------------------------
+// A query of a few candidate pages is a chain of dependent launches in the round-per-launch form — candidates (with the
+// first search riding along), then per further term the touched pages and the round's tail — and each launch costs the
+// caller ≈7.6 us (profiles/r02_query_trace_single.txt): 3.2 launches a query on the reference's log. Here ONE
+// workgroup walks the whole chain: a step = {the pages of a decode, where they go, the round's tail}; the 16 waves
+// take a step's pages in turn (wave w: pages w, w + 16, ...: no queue), a workgroup barrier separates a step's decode
+// from its tail and the tail from the next step (one CU, one L1: what a wave stored its neighbours read behind the
+// barrier), and the dictionary's LDS image is loaded once for all steps. How many pages a step has is what the
+// previous step's tail counted (qp.count), bounded by qp.bound.
+struct fused_step {
+    uint32_t* out;
+    uint64_t out_capacity;
+    uint8_t* gaps_left;
+    query_pages qp;
+    round_tail rt;  // rt.done == null: the step has no tail (the candidate pages)
+};
+
+template <bool MULTI>
+__device__ __forceinline__ void query_fused_body(const decode_args& kernarg, const fused_step* steps, uint32_t n_steps) {
+    const decode_args a = own_scalars(kernarg);
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    {
+        constexpr uint32_t kSteps = (kHotImageWords / 4 + kBlockThreads - 1) / kBlockThreads;
+        u32x4 part[kSteps];
+#pragma unroll
+        for (uint32_t k = 0; k != kSteps; ++k) {
+            const uint32_t i = threadIdx.x + k * kBlockThreads;
+            if (4 * i < a.dict.hot_words) part[k] = reinterpret_cast<const u32x4*>(a.dict.lds_image)[i];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k != kSteps; ++k) {
+            const uint32_t i = threadIdx.x + k * kBlockThreads;
+            if (4 * i < a.dict.hot_words) reinterpret_cast<u32x4*>(lds)[i] = part[k];
+        }
+    }
+    uint16_t* const cls = reinterpret_cast<uint16_t*>(lds + a.dict.hot_words);
+    build_class_table(cls);
+    uint32_t* const descs = lds + a.dict.hot_words + kDescWordAt;
+    if (threadIdx.x < 24) descs[threadIdx.x] = MULTI ? reinterpret_cast<const uint32_t*>(a.dict.descs)[threadIdx.x] : 0u;
+    const uint32_t lane = lane_id();
+    const uint32_t wave = uniform(threadIdx.x / kWave);
+    uint32_t* const scratch = lds + a.dict.hot_words + kClassTableWords + wave * kScratchWords;
+    for (uint32_t i = lane; i < kFwWords; i += kWave) scratch[i] = 0;  // the flag words start out zero
+    __syncthreads();
+    wave_ctx c;
+    c.lds = lds;
+    c.cls = cls;
+    c.descs = descs;
+    c.scratch = scratch;
+    c.lane = lane;
+    c.rs_dict = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.dict.tables), 0, int(a.dict.tables_bytes), 0x00020000);
+    c.heads_base = a.dict.heads_base;
+    c.tails_base = a.dict.tails_base;
+    c.goff_base = a.dict.goff_base;
+    c.gtable_base = a.dict.gtable_base;
+    prof_t pf;
+    for (uint32_t s = 0; s != n_steps; ++s) {
+        // (through the constant address space: scalar loads — a step's forty-odd pointers and counts are wave-uniform
+        // and belong in scalar registers; as ordinary loads they took 70 vector registers and spilled to scratch)
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef __attribute__((address_space(4))) const fused_step constant_step;
+        constant_step* const st = (constant_step*)(uintptr_t)(steps + s);
+#else
+        const fused_step* const st = steps + s;  // (the host pass only parses this)
+#endif
+        decode_args as = a;
+        as.out = st->out;
+        as.out_capacity = st->out_capacity;
+        as.gaps_left = st->gaps_left;
+        query_pages qp;
+        round_tail rt;
+#if defined(__HIP_DEVICE_COMPILE__)
+        {   // (member-wise: an address-space-4 struct has no copy constructor into a generic one)
+            typedef __attribute__((address_space(4))) const uint64_t constant_u64;
+            constant_u64* const src_q = (constant_u64*)(uintptr_t)&(steps + s)->qp;
+            constant_u64* const src_t = (constant_u64*)(uintptr_t)&(steps + s)->rt;
+            uint64_t* const dst_q = reinterpret_cast<uint64_t*>(&qp);
+            uint64_t* const dst_t = reinterpret_cast<uint64_t*>(&rt);
+            static_assert(sizeof(query_pages) % 8 == 0 && sizeof(round_tail) % 8 == 0, "copied as 64-bit words");
+#pragma unroll
+            for (uint32_t i = 0; i != sizeof(query_pages) / 8; ++i) dst_q[i] = src_q[i];
+#pragma unroll
+            for (uint32_t i = 0; i != sizeof(round_tail) / 8; ++i) dst_t[i] = src_t[i];
+        }
+#else
+        qp = st->qp;
+        rt = st->rt;
+#endif
+        uint64_t n_work = qp.bound;
+        if (qp.count) n_work = uniform(*qp.count) < n_work ? uniform(*qp.count) : n_work;
+        for (uint64_t page = wave; page < n_work; page += kWavesPerBlock) decode_query_page<MULTI>(as, c, qp, page, pf);
+        __syncthreads();
+        if (rt.done) {
+            and_round_tail(rt);
+            __syncthreads();
+        }
+    }
+}
+__global__ __launch_bounds__(kBlockThreads, DINT_MIN_WAVES) void decode_single_query_fused_kernel(decode_args a, const fused_step* steps,
+                                                                                                 uint32_t n_steps) {
+    query_fused_body<false>(a, steps, n_steps);
+}
+__global__ __launch_bounds__(kBlockThreads, DINT_MIN_WAVES) void decode_multi_query_fused_kernel(decode_args a, const fused_step* steps,
+                                                                                                uint32_t n_steps) {
+    query_fused_body<true>(a, steps, n_steps);
+}
+
 __global__ __launch_bounds__(kBlockThreads, DINT_MIN_WAVES) void decode_single_query_kernel(decode_args a, query_pages qp, round_tail t) {
     decode_kernel_body<false, true, true>(a, &qp, &t);
 }

@@ -28,7 +28,10 @@ def main():
     ap.add_argument("--cpu-queries", type=int, default=500)
     ap.add_argument("--forms", action="store_true", help="also time the single-query calls with each launch form forced")
     args = ap.parse_args()
-    args.forms = [("three_launches_per_decode", {"DINT_QUERY_LEAN_PAGES": "0"}),
+    args.forms = [("round_per_launch_no_fusing", {"DINT_QUERY_FUSED_PAGES": "0"}),
+                  ("whole_query_in_one_launch_up_to_1_page", {"DINT_QUERY_FUSED_PAGES": "1"}),
+                  ("whole_query_in_one_launch_up_to_4_pages", {"DINT_QUERY_FUSED_PAGES": "4"}),
+                  ("three_launches_per_decode", {"DINT_QUERY_LEAN_PAGES": "0"}),
                   ("one_launch_per_decode", {"DINT_QUERY_TAIL_PAGES": "0"}),
                   ("round_tail_up_to_4_pages", {"DINT_QUERY_TAIL_PAGES": "4"}),
                   ("round_tail_up_to_16_pages", {"DINT_QUERY_TAIL_PAGES": "16"}),

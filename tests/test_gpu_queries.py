@@ -112,6 +112,29 @@ def test_both_page_decode_forms(device, small_corpus, monkeypatch, kind, lean_pa
     qi.close()
 
 
+@pytest.mark.parametrize("fused_pages", ["0", "1", "4"])
+@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
+def test_whole_query_in_one_launch(device, small_corpus, monkeypatch, kind, fused_pages):
+    """A query of a few candidate pages runs as ONE launch of one workgroup that walks the whole chain — candidates, every
+    round's pages, every round's tail (query_fused_body); DINT_QUERY_FUSED_PAGES moves the switch (0: never — the
+    round-per-launch form). Single queries and the freqs variant (whose counting half takes the same path), all forms
+    equal to the plain intersection."""
+    monkeypatch.setenv("DINT_QUERY_FUSED_PAGES", fused_pages)
+    monkeypatch.setenv("DINT_QUERY_TAIL_PAGES", "4")
+    ix = get_index(small_corpus, kind)
+    qi = _query_index(device, ix, kind)
+    fd = device.Dictionary(kind, ix.freqs_dict)
+    qs = reference_queries(len(ix.lens))[:120] + heavy_queries(ix.lens, 40, seed=9)
+    for q in qs:
+        want = intersect(ix.docids, ix.bounds, q)
+        assert int(qi.and_queries([q])[0]) == want, q
+    for q in qs[::7]:
+        counts, sums, _ = qi.and_queries_with_freqs(fd, [q])
+        assert int(counts[0]) == intersect(ix.docids, ix.bounds, q)
+    assert np.array_equal(qi.and_queries(qs), np.array([intersect(ix.docids, ix.bounds, q) for q in qs], dtype=np.uint64))
+    qi.close()
+
+
 @pytest.mark.parametrize("tail_pages", ["0", "4", "64"])
 @pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
 def test_round_tail_over_several_workgroups(device, monkeypatch, kind, tail_pages):
