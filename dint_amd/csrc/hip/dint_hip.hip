@@ -1600,7 +1600,13 @@ static int and_queries_impl(dint_query_index* qi, const dint_dict* freqs_dict, c
         a.dict = dd->view;
         a.enc = qi->d_index;
         a.enc_bytes = qi->index_bytes;
-        const size_t lds_bytes = (size_t(dd->view.hot_words) + kClassTableWords + kWavesPerBlock * kScratchWords) * 4;
+        // lists of fewer than 256 postings are one interpolative block each and need no dictionary: a query of such lists
+        // only (most of a query log's) runs without the 88 KB LDS image — nothing reads it
+        bool any_full = false;
+        for (size_t q = 0; q != n_queries; ++q)
+            for (uint32_t term : plan[q]) any_full = any_full || qi->list_len[term] >= kBlock;
+        if (!any_full) a.dict.hot_words = 0;
+        const size_t lds_bytes = (size_t(a.dict.hot_words) + kClassTableWords + kWavesPerBlock * kScratchWords) * 4;
         if (dd->kind == DINT_DICT_MULTI_PACKED)
             hipLaunchKernelGGL(decode_multi_query_fused_kernel, dim3(1), dim3(kBlockThreads), lds_bytes, s, a, d_steps, uint32_t(rounds + 1));
         else
