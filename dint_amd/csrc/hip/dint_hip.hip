@@ -240,7 +240,7 @@ namespace {
 //   gtable   = [the file's payload words][16 words of padding], 32-bit: the slow path's source;
 //   LDS image = [256 u16 zeros]{[hot meta of dictionary d: hot_k[d] words]}[hot payloads as u16];
 //   hot meta = (size-1) << 24 | byte offset of the payload inside the image (runs -> the zeros), one dummy
-//              word behind the last;
+//              word behind the last; the two exception markers: kMetaException (one integer, from one staging cell);
 //   payloads = the union of the hot entries' table intervals, each word once (the packed formats nest
 //              short entries inside long ones: single_dictionary.hpp:109-160), as u16.
 // 16 bits per integer on chip: every value of a DSF dictionary built from d-gaps is far below 65536. An
@@ -313,10 +313,11 @@ int choose_hot_set(parsed_dict const& pd, hot_layout& out) {
             halves.push_back(uint16_t(pd.table[w]));
         }
     for (uint32_t d = 0; d != nd; ++d)
-        for (uint32_t i = 0; i != hot_k[d]; ++i) {
+        for (uint32_t i = 0; i != std::max<uint32_t>(2, hot_k[d]); ++i) {
             const uint32_t sz = pd.size[pd.start[d] + i];
             uint32_t m;
-            if (entry_is_wide(pd, d, i)) m = ((sz - 1) << 24) | kMetaCold | kMetaSlow;
+            if (i < 2) m = kMetaException;  // (the exception markers)
+            else if (entry_is_wide(pd, d, i)) m = ((sz - 1) << 24) | kMetaCold | kMetaSlow;
             else m = ((sz - 1) << 24) | (entry_payload_words(pd, d, i) ? 2 * where[pd.off[pd.start[d] + i]] : 0u);  // 0: the zero region
             const size_t at = 2 * (size_t(out.descs[d].hot_base) + i);
             halves[at] = uint16_t(m);
@@ -356,7 +357,7 @@ int stage_dictionary(dint_dict& dd, parsed_dict const& pd) {
             if (sz == 0 || sz > 256) return DINT_ERR_FORMAT;
             const uint32_t pw = (i >= kReserved && sz <= kMaxEntry) ? sz : 0;
             if (pw == 0) {  // runs copy zeros: their source is the zero region at the start of the LDS image
-                heads[slot * 4] = (sz - 1) << 24;
+                heads[slot * 4] = i < 2 ? kMetaException : (sz - 1) << 24;
                 continue;
             }
             bool slow = false;

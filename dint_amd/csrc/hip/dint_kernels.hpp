@@ -114,6 +114,8 @@ constexpr uint32_t kMetaCold = 1u << 23;              // the integers come throu
 constexpr uint32_t kMetaSlow = 1u << 22;              // ... or, with this bit, from gtable through slow_stores
 constexpr uint32_t kMetaOffMask = (1u << 20) - 1;     // hot: byte offset of the integers (u16 each) in the LDS image; else 0
                                                       // bits 20-21: staging cells a cold codeword takes (1: up to 6 integers, 2: up to 14, 3)
+constexpr uint32_t kMetaException = 1u << 20;         // what the two exception markers (slot values 0 and 1) look up: one integer, one
+                                                      // staging cell — the literal that follows the marker in the stream goes there
 constexpr uint32_t kQueueShards = 8;                  // dynamic unit queue: one counter per shard
 constexpr uint32_t kQueueStride = 32;                 // words between counters (own 128-byte line each)
 constexpr uint32_t kClockWordAt = 16;                 // in the chunk counter's line: shader-clock cycles of the launch's first wave (u64)
@@ -484,6 +486,16 @@ __device__ __forceinline__ uint32_t delta_word(uint32_t src2, uint32_t rel) {
 // batch), `source - position` by ordinal, and the rank base (codewords before the word, minus one) of every
 // flag word that begins inside this lane's outputs.
 //
+// The rank base of every flag word — the codewords that start before it, minus one — is the running count of the
+// flags themselves: lane w reads word w behind the ORs (a wave's LDS operations execute in order), one wave scan. (Until
+// round 3 every lane wrote the bases of the words that begin inside its outputs, in a loop: as many rounds for the whole
+// wave as the lane with the longest run needed, 17 vector instructions each — a fifth of the kernel's.)
+__device__ __forceinline__ void rank_bases(uint8_t* fw, uint32_t lane) {
+    const uint32_t flags = *reinterpret_cast<const uint32_t*>(fw + 8 * lane);
+    const uint32_t cnt = uint32_t(__builtin_popcount(flags));
+    *reinterpret_cast<uint32_t*>(fw + 8 * lane + 4) = wave_inclusive_sum(cnt) - cnt - 1u;
+}
+
 // A plain tile — four codeword headers in every lane, nothing clamped, one batch: ordinals are 4 lane + k, the
 // four deltas of a lane are one 16-byte store, nothing is masked.
 __device__ __forceinline__ void tables_plain(const tile_slots& t, uint8_t* fw, uint8_t* delta, uint32_t lane) {
@@ -499,20 +511,14 @@ __device__ __forceinline__ void tables_plain(const tile_slots& t, uint8_t* fw, u
         d[k] = delta_word(t.src2[k], rel[k]);
     }
     *reinterpret_cast<u32x4*>(delta + 16 * lane) = d;
-    const uint32_t rel_end = t.obase + t.lsum;
-#pragma nounroll
-    for (uint32_t w = (t.obase + 31u) >> 5; 32u * w < rel_end; ++w) {  // 0 or 1 rounds for most lanes
-        const uint32_t lim = 32u * w - t.obase;  // codewords of this lane that start before the word: 0 (lim = 0) .. 4
-        const uint32_t cnt = (lim != 0 ? 1u : 0u) + (t.off[1] < lim ? 1u : 0u) + (t.off[2] < lim ? 1u : 0u) + (t.off[3] < lim ? 1u : 0u);
-        *reinterpret_cast<uint32_t*>(fw + 8 * w + 4) = 4 * lane + cnt - 1u;
-    }
+    rank_bases(fw, lane);
 }
 
 // Any tile, one batch of it: the lanes `inb`, outputs and ordinals counted from `done` / `rdone`. Every slot
 // runs the same instructions: a codeword that is not live in this batch ORs a zero into an in-range flag word
 // and parks its delta in a dummy.
 __device__ __forceinline__ void tables_general(const tile_slots& t, uint8_t* fw, uint8_t* delta, bool inb, uint32_t done,
-                                               uint32_t rdone) {
+                                               uint32_t rdone, uint32_t lane) {
     const uint32_t inbM = inb ? ~0u : 0u;
     const uint32_t rel0 = t.obase - done, ord0 = t.rbase - rdone;
 #pragma unroll
@@ -524,17 +530,7 @@ __device__ __forceinline__ void tables_general(const tile_slots& t, uint8_t* fw,
         const uint32_t ord = (lv & (ord0 + t.lord(k))) | (~lv & (kTileSlots + k));
         *reinterpret_cast<uint32_t*>(delta + 4 * ord) = delta_word(t.src2[k], rel);
     }
-    if (inb) {
-        const uint32_t rel_end = rel0 + t.lsum;
-#pragma nounroll
-        for (uint32_t w = (rel0 + 31u) >> 5; 32u * w < rel_end; ++w) {
-            const uint32_t lim = 32u * w - rel0;
-            uint32_t cnt = 0;
-#pragma unroll
-            for (uint32_t k = 0; k != kSPL; ++k) cnt += ((t.liveb >> k) & (t.off[k] < lim ? 1u : 0u));
-            *reinterpret_cast<uint32_t*>(fw + 8 * (w & 63u) + 4) = ord0 + cnt - 1u;
-        }
-    }
+    rank_bases(fw, lane);
 }
 
 // A first-fit bundle (the multi-dictionary kernel, see bundle_map_first_fit) is any set of up to 8 units of one chunk;
@@ -646,7 +642,7 @@ __device__ __forceinline__ void expand_tile(const tile_slots& t, bool plain, boo
     if (ONE_BATCH || __builtin_expect(t.total <= kCap, 1)) {  // (ONE_BATCH: the caller knows; what lies past the cap is not decoded)
         const uint32_t total = t.total < kCap ? t.total : kCap;
         if (plain) tables_plain(t, fw, delta, lane);
-        else tables_general(t, fw, delta, t.lsum != 0, 0u, 0u);
+        else tables_general(t, fw, delta, t.lsum != 0, 0u, 0u, lane);
         wave_lds_fence();
         SECTION(pf, 7, "7_rows2");
         before_gathers();
@@ -670,7 +666,7 @@ __device__ __forceinline__ void expand_tile(const tile_slots& t, bool plain, boo
             if (done == 0) before_gathers();
             break;
         }
-        tables_general(t, fw, delta, inb, done, rdone);
+        tables_general(t, fw, delta, inb, done, rdone, lane);
         wave_lds_fence();
         if (done == 0) before_gathers();
         // (batches of lanes do not end on block boundaries: no docIDs here — the caller leaves such a tile as gaps)
@@ -821,6 +817,17 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const w
         SECTION(pf, 2, "2_sizes");
         // ---- 2. sizes, offsets; where each codeword's integers are -----------------------------------
         tile_slots t;
+        // A payload slot decodes to nothing and takes nothing: its metadata word (whatever its value looks up) becomes
+        // zero, and the 1 of "size - 1" is its live bit. An exception header needs no special case here: the
+        // metadata of the two markers says one integer from one staging cell (stage_dictionary, choose_hot_set).
+        uint32_t lv1[kSPL] = {1u, 1u, 1u, 1u};
+        if (special) {
+#pragma unroll
+            for (uint32_t k = 0; k != kSPL; ++k) {
+                cur.m[k] &= uint32_t(__builtin_amdgcn_sbfe(~row, k, 1));
+                lv1[k] = __builtin_amdgcn_ubfe(~row, k, 1);
+            }
+        }
         uint32_t e[kSPL];  // size - 1
 #pragma unroll
         for (uint32_t k = 0; k != kSPL; ++k) {
@@ -828,53 +835,48 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const w
             t.need[k] = __builtin_amdgcn_ubfe(cur.m[k], 20, 2);
             t.src2[k] = cur.m[k] & kMetaOffMask;  // hot: the image (runs: the zeros); cold, slow: zero for now
         }
-        uint32_t excval[kSPL];  // set and read only when tile_exc
-        if (special) {
-            // payload slots decode to nothing and take nothing; an exception header is one integer from one cell
+        // An exception's literal rides into its staging cell the way a cold codeword's first integers do: in the second
+        // word of the slot's head register (the integers of a cell start 4 bytes in), 32 bits wide. The expansion gathers
+        // its low half like any other integer, and — told by bit 0 of the source address — the upper half of one >= 65536.
+        bool wide[kSPL] = {false, false, false, false};
+        if (tile_exc) {
+            // the 32 bits of the stream behind each slot: the lane's later slots, then the next lane's first ones (lane
+            // 63: the next tile's; what lane 0 of the next tile holds is read with every lane enabled: a cross-lane read
+            // of a value computed under `lane == 63` would find lane 0's register untouched)
+            uint32_t w32[kSPL];
+            if (!narrow) {
+                const uint32_t p01 = (cur.s[1] << 16) | cur.s[0], p23 = (cur.s[3] << 16) | cur.s[2];
+                const uint32_t next0 = readlane((nxt.s[1] << 16) | nxt.s[0], 0);
+                uint32_t nlo = from_lane_above(p01);
+                if (lane == 63) nlo = next0;
+                w32[0] = __builtin_amdgcn_alignbit(p23, p01, 16);
+                w32[1] = p23;
+                w32[2] = __builtin_amdgcn_alignbit(nlo, p23, 16);
+                w32[3] = nlo;
+            } else {
+                const uint32_t b = cur.s[0] | (cur.s[1] << 8) | (cur.s[2] << 16) | (cur.s[3] << 24);
+                const uint32_t next0 = readlane(nxt.s[0] | (nxt.s[1] << 8) | (nxt.s[2] << 16) | (nxt.s[3] << 24), 0);
+                uint32_t nlo = from_lane_above(b);
+                if (lane == 63) nlo = next0;
+                w32[0] = __builtin_amdgcn_alignbit(nlo, b, 8);
+                w32[1] = __builtin_amdgcn_alignbit(nlo, b, 16);
+                w32[2] = __builtin_amdgcn_alignbit(nlo, b, 24);
+                w32[3] = nlo;
+            }
 #pragma unroll
             for (uint32_t k = 0; k != kSPL; ++k) {
-                const bool pay = ((row >> k) & 1u) != 0, exc = ((row >> (4 + k)) & 1u) != 0;
-                e[k] = pay ? ~0u : (exc ? 0u : e[k]);
-                t.need[k] = pay ? 0u : (exc ? 1u : t.need[k]);
-            }
-            if (tile_exc) {
-                // slot values after this lane's: the next lane's first ones (lane 63: next tile's)
-                // (what lane 0 of the next tile holds is read with every lane enabled: a cross-lane read of a
-                // value computed under `lane == 63` would find lane 0's register untouched)
-                if (!narrow) {
-                    const uint32_t next0 = readlane((nxt.s[1] << 16) | nxt.s[0], 0);
-                    uint32_t nlo = from_lane_above((cur.s[1] << 16) | cur.s[0]);
-                    if (lane == 63) nlo = next0;
-                    uint32_t v[kSPL + 2];
-#pragma unroll
-                    for (uint32_t k = 0; k != kSPL; ++k) v[k] = cur.s[k];
-                    v[kSPL] = nlo & 0xFFFFu;
-                    v[kSPL + 1] = nlo >> 16;
-#pragma unroll
-                    for (uint32_t k = 0; k != kSPL; ++k)
-                        excval[k] = v[k] == 0 ? v[k + 1] : (v[k + 1] | (v[k + 2] << 16));
-                } else {
-                    const uint32_t next0 = readlane(nxt.s[0] | (nxt.s[1] << 8) | (nxt.s[2] << 16) | (nxt.s[3] << 24), 0);
-                    uint32_t nlo = from_lane_above(cur.s[0] | (cur.s[1] << 8) | (cur.s[2] << 16) | (cur.s[3] << 24));
-                    if (lane == 63) nlo = next0;
-                    uint32_t v[kSPL + 4];
-#pragma unroll
-                    for (uint32_t k = 0; k != kSPL; ++k) v[k] = cur.s[k];
-#pragma unroll
-                    for (uint32_t k = 0; k != 4; ++k) v[kSPL + k] = (nlo >> (8 * k)) & 0xFFu;
-#pragma unroll
-                    for (uint32_t k = 0; k != kSPL; ++k) {
-                        const uint32_t lo16 = v[k + 1] | (v[k + 2] << 8);
-                        excval[k] = v[k] == 0 ? lo16 : (lo16 | (v[k + 3] << 16) | (v[k + 4] << 24));
-                    }
-                }
+                const uint32_t excM = uint32_t(__builtin_amdgcn_sbfe(row, 4 + k, 1));
+                // marker 0: the 16 bits behind it; marker 1: all 32 (0 - marker = which)
+                const uint32_t lit = w32[k] & ((0u - cur.s[k]) | 0xFFFFu) & excM;
+                hr.q[k].y = (hr.q[k].y & ~excM) | lit;
+                wide[k] = lit > 0xFFFFu;
             }
         }
         t.off[0] = 0;
-        t.off[1] = e[0] + 1u;
-        t.off[2] = t.off[1] + e[1] + 1u;
-        t.off[3] = t.off[2] + e[2] + 1u;
-        t.lsum = t.off[3] + e[3] + 1u;
+        t.off[1] = e[0] + lv1[0];
+        t.off[2] = t.off[1] + e[1] + lv1[1];
+        t.off[3] = t.off[2] + e[2] + lv1[2];
+        t.lsum = t.off[3] + e[3] + lv1[3];
         uint32_t hdrcnt = 4;
         uint32_t pincl;
         if (special) {
@@ -939,21 +941,7 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const w
         }
 #pragma unroll
         for (uint32_t k = 0; k != kSPL; ++k) t.src2[k] = t.need[k] != 0 ? cell_addr[k] : t.src2[k];
-        bool tile_wide = false;
-        if (tile_exc) {
-            // An exception's literal goes into its staging cell as 32 bits. The expansion gathers its low half
-            // like any other integer, and — told by bit 0 of the source address — the upper half of one >= 65536.
-            bool wide = false;
-#pragma unroll
-            for (uint32_t k = 0; k != kSPL; ++k)
-                if (((row >> (4 + k)) & 1u) != 0 && t.need[k] != 0) {
-                    *reinterpret_cast<uint32_t*>(lds_rw + cell_addr[k]) = excval[k];
-                    t.src2[k] |= excval[k] > 0xFFFFu ? 1u : 0u;
-                    wide = wide || excval[k] > 0xFFFFu;
-                    t.need[k] = 0;  // (no row lands there)
-                }
-            tile_wide = __ballot(wide) != 0;
-        }
+        const bool tile_wide = tile_exc && __ballot(wide[0] || wide[1] || wide[2] || wide[3]) != 0;
         const bool tile_slow = __ballot(slowb != 0) != 0;
         const bool tile_big = __ballot((t.need[0] | t.need[1] | t.need[2] | t.need[3]) > 1u) != 0;
         if (CHAINED && last_tile) {  // a chained segment asks for the next block as soon as it knows where this one ends
@@ -974,7 +962,7 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const w
         for (uint32_t k = 0; k != kSPL; ++k)
             if (t.need[k] != 0) {
                 *reinterpret_cast<u32x4*>(lds_rw + t.src2[k]) = hr.q[k];
-                t.src2[k] += 4;
+                t.src2[k] += 4u + (wide[k] ? 1u : 0u);
             }
         if (tile_big) {
 #pragma unroll
@@ -1390,7 +1378,7 @@ __device__ __forceinline__ uint64_t decode_segment_lean(const decode_args& a, co
         SECTION(pf, 4, "4_tables");
         const bool one_batch = !tile_slow && t.total <= kCap;  // wave-uniform
         if (__builtin_expect(one_batch, 1)) {
-            tables_general(t, fw, delta, t.lsum != 0, 0u, 0u);
+            tables_general(t, fw, delta, t.lsum != 0, 0u, 0u, lane);
             wave_lds_fence();
         }
         SECTION(pf, 7, "7_rows2");
