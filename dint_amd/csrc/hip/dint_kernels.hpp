@@ -385,7 +385,11 @@ __device__ __forceinline__ void request_metas(const wave_ctx& c, uint32_t hot_ba
     for (uint32_t k = 0; k != kSPL; ++k) mr.h[k] = c.lds[hot_base + (t.s[k] < hot_k ? t.s[k] : hot_k)];
 #pragma unroll
     for (uint32_t k = 0; k != kSPL; ++k)
+#ifdef DINT_EXP_HEADS_L1
+        if (t.s[k] >= hot_k) hr.q[k] = __builtin_amdgcn_raw_buffer_load_b128(c.rs_dict, c.heads_base + 16 * (meta_base + hot_k + (t.s[k] & 63u)), 0, 0);
+#else
         if (t.s[k] >= hot_k) hr.q[k] = __builtin_amdgcn_raw_buffer_load_b128(c.rs_dict, c.heads_base + 16 * (meta_base + t.s[k]), 0, 0);
+#endif
 }
 // ... where the wait is: everything has landed (the asm makes the values the asm's, not a load's: nothing
 // for the compiler to wait for later)
@@ -611,7 +615,15 @@ __device__ __forceinline__ void expand_batch(uint32_t bt, uint32_t out_int, cons
                     } else if (p0 < bt) {
                         u32x4 xv = {x[g][0], x[g][1], x[g][2], x[g][3]};
                         if (plus_one) xv += 1u;  // wave-uniform branch: nothing on the plain decode path
+                        // (DINT_EXP_*: timing experiments, tools/build_variants.sh — their results are wrong by construction)
+#ifdef DINT_EXP_NOSTORE
+                        asm volatile("" : : "v"(xv));
+#elif defined(DINT_EXP_STORE_LANES)
+                        if (lane < DINT_EXP_STORE_LANES) __builtin_amdgcn_raw_buffer_store_b128(xv, rs_out, 16 * g * kWave + 16 * lane, obyte, DINT_STORE_AUX);
+                        else asm volatile("" : : "v"(xv));
+#else
                         __builtin_amdgcn_raw_buffer_store_b128(xv, rs_out, 16 * g * kWave + 16 * lane, obyte, DINT_STORE_AUX);
+#endif
                     }
                 }
             }
