@@ -485,6 +485,7 @@ struct dint_query_index {
     device_buffer<uint64_t> ends;
     device_buffer<uint8_t> gaps_left;
     device_buffer<unsigned long long> freq_sums;
+    device_buffer<uint32_t> freq_counts;  // and_query<true>: per term, the blocks its matches fell into
     std::mutex mutex;
 };
 
@@ -1210,6 +1211,7 @@ void dint_query_index_destroy(dint_query_index* qi) {
     qi->ends.release();
     qi->gaps_left.release();
     qi->freq_sums.release();
+    qi->freq_counts.release();
     qi->sub.release();
     qi->units.release();
     delete qi;
@@ -1736,41 +1738,61 @@ static int and_queries_impl(dint_query_index* qi, const dint_dict* freqs_dict, c
     // matches fall into (for the rarest term: the candidate pages themselves), their docs and freqs parts, then
     // every match reads its freq at the position of its docID.
     std::vector<unsigned long long> h_sums;
+    std::vector<uint32_t> h_freq_counts;
     if (freqs_dict) {
         if (!qi->freq_sums.ensure(n_queries)) return DINT_ERR_HIP;
         HIP_TRY(hipMemsetAsync(qi->freq_sums.p, 0, n_queries * sizeof(unsigned long long), s));
+        // (the blocks a term's matches fall into are counted on the device; the launches of a term are sized for what
+        // the host knows — no more blocks than matches can exist, than the terms' lists hold, than the candidate pages for
+        // the rarest term — and the pages past the count are empty. Past kAsyncPages the count is read back after all,
+        // as in the rounds above. The counts themselves travel to the host with the results.)
+        if (!qi->freq_counts.ensure(rounds + 1)) return DINT_ERR_HIP;
+        HIP_TRY(hipMemsetAsync(qi->freq_counts.p, 0, (rounds + 1) * 4, s));
         for (size_t r = 0; r != rounds + 1; ++r) {  // r = 0: the rarest term; r >= 1: the term of round r - 1
             const uint32_t* first = r ? d_term_first + (r - 1) * n_queries : nullptr;
             const uint32_t* nblk = r ? d_term_blocks + (r - 1) * n_queries : nullptr;
-            HIP_TRY(hipMemsetAsync(qi->d_n_touched, 0, 4, s));
+            uint64_t list_blocks = n_pages;
+            if (r) {
+                list_blocks = 0;
+                for (size_t q = 0; q != n_queries; ++q) list_blocks += h_blocks[(r - 1) * n_queries + q];
+            }
+            size_t bound = size_t(std::min<uint64_t>(n_slots, list_blocks));
+            if (bound == 0) continue;
+            uint32_t* const d_cnt = qi->freq_counts.p + r;
             hipLaunchKernelGGL(and_freq_search_kernel, dim3(slot_grid), dim3(tb), 0, s, qi->cand.p, n_slots, d_page_query,
                                d_page_block, first, nblk, qi->d_block_max, qi->target.p, qi->d_needed, qi->d_rank,
-                               qi->d_touched, qi->d_n_touched);
-            uint32_t n_touched = 0;
-            HIP_TRY(hipMemcpyAsync(&n_touched, qi->d_n_touched, 4, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            if (n_touched == 0) continue;
-            if (freq_blocks) *freq_blocks += n_touched;
-            if (!qi->sub.ensure(std::max<size_t>(n_pages, n_touched)) || !qi->probe.ensure(uint64_t(n_touched) * kPageSlots) ||
-                !qi->fprobe.ensure(uint64_t(n_touched) * kPageSlots)) {
+                               qi->d_touched, d_cnt);
+            const uint32_t* d_count = d_cnt;
+            if (bound > kAsyncPages) {
+                uint32_t n_touched = 0;
+                HIP_TRY(hipMemcpyAsync(&n_touched, d_cnt, 4, hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                if (n_touched == 0) continue;
+                bound = n_touched;
+                d_count = nullptr;
+            }
+            if (!qi->sub.ensure(std::max<size_t>(n_pages, bound)) || !qi->probe.ensure(uint64_t(bound) * kPageSlots) ||
+                !qi->fprobe.ensure(uint64_t(bound) * kPageSlots)) {
                 (void)hipStreamSynchronize(s);
                 return DINT_ERR_HIP;
             }
-            const uint32_t tgrid = (n_touched + tb - 1) / tb;
-            hipLaunchKernelGGL(gather_pages_kernel, dim3(tgrid), dim3(tb), 0, s, qi->d_blocks, qi->d_touched, uint64_t(n_touched),
-                               qi->sub.p);
-            st = decode_pages(qi, n_touched, qi->probe.p, freqs_dict, qi->fprobe.p, s);
+            const uint32_t tgrid = uint32_t((bound + tb - 1) / tb);
+            hipLaunchKernelGGL(gather_pages_kernel, dim3(tgrid), dim3(tb), 0, s, qi->d_blocks, qi->d_touched, uint64_t(bound), qi->sub.p,
+                               d_count);
+            st = decode_pages(qi, bound, qi->probe.p, freqs_dict, qi->fprobe.p, s);
             if (st != DINT_OK) {
                 (void)hipStreamSynchronize(s);
                 return st;
             }
             hipLaunchKernelGGL(and_freq_gather_kernel, dim3(slot_grid), dim3(tb), 0, s, qi->cand.p, n_slots, d_page_query, nblk,
                                qi->d_blocks, qi->target.p, qi->d_rank, qi->probe.p, qi->fprobe.p, qi->freq_sums.p);
-            hipLaunchKernelGGL(and_release_kernel, dim3(tgrid), dim3(tb), 0, s, qi->d_touched, n_touched, qi->d_needed);
+            hipLaunchKernelGGL(and_release_kernel, dim3(tgrid), dim3(tb), 0, s, qi->d_touched, uint32_t(bound), qi->d_needed, d_count);
         }
         HIP_TRY(hipGetLastError());
         h_sums.resize(n_queries);
         HIP_TRY(hipMemcpyAsync(h_sums.data(), qi->freq_sums.p, n_queries * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        h_freq_counts.resize(rounds + 1);
+        HIP_TRY(hipMemcpyAsync(h_freq_counts.data(), qi->freq_counts.p, (rounds + 1) * 4, hipMemcpyDeviceToHost, s));
     }
     unsigned long long* const h_counts = static_cast<unsigned long long*>(qi->h_stage);  // (the inputs have long been copied)
     if (!results_to_host) HIP_TRY(hipMemcpyAsync(h_counts, d_counts, n_queries * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -1779,8 +1801,11 @@ static int and_queries_impl(dint_query_index* qi, const dint_dict* freqs_dict, c
     qi->claims_dirty = false;
     for (size_t q = 0; q != n_queries; ++q)
         if (!plan[q].empty()) counts[q] = h_counts[q];
-    if (freqs_dict)
+    if (freqs_dict) {
         for (size_t q = 0; q != n_queries; ++q) freq_sums[q] = h_sums[q];
+        if (freq_blocks)
+            for (uint32_t c : h_freq_counts) *freq_blocks += c;
+    }
     return DINT_OK;
 }
 

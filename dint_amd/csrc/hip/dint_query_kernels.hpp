@@ -23,11 +23,13 @@ constexpr uint32_t kDeadCandidate = 0xFFFFFFFFu;  // not a docID: docIDs are < n
 constexpr uint32_t kPageSlots = 256;              // one block per page
 
 // sub[i] = blocks[ids[i]] relocated to page i
+// (count set: page i >= *count is empty — n_pages is then what the host knows, an upper bound)
 __global__ void gather_pages_kernel(const dint_block_ref* blocks, const uint32_t* ids, uint64_t n_pages,
-                                    dint_block_ref* sub) {
+                                    dint_block_ref* sub, const uint32_t* count = nullptr) {
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n_pages) return;
-    dint_block_ref r = blocks[ids[i]];
+    dint_block_ref r{};
+    if (!count || i < *count) r = blocks[ids[i]];
     r.out_off = i * kPageSlots;
     sub[i] = r;
 }
@@ -290,9 +292,9 @@ __global__ void and_freq_gather_kernel(const uint32_t* cand, uint64_t n_slots, c
     if (pos < n && probe[page + pos] == c) atomicAdd(&freq_sums[q], (unsigned long long)fprobe[page + pos]);
 }
 
-__global__ void and_release_kernel(const uint32_t* touched, uint32_t n_touched, uint32_t* needed) {
+__global__ void and_release_kernel(const uint32_t* touched, uint32_t n_touched, uint32_t* needed, const uint32_t* count = nullptr) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n_touched) needed[touched[k]] = 0;
+    if (k < n_touched && (!count || k < *count)) needed[touched[k]] = 0;
 }
 // results += 1 per surviving candidate (queries.hpp:72-76); a page belongs to one query
 __global__ void and_count_kernel(const uint32_t* cand, uint64_t n_slots, const uint32_t* page_query,
