@@ -1030,6 +1030,12 @@ struct dint_block_table {
     sched_cache docs_sched, freqs_sched;
     bool freqs_units_ready = false;
     uint64_t max_out_end = 0;           // max over the blocks of out_off + n: a decode whose out_capacity is below it skips blocks
+    // Once the freqs parts' units are known (second decode on), their launch depends on nothing the docs launch produces:
+    // it runs on a stream of the table's own, beside the docs launch and the short blocks' decoder, between two events
+    // on the caller's stream (each launch is a quarter of a millisecond of persistent workgroups: one's ramp and tail
+    // under the other's body).
+    hipStream_t side = nullptr, side2 = nullptr;  // (side2: the short blocks' decoder)
+    hipEvent_t fork = nullptr, join = nullptr, join2 = nullptr;
 };
 
 namespace {
@@ -1078,9 +1084,47 @@ int block_table_decode(const dint_dict* docs_dict, const dint_dict* freqs_dict, 
     // its end offset unwritten — nothing may be derived from it.
     const bool covers = out_capacity >= t.max_out_end;
     const bool keep = t.owns_blocks && covers && t.decodes >= 1;  // (a one-shot table never reaches its second decode)
+    static const bool concurrent_ok = [] {
+        const char* e = std::getenv("DINT_INDEX_CONCURRENT");
+        return !e || std::atoi(e) != 0;
+    }();
+    // From the second decode of a table on (the side streams are the table's): the freqs launch beside the docs launch once
+    // its units are known, and the short blocks' decoder beside both.
+    const bool side_freqs = d_freqs && t.freqs_units_ready && keep && concurrent_ok;
+    const bool side_tails = tgrid != 0 && keep && concurrent_ok;
+    if (side_freqs || side_tails) {
+        if (!mt.side) {
+            HIP_TRY(hipStreamCreateWithFlags(&mt.side, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&mt.fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&mt.join, hipEventDisableTiming));
+            int prio_low = 0, prio_high = 0;  // (the short blocks' few, long-lived waves first: the DINT launches fill in around them)
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+            HIP_TRY(hipStreamCreateWithPriority(&mt.side2, hipStreamNonBlocking, prio_high));
+            HIP_TRY(hipEventCreateWithFlags(&mt.join2, hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(mt.fork, s));  // (what the caller put on its stream before this call — the index — is there)
+    }
+    hipStream_t fs = s;  // the freqs launch's stream
+    if (side_freqs) {
+        fs = mt.side;
+        HIP_TRY(hipStreamWaitEvent(fs, mt.fork, 0));
+    }
+    if (side_tails) {
+        // (the short blocks' outputs are their own; the "left as gaps" flags wait for the docs launch: finalize_flagged_kernel)
+        HIP_TRY(hipStreamWaitEvent(mt.side2, mt.fork, 0));
+        hipLaunchKernelGGL(interpolative_tails_kernel, dim3(tgrid), dim3(64), kTailLdsBytes, mt.side2, d_index, uint64_t(index_bytes), t.d_blocks,
+                           static_cast<const uint64_t*>(nullptr), t.d_tails, t.d_tails + n_blocks, d_docids, uint64_t(out_capacity),
+                           static_cast<uint64_t*>(nullptr), 0u, 1u, d_freqs, static_cast<uint8_t*>(nullptr), uint64_t(0));
+        HIP_TRY(hipEventRecord(mt.join2, mt.side2));
+    }
     int st = launch_decode(docs_dict, d_index, index_bytes, t.d_units, n_blocks, d_docids, out_capacity, t.d_ends, s, 1, t.d_spans, 0,
                            t.d_bases, t.d_gaps_left, keep ? &mt.docs_sched : nullptr);
-    if (st != DINT_OK) return st;
+    auto fail = [&](int code) {  // (nothing of this call may still be running on the table's streams when the caller hears of it)
+        if (side_freqs) (void)hipStreamSynchronize(mt.side);
+        if (side_tails) (void)hipStreamSynchronize(mt.side2);
+        return code;
+    };
+    if (st != DINT_OK) return fail(st);
     if (!t.spans_exact && covers) {  // (stream-ordered: the next decode on this table finds the exact spans)
         hipLaunchKernelGGL(exact_spans_kernel, dim3(grid), dim3(tb), 0, s, t.d_units, t.d_ends, uint64_t(n_blocks), t.d_spans);
         mt.spans_exact = true;
@@ -1094,13 +1138,18 @@ int block_table_decode(const dint_dict* docs_dict, const dint_dict* freqs_dict, 
             mt.freqs_units_ready = t.owns_blocks && covers;
         }
         // (freq = decoded value + 1, dict_posting_list.hpp:164-169: added where the values are stored)
-        st = launch_decode(freqs_dict, d_index, index_bytes, t.d_funits, n_blocks, d_freqs, out_capacity, nullptr, s, 1, t.d_fspans, 1,
+        st = launch_decode(freqs_dict, d_index, index_bytes, t.d_funits, n_blocks, d_freqs, out_capacity, nullptr, fs, 1, t.d_fspans, 1,
                            nullptr, nullptr, keep ? &mt.freqs_sched : nullptr);
-        if (st != DINT_OK) return st;
+        if (st != DINT_OK) return fail(st);
+        if (fs != s) HIP_TRY(hipEventRecord(mt.join, fs));
     }
     // the short blocks' waves also look through the "left as gaps" flags (a slow codeword, a block of more than 256
     // slots: next to none), one share each; a table without short blocks gets the flags kernel alone
-    if (tgrid)
+    if (side_tails) {
+        hipLaunchKernelGGL(finalize_flagged_kernel, dim3(uint32_t((n_blocks + 63) / 64)), dim3(64), 0, s, t.d_blocks, uint64_t(n_blocks),
+                           d_docids, uint64_t(out_capacity), t.d_gaps_left);
+        HIP_TRY(hipStreamWaitEvent(s, mt.join2, 0));
+    } else if (tgrid)
         hipLaunchKernelGGL(interpolative_tails_kernel, dim3(tgrid), dim3(64), kTailLdsBytes, s, d_index, uint64_t(index_bytes), t.d_blocks,
                            static_cast<const uint64_t*>(nullptr), t.d_tails, t.d_tails + n_blocks, d_docids, uint64_t(out_capacity),
                            static_cast<uint64_t*>(nullptr), 0u, 1u, d_freqs, t.d_gaps_left, uint64_t(n_blocks));
@@ -1108,6 +1157,7 @@ int block_table_decode(const dint_dict* docs_dict, const dint_dict* freqs_dict, 
         hipLaunchKernelGGL(finalize_flagged_kernel, dim3(uint32_t((n_blocks + 63) / 64)), dim3(64), 0, s, t.d_blocks, uint64_t(n_blocks),
                            d_docids, uint64_t(out_capacity), t.d_gaps_left);
     HIP_TRY(hipGetLastError());
+    if (fs != s) HIP_TRY(hipStreamWaitEvent(s, mt.join, 0));  // (everything behind this call on the caller's stream sees the freqs)
     if (covers) mt.decodes += 1;
     return DINT_OK;
 }
@@ -1152,6 +1202,15 @@ void dint_block_table_destroy(dint_block_table* t) {
     if (!t) return;
     (void)hipSetDevice(t->device);
     if (t->d_ws) (void)hipFree(t->d_ws);
+    if (t->side) {
+        (void)hipStreamSynchronize(t->side);
+        (void)hipStreamDestroy(t->side);
+        (void)hipEventDestroy(t->fork);
+        (void)hipEventDestroy(t->join);
+        (void)hipStreamSynchronize(t->side2);
+        (void)hipStreamDestroy(t->side2);
+        (void)hipEventDestroy(t->join2);
+    }
     if (t->docs_sched.d_mem) (void)hipFree(t->docs_sched.d_mem);
     if (t->freqs_sched.d_mem) (void)hipFree(t->freqs_sched.d_mem);
     if (t->owns_blocks && t->d_blocks) (void)hipFree(const_cast<dint_block_ref*>(t->d_blocks));
