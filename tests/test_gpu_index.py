@@ -97,6 +97,42 @@ def test_prepared_block_table_decodes_asynchronously(device, small_corpus, kind)
 
 
 @pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
+def test_block_table_side_streams_are_joined_to_the_callers_stream(device, small_corpus, kind):
+    """From its second decode on a table runs the freqs launch and the short blocks' decoder on streams of its own. What
+    the caller puts on ITS stream around a call must still be ordered with them: the poison written before a call is there
+    before any of the three kernels writes, and a copy issued right behind the call sees all of their outputs — six
+    calls back to back into the same two buffers, docs + freqs and docs only in turn, no host synchronisation between."""
+    import torch
+
+    ix = get_index(small_corpus, kind)
+    blocks, total = device.index_posting_lists(ix.bytes, ix.offsets)
+    dd, fd = device.Dictionary(kind, ix.docs_dict), device.Dictionary(kind, ix.freqs_dict)
+    dev = torch.device("cuda", 0)
+    padded = np.concatenate([ix.bytes, np.zeros(16, np.uint8)])
+    index_dev = torch.from_numpy(padded).to(dev)
+    table = device.BlockTable(dd, blocks, padded.size)
+    stream = torch.cuda.Stream(dev)
+    docids_dev = torch.empty(total, dtype=torch.int32, device=dev)
+    freqs_dev = torch.empty(total, dtype=torch.int32, device=dev)
+    got = []
+    with torch.cuda.stream(stream):
+        for i in range(6):
+            with_freqs = i % 2 == 0
+            docids_dev.fill_(-1)
+            freqs_dev.fill_(-1)
+            table.decode(dd, fd if with_freqs else None, index_dev, padded.size, docids_dev, freqs_dev if with_freqs else None,
+                         stream=stream.cuda_stream)
+            got.append((with_freqs, docids_dev.clone(), freqs_dev.clone()))
+    stream.synchronize()
+    for with_freqs, d, f in got:
+        assert np.array_equal(d.cpu().numpy().view(np.uint32), ix.docids)
+        if with_freqs:
+            assert np.array_equal(f.cpu().numpy().view(np.uint32), ix.freqs)
+        else:
+            assert (f.cpu().numpy() == -1).all()
+
+
+@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
 def test_block_table_keeps_nothing_from_a_decode_that_skipped_blocks(device, small_corpus, kind):
     """A prepared table keeps what its decodes learn (exact spans, the freqs parts' units, both bundle schedules). A
     decode whose out_capacity is too small for some blocks skips them — nothing may be learnt from it — and a schedule
