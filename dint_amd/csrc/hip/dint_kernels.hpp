@@ -375,11 +375,12 @@ __device__ __forceinline__ uint32_t* stage_of(uint32_t* scratch) { return scratc
 // dictionary entry from L2 — its metadata word and its first six integers (u16) in one lane request, addressed
 // by the slot value alone. (Round 1 and the first versions of this round fetched the metadata word and the
 // integers separately: two lane requests per cold codeword, and the vector-memory front end — 0.45 scattered
-// lane requests per CU and cycle, tools/micro/gather_rate.hip — was what the kernel waited for.) Whether a
-// slot is a codeword at all is not known yet (classification comes later): a payload slot that looks like a
-// cold codeword fetches a head nobody reads.
+// lane requests per CU and cycle, tools/micro/gather_rate.hip — was what the kernel waited for.)
+// `payload`: bit k = slot k is an exception's payload (decode_segment classifies a tile before it asks for its heads:
+// a payload slot is a 16-bit piece of a literal and looks like a cold codeword more often than not — 13 wasted requests
+// in a tile's 107); callers that do not know yet pass 0.
 __device__ __forceinline__ void request_metas(const wave_ctx& c, uint32_t hot_base, uint32_t hot_k, uint32_t meta_base,
-                                              const tile_regs& t, meta_regs& mr, head_regs& hr) {
+                                              const tile_regs& t, meta_regs& mr, head_regs& hr, uint32_t payload = 0) {
     // (the word behind a dictionary's hot metas is a dummy: the cold lanes read it, min instead of compare + select)
 #pragma unroll
     for (uint32_t k = 0; k != kSPL; ++k) mr.h[k] = c.lds[hot_base + (t.s[k] < hot_k ? t.s[k] : hot_k)];
@@ -388,7 +389,8 @@ __device__ __forceinline__ void request_metas(const wave_ctx& c, uint32_t hot_ba
 #ifdef DINT_EXP_HEADS_L1
         if (t.s[k] >= hot_k) hr.q[k] = __builtin_amdgcn_raw_buffer_load_b128(c.rs_dict, c.heads_base + 16 * (meta_base + hot_k + (t.s[k] & 63u)), 0, 0);
 #else
-        if (t.s[k] >= hot_k) hr.q[k] = __builtin_amdgcn_raw_buffer_load_b128(c.rs_dict, c.heads_base + 16 * (meta_base + t.s[k]), 0, 0);
+        if (t.s[k] >= hot_k && ((payload >> k) & 1u) == 0)
+            hr.q[k] = __builtin_amdgcn_raw_buffer_load_b128(c.rs_dict, c.heads_base + 16 * (meta_base + t.s[k]), 0, 0);
 #endif
 }
 // ... where the wait is: everything has landed (the asm makes the values the asm's, not a load's: nothing
@@ -777,14 +779,49 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const w
         unpack_slots(narrow, raw0, cur);
     }
     ch.valid = false;
-    request_metas(c, dd.hot_base, hot_k, dd.meta_base, cur, mr, hr);
+    // ---- classification of a tile's slots — which are an exception's payload, which exception headers — by table
+    // lookup, repeated until the lane-to-lane carries agree. It needs the slots and the carry of the tile before and
+    // nothing else, so it runs a tile AHEAD, before the tile's heads are requested: payload slots ask for none.
+    struct tile_class {
+        uint32_t row;        // the lane's classification row (kPlainRow: four codeword headers)
+        uint32_t carry_out;  // payload slots the tile's last exception still owns in the next tile (wave-uniform)
+        bool special;        // some slot is an exception header or payload (wave-uniform)
+        bool tile_exc;       // some slot is an exception header (wave-uniform)
+    };
+    auto classify = [&](const tile_regs& tr, uint32_t carry_in) -> tile_class {
+        tile_class k{kPlainRow, 0u, false, false};
+        uint32_t smin = tr.s[0];
+#pragma unroll
+        for (uint32_t j = 1; j != kSPL; ++j) smin = smin < tr.s[j] ? smin : tr.s[j];
+        k.special = __builtin_expect(__ballot(smin < 2) != 0 || carry_in != 0, 0);
+        if (k.special) {
+            // base-3 digits of the four slots: 2 - min(slot, 2)
+            uint32_t lo = 0;
+#pragma unroll
+            for (uint32_t j = kSPL; j-- != 0;) lo = 3 * lo + (2u - (tr.s[j] < 2 ? tr.s[j] : 2u));
+            uint32_t st_in = lane == 0 ? carry_in : 0u;
+            uint32_t row;
+            for (;;) {
+                row = rows[st_in * 81 + lo];
+                uint32_t prev = from_lane_below((row >> 8) & 7u);
+                if (lane == 0) prev = carry_in;
+                if (__ballot(prev != st_in) == 0) break;
+                st_in = prev;
+            }
+            k.row = row;
+            k.carry_out = readlane((row >> 8) & 7u, 63);
+            k.tile_exc = __ballot((row & 0xF0u) != 0) != 0;
+        }
+        return k;
+    };
+    tile_class kc = classify(cur, 0u);
+    request_metas(c, dd.hot_base, hot_k, dd.meta_base, cur, mr, hr, kc.row & 15u);
     // Everything loaded so far has landed before the loop is entered: inside it, a wait may only
     // ever sit before a tile's stores (see the notes below), never right after them.
     asm volatile("" : "+v"(raw1), "+v"(raw2));
     unpack_slots(narrow, raw1, nxt);
 
     uint32_t produced = 0;
-    uint32_t carry = 0;            // payload slots an exception of the previous tile still owns
     uint64_t tile_base = in_off_u; // byte offset of slot 0 of the current tile (wave-uniform)
     uint32_t end_slot = 0;
     MARK("loop_top");
@@ -800,31 +837,11 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const w
         SECTION(pf, 1, "1_classify");
         // this tile's metadata: requested before the previous tile's stores (so this is no wait for them)
         take_metas(hot_k, mr, hr, cur);
-        // ---- 1. classification: table lookup, repeated until the lane-to-lane carries agree ----
-        uint32_t smin = cur.s[0];
-#pragma unroll
-        for (uint32_t k = 1; k != kSPL; ++k) smin = smin < cur.s[k] ? smin : cur.s[k];
-        const bool special = __builtin_expect(__ballot(smin < 2) != 0 || carry != 0, 0);
-        const bool tile_slow_dict = __ballot(((cur.m[0] | cur.m[1] | cur.m[2] | cur.m[3]) & kMetaSlow) != 0) != 0;
-        uint32_t row = kPlainRow;
-        uint32_t carry_out = 0;
-        bool tile_exc = false;
-        if (special) {
-            // base-3 digits of the four slots: 2 - min(slot, 2)
-            uint32_t lo = 0;
-#pragma unroll
-            for (uint32_t k = kSPL; k-- != 0;) lo = 3 * lo + (2u - (cur.s[k] < 2 ? cur.s[k] : 2u));
-            uint32_t st_in = lane == 0 ? carry : 0u;
-            for (;;) {
-                row = rows[st_in * 81 + lo];
-                uint32_t prev = from_lane_below((row >> 8) & 7u);
-                if (lane == 0) prev = carry;
-                if (__ballot(prev != st_in) == 0) break;
-                st_in = prev;
-            }
-            carry_out = readlane((row >> 8) & 7u, 63);
-            tile_exc = __ballot((row & 0xF0u) != 0) != 0;
-        }
+        // ---- 1. classification: done a tile ago (kc) ----
+        const bool special = kc.special;
+        const uint32_t row = kc.row;
+        const uint32_t carry_out = kc.carry_out;
+        const bool tile_exc = kc.tile_exc;
 
         SECTION(pf, 2, "2_sizes");
         // ---- 2. sizes, offsets; where each codeword's integers are -----------------------------------
@@ -840,6 +857,8 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const w
                 lv1[k] = __builtin_amdgcn_ubfe(~row, k, 1);
             }
         }
+        // (behind the mask: a payload slot asked for no head, what its register holds is stale)
+        const bool tile_slow_dict = __ballot(((cur.m[0] | cur.m[1] | cur.m[2] | cur.m[3]) & kMetaSlow) != 0) != 0;
         uint32_t e[kSPL];  // size - 1
 #pragma unroll
         for (uint32_t k = 0; k != kSPL; ++k) {
@@ -1005,7 +1024,10 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const w
             // the next tile is no wait for the stores (vmcnt is one in-order counter for loads AND stores on
             // gfx950). The last tile of a segment has no successor.
             SECTION(pf, 3, "3_prefetch");
-            if (!last_tile) request_metas(c, dd.hot_base, hot_k, dd.meta_base, nxt, mr, hr);
+            if (!last_tile) {
+                kc = classify(nxt, carry_out);
+                request_metas(c, dd.hot_base, hot_k, dd.meta_base, nxt, mr, hr, kc.row & 15u);
+            }
         });
 
         SECTION(pf, 10, "10_tail");
@@ -1014,7 +1036,6 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const w
                            hot_k, dd.meta_base, rs_out);
         SECTION(pf, 5, "10_rotate");
         produced += t.total;
-        carry = carry_out;
         if (produced < n) tile_base += kTileBytes;
 
         // ---- rotate the pipeline ---------------------------------------------------
