@@ -213,7 +213,10 @@ void dint_block_table_destroy(dint_block_table* table);
  * frequencies). ASYNCHRONOUS: enqueues on `stream` and returns. Full blocks go through the DINT kernels —
  * the docID prefix sums are formed in the expansion, one wave scan per block, the gaps never reach memory;
  * freq = value + 1 is added where the values are stored — blocks shorter than 256 through the
- * binary-interpolative decoder (whose code is the prefix sums already).
+ * binary-interpolative decoder (whose code is the prefix sums already). From a table's second decode on, the freqs
+ * launch and the short blocks' decoder run on streams the table owns, beside the docs launch, forked from and joined
+ * to `stream` inside the call: to the caller everything is ordered on `stream` as before (DINT_INDEX_CONCURRENT=0 in
+ * the environment: one stream).
  * Replaces: see dint_decode_posting_blocks. */
 int dint_decode_block_table(const dint_dict* docs_dict, const dint_dict* freqs_dict, const uint8_t* d_index,
                             size_t index_bytes, dint_block_table* table, uint32_t* d_docids, uint32_t* d_freqs,
