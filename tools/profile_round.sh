@@ -21,3 +21,16 @@ python3 tools/pmc_traffic.py $OUT/fetch $OUT/write $TYPE $INTS $OUT/traffic.json
 python3 tools/pmc_sq_summary.py $OUT $INTS | tee $OUT/sq.txt
 python3 bench.py --cpu-seconds 0 --traffic-file $OUT/traffic.json "$@" > $OUT/bench_with_traffic.json 2>> $OUT/bench.err; cat $OUT/bench_with_traffic.json
 find $OUT/stats -name "*kernel_stats.csv" -exec cat {} \; | head -8 | tee $OUT/kernel_stats_head.csv
+# (the stats average over EVERY launch of the decode kernel in the profiled process — bench.py's placement trials during
+# set-up included, some of them into buffers the bench then drops; the timed region's launches are the last ones)
+python3 - <<PY | tee $OUT/kernel_stats_timed.txt
+import csv, glob
+rows = []
+for f in glob.glob("$OUT/stats/**/*kernel_trace.csv", recursive=True):
+    rows += [r for r in csv.DictReader(open(f)) if "decode_" in r["Kernel_Name"] and "_kernel" in r["Kernel_Name"] and "query" not in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
+timed = dur[-5:]
+print(f"decode kernel launches in the profiled process: {len(dur)}; all: mean {sum(dur) / max(1, len(dur)):.4f} ms; the timed region's last 5: "
+      + " ".join(f"{d:.4f}" for d in timed) + f" ms, mean {sum(timed) / max(1, len(timed)):.4f} ms")
+PY
