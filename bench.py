@@ -49,9 +49,9 @@ def parse_args(argv=None):
                          "per step: SURVEY §8d config 2); clueweb: universe 50M, 1.25e9 postings per GPU (config 4 at 8 GPUs)")
     ap.add_argument("--postings", type=float, default=None, help="postings encoded per GPU (weak scaling: fixed per GPU)")
     ap.add_argument("--placement-trials", type=int, default=6,
-                    help="candidate (stream, output) buffer pairs allocated during set-up; the pair the decode kernel runs "
-                         "fastest on is kept (the kernel's time differs by 10-17 %% with WHERE the driver puts the two "
-                         "buffers, process by process: DESIGN.md section 4e). 1: the first allocation, as before")
+                    help="candidate output buffers, then candidate stream buffers, allocated during set-up; the pair the decode "
+                         "kernel runs fastest on is kept (the kernel's time differs by 10-17 %% with WHERE the driver puts the "
+                         "two buffers: DESIGN.md section 4e). 1: the first allocation, as before")
     ap.add_argument("--replicate", type=int, default=None,
                     help="device-side copies of the encoded shard at distinct addresses, all decoded in one step")
     ap.add_argument("--universe", type=int, default=None, help="documents")
@@ -340,38 +340,55 @@ def main():
     units_dev = device.units_to_device(units_all, dev)
     n_units = len(units_all)
 
-    def allocate_pair():
+    def allocate_stream():
         e = torch.empty(enc.size * R, dtype=torch.uint8, device=dev)
         for r in range(R):
             e[r * enc.size:(r + 1) * enc.size].copy_(enc_one)
-        return e, torch.empty(n_ints, dtype=torch.int32, device=dev)
+        return e
+
+    def allocate_output():
+        return torch.empty(n_ints, dtype=torch.int32, device=dev)
 
     # Placement (set-up, untimed): the decode kernel's time depends on WHERE the driver puts the stream it reads and the
     # output it writes — 10-17 % between two pairs of buffers in one process, stable for the life of a pair, and nothing
     # a plain fill / copy / gather notices (tools/box_spread/realloc_probe.py). A caller who keeps its
-    # buffers for many decodes picks them once; so does the bench: a few candidate pairs, two launches each, the fastest
-    # stays, the others are freed before the timed region.
+    # buffers for many decodes picks them once; so does the bench: a few candidate output buffers for the first copy of
+    # the stream, then a few candidate copies of the stream for the output buffer that won, two launches each; the
+    # fastest pair stays, the others are freed before the timed region.
     trials = max(1, args.placement_trials) if dev.type == "cuda" and not os.environ.get("DINT_BENCH_STUB") else 1
-    enc_dev, out_dev = allocate_pair()
-    placement_ms = []
-    if trials > 1:
-        pairs = [(enc_dev, out_dev)]
+    enc_dev, out_dev = allocate_stream(), allocate_output()
+    placement_ms = None
+
+    def kernel_ms(e, o):
+        ms = []
+        for _ in range(3):
+            d.decode_units(e, units_dev, n_units, o)
+            torch.cuda.synchronize(dev)
+            ms.append(d.last_kernel_ms())
+        return round(min(ms[1:]), 4)
+
+    def candidates(first, allocate):
+        out = [first]
         for _ in range(trials - 1):
             try:
-                pairs.append(allocate_pair())
+                out.append(allocate())
             except RuntimeError:  # (out of memory: fewer candidates)
                 break
-        for e, o in pairs:
-            ms = []
-            for _ in range(3):
-                d.decode_units(e, units_dev, n_units, o)
-                torch.cuda.synchronize(dev)
-                ms.append(d.last_kernel_ms())
-            placement_ms.append(round(min(ms[1:]), 4))
-        enc_dev, out_dev = pairs[int(np.argmin(placement_ms))]
-        del pairs, e, o
+        return out
+
+    if trials > 1:
+        outs = candidates(out_dev, allocate_output)
+        ms_out = [kernel_ms(enc_dev, o) for o in outs]
+        out_dev = outs[int(np.argmin(ms_out))]
+        del outs
         torch.cuda.empty_cache()
-        log(rank, f"placement: kernel ms of the candidate buffer pairs {placement_ms}")
+        encs = candidates(enc_dev, allocate_stream)
+        ms_enc = [min(ms_out)] + [kernel_ms(e, out_dev) for e in encs[1:]]
+        enc_dev = encs[int(np.argmin(ms_enc))]
+        del encs
+        torch.cuda.empty_cache()
+        placement_ms = {"output_buffers": ms_out, "stream_buffers": ms_enc}
+        log(rank, f"placement: kernel ms of the candidate output buffers {ms_out}, of the candidate stream buffers {ms_enc}")
     del enc_one
     end_dev = torch.zeros(n_units, dtype=torch.int64, device=dev)
     log(rank, f"device buffers: enc {enc_dev.data_ptr():#x} ({enc_dev.data_ptr() % (2 << 20):#x} mod 2 MB) "
@@ -541,9 +558,10 @@ def main():
                 "units_per_gpu": n_units,
                 "unit_ints": args.unit_ints,
                 "schedule": "prepared unit table (set-up)" if unit_table is not None else "per launch (timed)",
-                "placement": (f"fastest of {len(placement_ms)} candidate (stream, output) buffer pairs, chosen during set-up"
+                "placement": (f"fastest of {len(placement_ms['output_buffers'])} candidate output buffers, then of "
+                              f"{len(placement_ms['stream_buffers'])} candidate stream buffers, chosen during set-up"
                               if placement_ms else "first allocation"),
-                "placement_trial_kernel_ms": placement_ms or None,
+                "placement_trial_kernel_ms": placement_ms,
                 "bits_per_int": round(bpi, 3),
                 **stream,
                 "hot_codewords_in_lds": int(info.hot_entries),
