@@ -9,7 +9,11 @@ collection (every unit of every posting list). Inputs (encoded stream, unit
 table, dictionary) are in HBM before the timed region starts. Posting lists
 are partitioned statically across ranks, the dictionary is replicated, and
 there is no data-path collective: the only collectives are the dictionary
-broadcast during set-up and the max-over-ranks of the elapsed time.
+broadcast during set-up and the max-over-ranks of the elapsed time. Set-up also
+picks the two big buffers (the encoded stream, the output) among a few candidate
+allocations by decoding into each (--placement-trials: the kernel's time depends
+by 10-17 % on where the driver puts the pair); the losers
+are freed before the warm-up.
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
 """
@@ -56,7 +60,7 @@ def parse_args(argv=None):
                     help="device-side copies of the encoded shard at distinct addresses, all decoded in one step")
     ap.add_argument("--universe", type=int, default=None, help="documents")
     ap.add_argument("--unit-ints", type=int, default=16384,
-                    help="the sidecar's granularity: integers per unit (16384: 1.6 % faster than 8192 at 5e9 integers per launch, profiles/r03_unit_sweep.txt)")
+                    help="the sidecar's granularity: integers per unit (16384: 1.6 %% faster than 8192 at 5e9 integers per launch, profiles/r03_unit_sweep.txt)")
     ap.add_argument("--dict-sample", type=float, default=2.0e7,
                     help="postings the DSF dictionary statistics are collected from")
     ap.add_argument("--seed", type=int, default=12345)
