@@ -149,3 +149,10 @@ def test_bench_as_rank_takes_that_ranks_shard():
     assert line["config"]["parallelism"] == "list-range shard 3 of 8" and line["n_gpus"] == 1
     bad = _stub_bench(["--gpus", "1", "--as-rank", "8/8"], {})
     assert bad.returncode != 0
+
+
+def test_bench_help_renders():
+    """argparse formats every help string with %: an unescaped per cent sign in one of them breaks --help."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "--placement-trials" in r.stdout
