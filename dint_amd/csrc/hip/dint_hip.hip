@@ -1093,14 +1093,24 @@ int block_table_decode(const dint_dict* docs_dict, const dint_dict* freqs_dict, 
     const bool side_freqs = d_freqs && t.freqs_units_ready && keep && concurrent_ok;
     const bool side_tails = tgrid != 0 && keep && concurrent_ok;
     if (side_freqs || side_tails) {
-        if (!mt.side) {
-            HIP_TRY(hipStreamCreateWithFlags(&mt.side, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&mt.fork, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&mt.join, hipEventDisableTiming));
+        if (!mt.side) {  // (all five or none: a table with half of them would trip over the missing ones on its next decode)
+            hipStream_t s1 = nullptr, s2 = nullptr;
+            hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
             int prio_low = 0, prio_high = 0;  // (the short blocks' few, long-lived waves first: the DINT launches fill in around them)
-            HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
-            HIP_TRY(hipStreamCreateWithPriority(&mt.side2, hipStreamNonBlocking, prio_high));
-            HIP_TRY(hipEventCreateWithFlags(&mt.join2, hipEventDisableTiming));
+            const bool ok = hip_ok(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking), "hipStreamCreateWithFlags") &&
+                            hip_ok(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high), "hipDeviceGetStreamPriorityRange") &&
+                            hip_ok(hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, prio_high), "hipStreamCreateWithPriority") &&
+                            hip_ok(hipEventCreateWithFlags(&e0, hipEventDisableTiming), "hipEventCreateWithFlags") &&
+                            hip_ok(hipEventCreateWithFlags(&e1, hipEventDisableTiming), "hipEventCreateWithFlags") &&
+                            hip_ok(hipEventCreateWithFlags(&e2, hipEventDisableTiming), "hipEventCreateWithFlags");
+            if (!ok) {
+                if (s1) (void)hipStreamDestroy(s1);
+                if (s2) (void)hipStreamDestroy(s2);
+                for (hipEvent_t e : {e0, e1, e2})
+                    if (e) (void)hipEventDestroy(e);
+                return DINT_ERR_HIP;
+            }
+            mt.side = s1, mt.side2 = s2, mt.fork = e0, mt.join = e1, mt.join2 = e2;
         }
         HIP_TRY(hipEventRecord(mt.fork, s));  // (what the caller put on its stream before this call — the index — is there)
     }
