@@ -26,6 +26,10 @@ def test_bench_line_contract(extra):
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["bit_exact"] is True and d["value"] > 0 and d["higher_is_better"] is True and d["dtype"] == "u32"
     assert "workload" in d["config"] and "model" not in d["config"]
+    # the buffers were picked during set-up among candidate allocations, and the line says which and how they timed
+    trials = d["config"]["placement_trial_kernel_ms"]
+    assert "candidate output buffers" in d["config"]["placement"] and len(trials["output_buffers"]) == 6
+    assert len(trials["stream_buffers"]) == 6 and min(trials["stream_buffers"]) <= min(trials["output_buffers"])
     assert d["config"]["ints_per_gpu_per_step"] >= 6_000_000 * 0.9
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["kernel_launches_timed"] == 3
