@@ -30,3 +30,24 @@ for enc_off in [int(x) for x in os.environ.get("STREAM_AT", "0,5,40").split(",")
         o = pool[out_off * GB: out_off * GB + 4 * coll.num_postings].view(torch.int32)
         row.append(f"{run(e, o):.2f}")
     print(f"stream at +{enc_off:3d} GB; output at +0, +{STEP}, ... GB: " + " ".join(row), flush=True)
+# Is it the decode kernel, or any kernel that reads one buffer and writes another? A plain copy of 4 GB from the first stream
+# position's stretch into the slowest and into the fastest output position found for it.
+enc_off = int(os.environ.get("STREAM_AT", "0,5,40").split(",")[0])
+e = pool[enc_off * GB: enc_off * GB + enc.size]; e.copy_(enc_t)
+times = {}
+for out_off in range(0, POOL - 4, STEP):
+    if abs(out_off - enc_off) < 5: continue
+    o = pool[out_off * GB: out_off * GB + 4 * coll.num_postings].view(torch.int32)
+    times[out_off] = run(e, o)
+slow, fast = max(times, key=times.get), min(times, key=times.get)
+src = pool[enc_off * GB: (enc_off + 4) * GB]
+def copy_rate(dst_off):
+    dst = pool[dst_off * GB: (dst_off + 4) * GB]
+    dst.copy_(src); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): dst.copy_(src)
+    e1.record(); torch.cuda.synchronize()
+    return 10 * 8 * GB / (e0.elapsed_time(e1) * 1e-3) / 1e12
+print(f"decode: output at +{slow} GB {times[slow]:.3f} ms (slow), at +{fast} GB {times[fast]:.3f} ms (fast); a plain 4 GB copy from +{enc_off} GB "
+      f"(read + write): into +{slow} GB {copy_rate(slow):.2f} TB/s, into +{fast} GB {copy_rate(fast):.2f} TB/s, again {copy_rate(slow):.2f} / {copy_rate(fast):.2f}")
