@@ -346,6 +346,17 @@ int dinth_build_index(int kind, const void* docs_dict_file, size_t docs_dict_len
 
 uint64_t dinth_hash_u32s(const uint32_t* p, size_t n) { return dint::hash_u32s(p, n); }
 
+int dinth_constants(uint32_t* out, int cap) {
+    const uint32_t v[] = {dint::kExceptions, dint::kNumSelectors, dint::kMaxEntrySize, dint::kNumEntries, dint::kNumTargetSizes,
+                          dint::kTargetSizes[0], dint::kTargetSizes[1], dint::kTargetSizes[2], dint::kTargetSizes[3],
+                          dint::kTargetSizes[4], dint::kBlockSize, dint::kReserved};
+    const int n = int(sizeof(v) / sizeof(v[0]));
+    for (int i = 0; out && i != n && i < cap; ++i) out[i] = v[i];
+    return n;
+}
+
+uint32_t dinth_block_selector(const uint32_t* p, size_t n) { return p ? dint::block_selector(p, n) : 0; }
+
 int dinth_dict_num_entries(int kind, const void* dict_file, size_t dict_len, uint32_t d, uint32_t* n_out) {
     if (!dict_file || !n_out) return DINT_ERR_ARG;
     return guarded([&] {

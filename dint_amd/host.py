@@ -73,6 +73,9 @@ def _load():
                                       C.POINTER(vp), C.POINTER(vp)]
     lib.dinth_hash_u32s.restype = u64
     lib.dinth_hash_u32s.argtypes = [vp, C.c_size_t]
+    lib.dinth_constants.argtypes = [vp, i32]
+    lib.dinth_block_selector.restype = u32
+    lib.dinth_block_selector.argtypes = [vp, C.c_size_t]
     lib.dinth_dict_entry.argtypes = [i32, vp, C.c_size_t, u32, u32, C.POINTER(u32), vp]
     lib.dinth_dict_num_entries.argtypes = [i32, vp, C.c_size_t, u32, C.POINTER(u32)]
     return lib
@@ -290,6 +293,21 @@ def build_index(kind: int, docs_dict: bytes, freqs_dict: bytes, docids: np.ndarr
 def hash_u32s(words) -> int:
     w = _u32(words)
     return int(_lib.dinth_hash_u32s(w.ctypes.data, w.size))
+
+
+def constants() -> dict:
+    """The compile-time constants of this build (dint/constants.hpp; reference dint_configuration.hpp:6,20,24-28)."""
+    v = np.zeros(16, dtype=np.uint32)
+    n = _lib.dinth_constants(v.ctypes.data, v.size)
+    assert n == 12
+    return {"exceptions": int(v[0]), "num_selectors": int(v[1]), "max_entry_size": int(v[2]), "num_entries": int(v[3]),
+            "target_sizes": [int(x) for x in v[5:5 + int(v[4])]], "block_size": int(v[10]), "reserved": int(v[11])}
+
+
+def block_selector(values) -> int:
+    """The context of a block of gaps (selector::get, reference statistics_collectors.hpp:21-40)."""
+    w = _u32(values)
+    return int(_lib.dinth_block_selector(w.ctypes.data, w.size))
 
 
 def dict_num_entries(kind: int, dict_file: bytes, d: int = 0) -> int:

@@ -98,6 +98,13 @@ int dinth_build_index(int kind, const void* docs_dict_file, size_t docs_dict_len
 /* MurmurHash64A(seed 0) of n u32 words (reference include/dint/hash_utils.hpp:7-80). */
 uint64_t dinth_hash_u32s(const uint32_t* p, size_t n);
 
+/* The compile-time constants this build was made with (dint/constants.hpp), for tests that pin them to the reference's
+ * dint_configuration.hpp:6,20,24-28 / util.hpp:33-35: {exceptions, num_selectors, max_entry_size, num_entries,
+ * num_target_sizes, target_sizes[0..4], block_size, reserved}. Returns how many there are; writes at most cap. */
+int dinth_constants(uint32_t* out, int cap);
+/* The context of a block (selector::get, reference statistics_collectors.hpp:21-40). */
+uint32_t dinth_block_selector(const uint32_t* p, size_t n);
+
 /* Dictionary file introspection for tests: writes up to cap (size, first
  * payload words) — returns number of entries of dictionary `d`. */
 int dinth_dict_entry(int kind, const void* dict_file, size_t dict_len, uint32_t d, uint32_t index,

@@ -110,6 +110,33 @@ uint64_t oracle_and_query_freqs(const oracle_dict* docs_dict, const oracle_dict*
                                 const uint64_t* list_offsets, uint64_t num_docs, const uint32_t* terms_in, size_t n_terms,
                                 uint64_t* freq_sum, uint64_t* freqs_blocks);
 
+/* ---- dictionary construction statistics (dint_oracle_stats.c) ----------------------------- */
+
+/* selector::get (include/dint/statistics_collectors.hpp:21-40): the context of a block of n integers. */
+uint32_t oracle_selector_get(const uint32_t* entry, size_t n);
+/* hash_bytes64 over whole u32 words (include/dint/hash_utils.hpp:7-71, :77-80): the n-grams' only key. */
+uint64_t oracle_hash_u32s(const uint32_t* p, size_t n);
+
+typedef struct oracle_stats oracle_stats;
+typedef struct {
+    uint64_t pos;     /* the n-gram's integers: gaps[pos, pos + len) (its first occurrence) */
+    uint64_t freq;    /* occurrences counted */
+    uint32_t len;     /* 1, 2, 4, 8 or 16 */
+    uint32_t context; /* 0 for single dictionaries, the block selector for multi */
+} oracle_ngram;
+
+/* block_statistics / block_multi_statistics construction (include/dint/block_statistics.hpp:45-108, :201-279):
+ * create over the collection's gaps (the caller's array, kept by reference), collect() once per list, then read the
+ * counts (entries) or the dictionary-ordered selection (select: filter, freq_length_sorter, the first 65536). */
+oracle_stats* oracle_stats_create(int multi, const uint32_t* gaps);
+void oracle_stats_free(oracle_stats* st);
+int oracle_stats_collect(oracle_stats* st, uint64_t first, uint64_t n); /* adjusted::collect, statistics_collectors.hpp:90-118 */
+uint64_t oracle_stats_total(const oracle_stats* st);
+uint64_t oracle_stats_distinct(const oracle_stats* st, uint32_t context);
+uint64_t oracle_stats_entries(const oracle_stats* st, uint32_t context, oracle_ngram* out, uint64_t cap);
+/* dictionary_builders.hpp:15-38, :50-75: returns the number of entries that pass the filter; writes min(that, 65536, cap) */
+uint64_t oracle_stats_select(const oracle_stats* st, uint32_t context, oracle_ngram* out, uint64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

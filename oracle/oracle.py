@@ -13,7 +13,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "liboracle.so")
+# DINT_ORACLE_LIB: another build of the same library (the sanitizer build, `make -C oracle asan`; README "Sanitizers")
+_LIB = os.environ.get("DINT_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")
 
 RECT, SINGLE_PACKED, MULTI_PACKED = 0, 1, 2
 
@@ -54,6 +55,24 @@ def _load():
     lib.oracle_time_stream_parallel.restype = C.c_double
     lib.oracle_time_stream_parallel.argtypes = [vp, vp, C.c_size_t, vp, C.c_uint32, C.c_double,
                                                 C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.oracle_selector_get.restype = C.c_uint32
+    lib.oracle_selector_get.argtypes = [vp, C.c_size_t]
+    lib.oracle_hash_u32s.restype = C.c_uint64
+    lib.oracle_hash_u32s.argtypes = [vp, C.c_size_t]
+    lib.oracle_stats_create.restype = vp
+    lib.oracle_stats_create.argtypes = [C.c_int, vp]
+    lib.oracle_stats_free.restype = None
+    lib.oracle_stats_free.argtypes = [vp]
+    lib.oracle_stats_collect.restype = C.c_int
+    lib.oracle_stats_collect.argtypes = [vp, C.c_uint64, C.c_uint64]
+    lib.oracle_stats_total.restype = C.c_uint64
+    lib.oracle_stats_total.argtypes = [vp]
+    lib.oracle_stats_distinct.restype = C.c_uint64
+    lib.oracle_stats_distinct.argtypes = [vp, C.c_uint32]
+    lib.oracle_stats_entries.restype = C.c_uint64
+    lib.oracle_stats_entries.argtypes = [vp, C.c_uint32, vp, C.c_uint64]
+    lib.oracle_stats_select.restype = C.c_uint64
+    lib.oracle_stats_select.argtypes = [vp, C.c_uint32, vp, C.c_uint64]
     return lib
 
 
@@ -184,3 +203,68 @@ class OracleIndex:
         n = _lib.oracle_and_query_freqs(self.docs_dict._h, freqs_dict._h, self._padded.ctypes.data, self._offs.ctypes.data,
                                         self.num_docs, t.ctypes.data, t.size, C.byref(fsum), C.byref(fblocks))
         return int(n), int(fsum.value), int(fblocks.value)
+
+
+# ---- dictionary construction statistics (dint_oracle_stats.c) ----
+
+NGRAM_DTYPE = np.dtype([("pos", "<u8"), ("freq", "<u8"), ("len", "<u4"), ("context", "<u4")])  # oracle_ngram
+
+
+def selector_get(values) -> int:
+    """selector::get (statistics_collectors.hpp:21-40): the context of a block."""
+    v = np.ascontiguousarray(values, dtype=np.uint32)
+    return int(_lib.oracle_selector_get(v.ctypes.data, v.size))
+
+
+def hash_u32s(values) -> int:
+    """hash_bytes64 over u32 words (hash_utils.hpp:77-80)."""
+    v = np.ascontiguousarray(values, dtype=np.uint32)
+    return int(_lib.oracle_hash_u32s(v.ctypes.data, v.size))
+
+
+class Stats:
+    """block_statistics (multi=False) / block_multi_statistics (multi=True) over a collection's gaps: collect() once per
+    list, then entries(context) = every distinct n-gram with its count, select(context) = what DSF appends, in order."""
+
+    def __init__(self, multi: bool, gaps: np.ndarray):
+        self.gaps = np.ascontiguousarray(gaps, dtype=np.uint32)
+        self.contexts = 6 if multi else 1
+        self._h = _lib.oracle_stats_create(int(bool(multi)), self.gaps.ctypes.data)
+        if not self._h:
+            raise MemoryError("oracle_stats_create")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.oracle_stats_free(h)
+
+    def collect(self, first: int, n: int) -> None:
+        assert 0 <= first and first + n <= self.gaps.size
+        if not _lib.oracle_stats_collect(self._h, first, n):
+            raise MemoryError("oracle_stats_collect")
+
+    def collect_lists(self, lens) -> None:
+        first = 0
+        for n in lens:
+            self.collect(first, int(n))
+            first += int(n)
+
+    @property
+    def total_integers(self) -> int:
+        return int(_lib.oracle_stats_total(self._h))
+
+    def entries(self, context: int = 0) -> np.ndarray:
+        n = int(_lib.oracle_stats_distinct(self._h, context))
+        out = np.empty(n, dtype=NGRAM_DTYPE)
+        got = int(_lib.oracle_stats_entries(self._h, context, out.ctypes.data, n))
+        assert got == n
+        return out
+
+    def select(self, context: int = 0):
+        """-> (the entries DSF appends for this context, in dictionary order; how many passed the filter)."""
+        out = np.empty(65536, dtype=NGRAM_DTYPE)
+        passed = int(_lib.oracle_stats_select(self._h, context, out.ctypes.data, out.size))
+        return out[: min(passed, 65536)].copy(), passed
+
+    def ngram(self, e) -> tuple:
+        return tuple(int(x) for x in self.gaps[int(e["pos"]): int(e["pos"]) + int(e["len"])])

@@ -316,14 +316,35 @@ def test_seeded_sweep_of_small_collections(device, kind):
 @pytest.mark.parametrize("kind", ALL_KINDS)
 @pytest.mark.parametrize("corpus_name", ["small_corpus", "sparse_corpus"])
 def test_block_statistics_on_the_device(device, request, kind, corpus_name):
-    """the n-gram counting of the dictionary construction on the device (dint_count_ngrams,
-    statistics_collectors.hpp:90-118) + the host's selection == the host-only construction, byte for byte."""
+    """SURVEY §8 f2 against the ORACLE (oracle/dint_oracle_stats.c: selector::get, adjusted::collect, the saving
+    filter, freq_length_sorter and the DSF cut restated from statistics_collectors.hpp:21-118, block_statistics.hpp:82-106,
+    dictionary_builders.hpp:15-75): the device's n-gram counts (dint_count_ngrams) are the oracle's, n-gram for n-gram
+    and context for context, and the device's selection (dint_select_ngrams) is the oracle's, in the same order — the
+    order among entries of equal frequency and length is by their integers in both (the reference's depends on
+    libstdc++: oracle header). The dictionary file built from it equals the host library's."""
+    import torch
+
     coll = request.getfixturevalue(corpus_name).coll
-    got, ms = device.build_dictionary(kind, coll)
-    assert got == host.build_dictionary(kind, coll)
+    multi = kind == host.MULTI_PACKED
+    gaps = np.ascontiguousarray(coll.gaps, dtype=np.uint32)
+    st = oracle.Stats(multi, gaps)
+    st.collect_lists(coll.lens)
+    gaps_dev = torch.from_numpy(gaps.view(np.int32)).cuda()
+    starts = np.zeros(len(coll.lens) + 1, dtype=np.uint64)
+    np.cumsum(coll.lens, out=starts[1:])
+    entries, ms = device.count_ngrams(gaps_dev, starts, multi)
+    ngram = lambda e: tuple(int(x) for x in gaps[int(e["pos"]):int(e["pos"]) + int(e["len"])])
+    got = {(int(e["ctx"]), ngram(e)): int(e["freq"]) for e in entries}
+    want = {(c, st.ngram(e)): int(e["freq"]) for c in range(st.contexts) for e in st.entries(c)}
+    assert len(got) == len(entries) and got == want
+    chosen = device.select_ngrams(gaps_dev, entries, coll.num_postings, top_k=65536)
+    want_sel = [(c, int(e["freq"]), st.ngram(e)) for c in range(st.contexts) for e in st.select(c)[0]]
+    assert [(int(e["ctx"]), int(e["freq"]), ngram(e)) for e in chosen] == want_sel
+    built, ms2 = device.build_dictionary(kind, coll)
+    assert built == host.build_dictionary(kind, coll)
     sampled, _ = device.build_dictionary(kind, coll, max_sample_ints=coll.num_postings // 3)
     assert sampled == host.build_dictionary(kind, coll, max_sample_ints=coll.num_postings // 3)
-    assert ms > 0
+    assert ms > 0 and ms2 > 0
 
 
 @pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
