@@ -199,7 +199,6 @@ struct dint_dict {
     // timing events of the decode kernel: one pair per queue slot (launches on different streams may
     // interleave); dint_last_kernel_ms reads the pair of the most recent launch
     int last_slot = -1;
-    bool no_bundles = false;  // DINT_NO_BUNDLES in the environment when the dictionary was created (diagnostic)
     // work-queue counters: one slot per in-flight launch, recycled round-robin
     // behind the event of the launch that used the slot last
     static constexpr uint32_t kQueueSlots = 64;
@@ -489,9 +488,47 @@ struct dint_query_index {
     std::mutex mutex;
 };
 
+// ---- options (dint_set_option): process-wide switches for tests and measurements, read by the entry points with one
+// relaxed atomic load — no environment variable is looked at anywhere in this library -----------------------------------
+namespace {
+struct option_def {
+    const char* key;
+    long long def;
+};
+constexpr option_def kOptionDefs[DINT_OPT_COUNT_] = {
+    {"bundles", 1},                 // DINT_OPT_BUNDLES
+    {"index_concurrent", 1},        // DINT_OPT_INDEX_CONCURRENT
+    {"query_lean_pages", -1},       // DINT_OPT_QUERY_LEAN_PAGES (-1: every page decode takes the one-launch form)
+    {"query_tail_pages", 4},        // DINT_OPT_QUERY_TAIL_PAGES
+    {"query_fused_pages", 2},       // DINT_OPT_QUERY_FUSED_PAGES
+};
+std::atomic<long long> g_options[DINT_OPT_COUNT_] = {{1}, {1}, {-1}, {4}, {2}};
+inline long long opt(int which) { return g_options[which].load(std::memory_order_relaxed); }
+}  // namespace
+
 extern "C" {
 
 int dint_abi_version(void) { return DINT_ABI_VERSION; }
+
+int dint_set_option(int option, long long value) {
+    if (option < 0 || option >= DINT_OPT_COUNT_) return DINT_ERR_ARG;
+    if (option != DINT_OPT_QUERY_LEAN_PAGES && value < 0) return DINT_ERR_ARG;
+    g_options[option].store(value, std::memory_order_relaxed);
+    return DINT_OK;
+}
+
+int dint_get_option(int option, long long* value) {
+    if (option < 0 || option >= DINT_OPT_COUNT_ || !value) return DINT_ERR_ARG;
+    *value = opt(option);
+    return DINT_OK;
+}
+
+const char* dint_option_name(int option) { return option < 0 || option >= DINT_OPT_COUNT_ ? nullptr : kOptionDefs[option].key; }
+
+int dint_reset_options(void) {
+    for (int i = 0; i != DINT_OPT_COUNT_; ++i) g_options[i].store(kOptionDefs[i].def, std::memory_order_relaxed);
+    return DINT_OK;
+}
 
 const char* dint_strerror(int status) {
     switch (status) {
@@ -541,7 +578,6 @@ int dint_dict_create(int kind, const void* file_bytes, size_t len, int device, d
     dd->entries = pd.entries;
     dd->h_start = pd.start;
     dd->h_size = pd.size;
-    dd->no_bundles = std::getenv("DINT_NO_BUNDLES") != nullptr;
     hipDeviceProp_t prop;
     if (!hip_ok(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties")) {
         delete dd;
@@ -804,7 +840,7 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
         else
             hipLaunchKernelGGL(multi ? decode_multi_kernel : decode_single_kernel, dim3(grid), dim3(kBlockThreads), lds_bytes, s, a);
     };
-    if (d_zeroed_queue && (n_units < schedule_from || dd->no_bundles)) {
+    if (d_zeroed_queue && (n_units < schedule_from || (opt(DINT_OPT_BUNDLES) == 0))) {
         // the lean launch: the caller brings the (zeroed) queue counters, nothing is timed, nothing scheduled — one
         // API call (a query's pages: the host-side cost of a launch sequence is what a single query waits for)
         a.queue = d_zeroed_queue;
@@ -841,7 +877,7 @@ static int launch_decode(const dint_dict* dd, const uint8_t* d_enc, size_t enc_b
     // (schedule_from: a caller that decodes a handful of units at a time — a query's pages — does without the three
     // schedule launches: with fewer units than waves nothing is gained by sharing tiles)
     if (n_units >= schedule_from && n_units < 0xFFFFFFFFull &&
-        !dd->no_bundles) {
+        !(opt(DINT_OPT_BUNDLES) == 0)) {
         sched_layout L(n_units);
         if (cache) {
             if (!cache->matches(dd, d_enc, enc_bytes, d_units, n_units, d_spans, out_capacity, only_full)) {
@@ -923,7 +959,7 @@ int dint_unit_table_create(const dint_dict* dd, const uint8_t* d_enc, size_t enc
     t->d_units = d_units;
     t->n_units = n_units;
     t->out_capacity = out_capacity;
-    if (n_units >= 2 && n_units < 0xFFFFFFFFull && !dd->no_bundles) {
+    if (n_units >= 2 && n_units < 0xFFFFFFFFull && !(opt(DINT_OPT_BUNDLES) == 0)) {
         int st = build_schedule(dd, d_enc, enc_bytes, d_units, n_units, out_capacity, 0, nullptr, &t->sched, static_cast<hipStream_t>(stream));
         if (st == DINT_OK) {  // how many work items the unit queue got (none: the bundles-only kernel serves the table)
             sched_layout L(n_units);
@@ -1084,10 +1120,7 @@ int block_table_decode(const dint_dict* docs_dict, const dint_dict* freqs_dict, 
     // its end offset unwritten — nothing may be derived from it.
     const bool covers = out_capacity >= t.max_out_end;
     const bool keep = t.owns_blocks && covers && t.decodes >= 1;  // (a one-shot table never reaches its second decode)
-    static const bool concurrent_ok = [] {
-        const char* e = std::getenv("DINT_INDEX_CONCURRENT");
-        return !e || std::atoi(e) != 0;
-    }();
+    const bool concurrent_ok = opt(DINT_OPT_INDEX_CONCURRENT) != 0;
     // From the second decode of a table on (the side streams are the table's): the freqs launch beside the docs launch once
     // its units are known, and the short blocks' decoder beside both.
     const bool side_freqs = d_freqs && t.freqs_units_ready && keep && concurrent_ok;
@@ -1379,20 +1412,14 @@ constexpr size_t kCtrlWords = kCtrlQueueAt + (kQueueShards + 1) * kQueueStride;
 // single query 95 -> 53 us, the reference's query log as one batch 2.16 -> 1.53 us per query, the longest lists
 // 5.6 -> 5.0 — so it is the default; the variable keeps the other form testable (tests/test_gpu_queries.py).
 static size_t lean_pages() {
-    const char* e = std::getenv("DINT_QUERY_LEAN_PAGES");
-    return e ? size_t(std::strtoull(e, nullptr, 10)) : ~size_t(0);
+    const long long v = opt(DINT_OPT_QUERY_LEAN_PAGES);
+    return v < 0 ? ~size_t(0) : size_t(v);
 }
 
 // (one workgroup walks all the candidates: past a few pages the probe and search launches, a thread per candidate, win)
-static size_t tail_pages() {
-    const char* e = std::getenv("DINT_QUERY_TAIL_PAGES");
-    return e ? size_t(std::strtoull(e, nullptr, 10)) : size_t(4);
-}
+static size_t tail_pages() { return size_t(opt(DINT_OPT_QUERY_TAIL_PAGES)); }
 // (a query of at most this many candidate pages runs as ONE launch of one workgroup: query_fused_body)
-static size_t fused_pages() {
-    const char* e = std::getenv("DINT_QUERY_FUSED_PAGES");
-    return e ? size_t(std::strtoull(e, nullptr, 10)) : size_t(2);
-}
+static size_t fused_pages() { return size_t(opt(DINT_OPT_QUERY_FUSED_PAGES)); }
 static int decode_pages_lean(dint_query_index* qi, const uint32_t* d_ids, const uint32_t* d_count, size_t bound, uint32_t* d_docs,
                              uint32_t* ctrl, uint32_t retire, hipStream_t s, const query_pages* search,
                              const round_tail* tail = nullptr);

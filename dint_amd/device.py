@@ -27,7 +27,7 @@ _LIB_PATH = os.environ.get("DINT_HIP_LIB") or os.path.join(_HERE, "libdint_hip.s
 
 #: every symbol include/dint_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
-    "dint_abi_version", "dint_strerror", "dint_last_hip_error", "dint_device_count",
+    "dint_abi_version", "dint_set_option", "dint_get_option", "dint_option_name", "dint_reset_options", "dint_strerror", "dint_last_hip_error", "dint_device_count",
     "dint_dict_create", "dint_dict_destroy", "dint_dict_info_get", "dint_index_stream", "dint_free",
     "dint_decode_units", "dint_unit_table_create", "dint_unit_table_destroy", "dint_decode_unit_table", "dint_decode_list_host", "dint_last_kernel_ms", "dint_recent_kernel_ms",
     "dint_stream_stats_get",
@@ -68,6 +68,10 @@ def _load():
     lib.dint_abi_version.restype = C.c_int
     lib.dint_strerror.restype = C.c_char_p
     lib.dint_strerror.argtypes = [C.c_int]
+    lib.dint_set_option.argtypes = [C.c_int, C.c_longlong]
+    lib.dint_get_option.argtypes = [C.c_int, C.POINTER(C.c_longlong)]
+    lib.dint_option_name.restype = C.c_char_p
+    lib.dint_option_name.argtypes = [C.c_int]
     lib.dint_last_hip_error.restype = C.c_char_p
     lib.dint_device_count.argtypes = [C.POINTER(C.c_int)]
     lib.dint_dict_create.argtypes = [C.c_int, vp, sz, C.c_int, C.POINTER(vp)]
@@ -132,6 +136,48 @@ def _check(status: int, where: str) -> None:
 
 def abi_version() -> int:
     return _lib.dint_abi_version()
+
+
+#: dint_option (include/dint_hip.h): name -> number, from the library itself
+OPTIONS = {}
+_i = 0
+while _lib.dint_option_name(_i):
+    OPTIONS[_lib.dint_option_name(_i).decode()] = _i
+    _i += 1
+
+
+def set_option(name: str, value: int) -> None:
+    """dint_set_option: a process-wide switch for tests and measurements ("bundles", "index_concurrent",
+    "query_lean_pages", "query_tail_pages", "query_fused_pages")."""
+    _check(_lib.dint_set_option(OPTIONS[name], int(value)), f"dint_set_option({name})")
+
+
+def get_option(name: str) -> int:
+    v = C.c_longlong()
+    _check(_lib.dint_get_option(OPTIONS[name], C.byref(v)), f"dint_get_option({name})")
+    return int(v.value)
+
+
+def reset_options() -> None:
+    _check(_lib.dint_reset_options(), "dint_reset_options")
+
+
+class options:
+    """with device.options(query_fused_pages=0): ...  — the options set inside, restored on the way out."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: get_option(k) for k in self.kw}
+        for k, v in self.kw.items():
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False
 
 
 def device_count() -> int:

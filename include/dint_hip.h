@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DINT_ABI_VERSION 3
+#define DINT_ABI_VERSION 4
 
 /* A unit decodes to at most this many integers (the kernels address a unit's output with 32-bit byte
  * offsets); dint_index_stream never cuts larger ones, dint_decode_units skips them. */
@@ -77,6 +77,23 @@ typedef struct dint_dict_info {
 } dint_dict_info;
 
 int dint_abi_version(void);
+
+/* Process-wide switches for tests and measurements (the library reads no environment variable). Defaults are what a
+ * caller wants; every entry point reads them with one relaxed atomic load, so a change takes effect from the next call
+ * on and is safe against concurrent calls. dint_set_option refuses values outside an option's range (DINT_ERR_ARG). */
+typedef enum dint_option {
+    DINT_OPT_BUNDLES = 0,             /* 1 (default): tiny units share tiles (bundle schedule); 0: every unit on its own           */
+    DINT_OPT_INDEX_CONCURRENT = 1,    /* 1 (default): dint_decode_block_table runs its launches side by side; 0: one stream      */
+    DINT_OPT_QUERY_LEAN_PAGES = 2,    /* page decodes of at least this many pages take the three-launch form; -1 (default): none */
+    DINT_OPT_QUERY_TAIL_PAGES = 3,    /* calls of at most this many candidate pages run a round per launch; default 4            */
+    DINT_OPT_QUERY_FUSED_PAGES = 4,   /* ... of at most this many run as ONE launch; default 2, 0: never                         */
+    DINT_OPT_COUNT_ = 5
+} dint_option;
+int dint_set_option(int option, long long value);
+int dint_get_option(int option, long long* value);
+const char* dint_option_name(int option); /* "bundles", "index_concurrent", ... ; NULL past the last */
+int dint_reset_options(void);             /* every option back to its default */
+
 const char* dint_strerror(int status);
 /* text of the last HIP error seen by the calling thread ("" if none) */
 const char* dint_last_hip_error(void);
@@ -215,7 +232,7 @@ void dint_block_table_destroy(dint_block_table* table);
  * freq = value + 1 is added where the values are stored — blocks shorter than 256 through the
  * binary-interpolative decoder (whose code is the prefix sums already). From a table's second decode on, the freqs
  * launch and the short blocks' decoder run on streams the table owns, beside the docs launch, forked from and joined
- * to `stream` inside the call: to the caller everything is ordered on `stream` as before (DINT_INDEX_CONCURRENT=0 in
+ * to `stream` inside the call: to the caller everything is ordered on `stream` as before (dint_set_option(DINT_OPT_INDEX_CONCURRENT, 0) in
  * the environment: one stream).
  * Replaces: see dint_decode_posting_blocks. */
 int dint_decode_block_table(const dint_dict* docs_dict, const dint_dict* freqs_dict, const uint8_t* d_index,
@@ -252,10 +269,9 @@ void dint_query_index_destroy(dint_query_index* qi);
  * once, queries.hpp:28-31; an empty query counts 0, :38). terms/query_offsets/counts are HOST
  * arrays: query q is terms[query_offsets[q] .. query_offsets[q+1]). A term >= n_lists is
  * DINT_ERR_ARG. The call enqueues on `stream` and returns after synchronising it: one copy in, then one launch
- * per term for a query of a few pages, three per round for a batch. Two environment variables,
- * read per call, exist for tests and measurements: DINT_QUERY_LEAN_PAGES (page decodes of at least this many
- * pages take the three-launch form; unset: none does) and DINT_QUERY_TAIL_PAGES (calls of at most this many
- * candidate pages run a whole round per launch; unset: 4). */
+ * per term for a query of a few pages, three per round for a batch. Which form a call
+ * takes is moved, for tests and measurements, by dint_set_option: DINT_OPT_QUERY_LEAN_PAGES, DINT_OPT_QUERY_TAIL_PAGES,
+ * DINT_OPT_QUERY_FUSED_PAGES. */
 int dint_and_queries(dint_query_index* qi, const uint32_t* terms, const uint64_t* query_offsets,
                      size_t n_queries, uint64_t* counts, void* stream);
 

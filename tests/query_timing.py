@@ -28,14 +28,14 @@ def main():
     ap.add_argument("--cpu-queries", type=int, default=500)
     ap.add_argument("--forms", action="store_true", help="also time the single-query calls with each launch form forced")
     args = ap.parse_args()
-    args.forms = [("round_per_launch_no_fusing", {"DINT_QUERY_FUSED_PAGES": "0"}),
-                  ("whole_query_in_one_launch_up_to_1_page", {"DINT_QUERY_FUSED_PAGES": "1"}),
-                  ("whole_query_in_one_launch_up_to_4_pages", {"DINT_QUERY_FUSED_PAGES": "4"}),
-                  ("three_launches_per_decode", {"DINT_QUERY_LEAN_PAGES": "0"}),
-                  ("one_launch_per_decode", {"DINT_QUERY_TAIL_PAGES": "0"}),
-                  ("round_tail_up_to_4_pages", {"DINT_QUERY_TAIL_PAGES": "4"}),
-                  ("round_tail_up_to_16_pages", {"DINT_QUERY_TAIL_PAGES": "16"}),
-                  ("round_tail_up_to_64_pages", {"DINT_QUERY_TAIL_PAGES": "64"})] if args.forms else []
+    args.forms = [("round_per_launch_no_fusing", {"query_fused_pages": 0}),
+                  ("whole_query_in_one_launch_up_to_1_page", {"query_fused_pages": 1}),
+                  ("whole_query_in_one_launch_up_to_4_pages", {"query_fused_pages": 4}),
+                  ("three_launches_per_decode", {"query_lean_pages": 0}),
+                  ("one_launch_per_decode", {"query_tail_pages": 0}),
+                  ("round_tail_up_to_4_pages", {"query_tail_pages": 4}),
+                  ("round_tail_up_to_16_pages", {"query_tail_pages": 16}),
+                  ("round_tail_up_to_64_pages", {"query_tail_pages": 64})] if args.forms else []
 
     import torch
     from dint_amd import device, host
@@ -70,9 +70,10 @@ def main():
             qi.and_queries(qs)
             t_batch.append(time.perf_counter() - t0)
         batch_forms = {}
-        for form, env in ([("three_launches_per_decode", {"DINT_QUERY_LEAN_PAGES": "0"}),
-                           ("one_launch_per_decode", {"DINT_QUERY_LEAN_PAGES": "1000000000"})] if args.forms else []):
-            os.environ.update(env)
+        for form, env in ([("three_launches_per_decode", {"query_lean_pages": 0}),
+                           ("one_launch_per_decode", {"query_lean_pages": 1000000000})] if args.forms else []):
+            for k, v in env.items():
+                device.set_option(k, v)
             qi.and_queries(qs)
             ts = []
             for _ in range(args.runs):
@@ -80,8 +81,7 @@ def main():
                 qi.and_queries(qs)
                 ts.append(time.perf_counter() - t0)
             batch_forms[form] = min(ts) * 1e6 / len(qs)
-            for k in env:
-                del os.environ[k]
+            device.reset_options()
         # one query per call, the reference's op_perftest shape: the queries are parsed (packed) beforehand, the
         # timed region is the call
         packed = []
@@ -104,11 +104,11 @@ def main():
         # this box: boxes differ by more than the forms do
         forms = {}
         for form, env in args.forms:
-            os.environ.update(env)
+            for k, v in env.items():
+                device.set_option(k, v)
             singles()
             forms[form] = float(singles().mean())
-            for k in env:
-                del os.environ[k]
+            device.reset_options()
         cpu_q = qs[:args.cpu_queries]
         cpu = []
         for q in cpu_q:

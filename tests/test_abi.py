@@ -28,7 +28,27 @@ def test_python_binding_lists_the_same_symbols():
     from dint_amd import device
 
     assert sorted(device.ABI_SYMBOLS) == declared_functions("dint_hip.h")
-    assert device.abi_version() == 3
+    assert device.abi_version() == 4
+
+
+def test_options_are_an_api_not_the_environment():
+    """dint_set_option / dint_get_option: process-wide switches with defaults and ranges; no GPU needed. The library
+    reads no environment variable (the strings of its binary hold no getenv target of ours)."""
+    from dint_amd import device
+
+    assert set(device.OPTIONS) == {"bundles", "index_concurrent", "query_lean_pages", "query_tail_pages", "query_fused_pages"}
+    device.reset_options()
+    defaults = {k: device.get_option(k) for k in device.OPTIONS}
+    assert defaults == {"bundles": 1, "index_concurrent": 1, "query_lean_pages": -1, "query_tail_pages": 4,
+                        "query_fused_pages": 2}
+    with device.options(query_fused_pages=0, query_tail_pages=16):
+        assert device.get_option("query_fused_pages") == 0 and device.get_option("query_tail_pages") == 16
+    assert {k: device.get_option(k) for k in device.OPTIONS} == defaults
+    lib = device._lib
+    assert lib.dint_set_option(device.OPTIONS["bundles"], C.c_longlong(-1)) == -1
+    assert lib.dint_set_option(99, C.c_longlong(0)) == -1 and lib.dint_get_option(0, None) == -1
+    blob = open(os.path.join(ROOT, "dint_amd", "libdint_hip.so"), "rb").read()
+    assert b"DINT_QUERY_" not in blob and b"DINT_NO_BUNDLES" not in blob and b"DINT_INDEX_CONCURRENT" not in blob
 
 
 def test_errors_are_status_codes_not_exceptions():

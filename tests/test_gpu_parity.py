@@ -277,11 +277,8 @@ def test_bundles_of_tiny_lists(device, kind, unit_ints):
         units, total, _ = d.index_stream(enc, unit_ints)
         out, ends, _ = device.decode_stream(d, enc, units, total)
         assert np.array_equal(out, coll.gaps)
-        os.environ["DINT_NO_BUNDLES"] = "1"
-        try:
+        with device.options(bundles=0):
             out1, ends1, _ = device.decode_stream(d, enc, units, total)
-        finally:
-            del os.environ["DINT_NO_BUNDLES"]
         assert np.array_equal(out1, coll.gaps)
         assert np.array_equal(ends, ends1)
         # a unit ends where the next one starts, minus that list's header when it opens a new list

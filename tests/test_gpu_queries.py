@@ -21,6 +21,12 @@ def device():
     return dev
 
 
+@pytest.fixture(autouse=True)
+def _options_back_to_default(device):
+    yield
+    device.reset_options()
+
+
 def _query_index(device, ix, kind):
     dd = device.Dictionary(kind, ix.docs_dict)
     return device.QueryIndex(dd, ix.bytes, ix.offsets)
@@ -97,11 +103,11 @@ def test_disjoint_and_identical_lists(device):
 
 @pytest.mark.parametrize("lean_pages", ["0", "1000000000"])
 @pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
-def test_both_page_decode_forms(device, small_corpus, monkeypatch, kind, lean_pages):
+def test_both_page_decode_forms(device, small_corpus, kind, lean_pages):
     """A round's pages are decoded by one launch (few pages: decode_*_query_kernel) or by three (prepare, the
-    scheduled decode kernel, fix-up); DINT_QUERY_LEAN_PAGES moves the switch — both forms, forced, on batches
+    scheduled decode kernel, fix-up); the option query_lean_pages moves the switch — both forms, forced, on batches
     and on single queries."""
-    monkeypatch.setenv("DINT_QUERY_LEAN_PAGES", lean_pages)
+    device.set_option("query_lean_pages", int(lean_pages))
     ix = get_index(small_corpus, kind)
     qi = _query_index(device, ix, kind)
     qs = reference_queries(len(ix.lens))[:300] + heavy_queries(ix.lens, 100, seed=5)
@@ -114,13 +120,13 @@ def test_both_page_decode_forms(device, small_corpus, monkeypatch, kind, lean_pa
 
 @pytest.mark.parametrize("fused_pages", ["0", "1", "4"])
 @pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
-def test_whole_query_in_one_launch(device, small_corpus, monkeypatch, kind, fused_pages):
+def test_whole_query_in_one_launch(device, small_corpus, kind, fused_pages):
     """A query of a few candidate pages runs as ONE launch of one workgroup that walks the whole chain — candidates, every
-    round's pages, every round's tail (query_fused_body); DINT_QUERY_FUSED_PAGES moves the switch (0: never — the
+    round's pages, every round's tail (query_fused_body); the option query_fused_pages moves the switch (0: never — the
     round-per-launch form). Single queries and the freqs variant (whose counting half takes the same path), all forms
     equal to the plain intersection."""
-    monkeypatch.setenv("DINT_QUERY_FUSED_PAGES", fused_pages)
-    monkeypatch.setenv("DINT_QUERY_TAIL_PAGES", "4")
+    device.set_option("query_fused_pages", int(fused_pages))
+    device.set_option("query_tail_pages", 4)
     ix = get_index(small_corpus, kind)
     qi = _query_index(device, ix, kind)
     fd = device.Dictionary(kind, ix.freqs_dict)
@@ -137,12 +143,12 @@ def test_whole_query_in_one_launch(device, small_corpus, monkeypatch, kind, fuse
 
 @pytest.mark.parametrize("tail_pages", ["0", "4", "64"])
 @pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
-def test_round_tail_over_several_workgroups(device, monkeypatch, kind, tail_pages):
+def test_round_tail_over_several_workgroups(device, kind, tail_pages):
     """A small call runs a whole round per launch (round_tail): the workgroup of the page decode that finishes last
     probes and searches. A short rarest list whose postings fall into every block of two long lists makes the
     rounds' page decodes launches of several workgroups (the fenced hand-over), a rarest list of one short block
-    the launch of one; DINT_QUERY_TAIL_PAGES = 0 is the same call without the tail."""
-    monkeypatch.setenv("DINT_QUERY_TAIL_PAGES", tail_pages)
+    the launch of one; query_tail_pages = 0 is the same call without the tail."""
+    device.set_option("query_tail_pages", int(tail_pages))
     r = np.random.default_rng(5)
     long_a = np.arange(0, 60000, 3, dtype=np.uint32)                      # 20000 postings, 79 blocks
     long_b = np.unique(r.integers(0, 60000, 30000)).astype(np.uint32)     # ~ 24000 postings
@@ -173,11 +179,11 @@ def test_round_tail_over_several_workgroups(device, monkeypatch, kind, tail_page
 
 @pytest.mark.parametrize("lean_pages", ["0", "1000000000"])
 @pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
-def test_blocks_left_as_gaps(device, monkeypatch, kind, lean_pages):
+def test_blocks_left_as_gaps(device, kind, lean_pages):
     """Blocks the expansion cannot turn into docIDs on the fly — a dictionary entry holding a value >= 65536 (a
     constant stride of 70000: the dictionary learns runs of 69999), or more than 256 slots in the block (every gap
     an exception) — are summed afterwards, by the decoding wave or by the fix-up launch."""
-    monkeypatch.setenv("DINT_QUERY_LEAN_PAGES", lean_pages)
+    device.set_option("query_lean_pages", int(lean_pages))
     r = np.random.default_rng(77)
     stride = (np.arange(700, dtype=np.uint64) * 70000).astype(np.uint32)
     wild = np.cumsum(r.integers(100000, 3000000, 700, dtype=np.uint64)).astype(np.uint32)

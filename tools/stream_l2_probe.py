@@ -91,6 +91,15 @@ for spec in args.libs:
                 ts.append(ms.value)
         got = out_dev.cpu().numpy().view(np.uint32)
         ok = all(np.array_equal(got[r * n_slice:(r + 1) * n_slice], expect) for r in (0, R // 2, R - 1))
+        if hasattr(lib, "dint_debug_read_profile"):  # a -DDINT_PROFILE build: where the waves' cycles went (last launch)
+            prof = (C.c_ulonglong * 16)()
+            if lib.dint_debug_read_profile(prof) == 0 and sum(prof):
+                names = {0: "outside", 1: "classify (tile-top wait)", 2: "sizes + scans", 3: "metas + heads of next tile", 4: "tables",
+                         5: "rotate + far prefetch", 7: "tails land", 8: "wait point", 9: "expand + stores", 10: "slow stores",
+                         11: "prologue", 12: "bundle front end", 13: "epilogue", 14: "queue ticket"}
+                for i in range(16):
+                    if prof[i]:
+                        print(f"      {i:2d} {names.get(i, '?'):28s} {prof[i] / (R * n_slice) * 900:8.0f} cycles per 900 ints")
         v = np.array(ts)
         print(f"{name:12s} {label:32s} median {np.median(v):.4f} ms  min {v.min():.4f}  {R * n_slice / np.median(v) / 1e6:.1f} G ints/s  bit-exact {ok}",
               flush=True)
