@@ -254,6 +254,7 @@ struct hot_layout {
     std::vector<uint32_t> image;
     std::vector<dict_desc> descs;
     uint32_t hot_entries = 0;
+    uint32_t long_bitmap_word = 0;  // single-dictionary files: where the long-entry bitmap sits in the image (words)
 };
 
 uint32_t entry_payload_words(parsed_dict const& pd, uint32_t d, uint32_t i) {
@@ -270,7 +271,9 @@ bool entry_is_wide(parsed_dict const& pd, uint32_t d, uint32_t i) {
 
 int choose_hot_set(parsed_dict const& pd, hot_layout& out) {
     const uint32_t nd = pd.num_dicts;
-    const uint64_t share = (2 * uint64_t(kHotImageWords) - kZeroHalves - 8) / nd - 8;  // in u16 units
+    // (single-dictionary files: 8 KB of the image are the long-entry bitmap, kLongBitmapWords behind the zeros)
+    const uint32_t bitmap_halves = (DINT_LEAN_SEGMENT == 2 && nd == 1) ? 2 * kLongBitmapWords : 0;  // (only a build with decode_segment_v4 reads it)
+    const uint64_t share = (2 * uint64_t(kHotImageWords) - kZeroHalves - bitmap_halves - 8) / nd - 8;  // in u16 units
     std::vector<uint8_t> covered(pd.table.size(), 0);
     std::vector<uint32_t> hot_k(nd, 0);
     // pass 1: how many codewords of each dictionary fit its share (a meta word = 2 units, a payload integer = 1)
@@ -291,7 +294,16 @@ int choose_hot_set(parsed_dict const& pd, hot_layout& out) {
         hot_k[d] = k;
     }
     // pass 2: lay the image out (u16 units; the metas sit on word boundaries)
-    std::vector<uint16_t> halves(kZeroHalves, 0);
+    std::vector<uint16_t> halves(kZeroHalves + bitmap_halves, 0);
+    out.long_bitmap_word = bitmap_halves ? kLongBitmapWordAt : 0;
+    if (bitmap_halves) {
+        // bit i: codeword i is cold and its integers do not fit its 16-byte head (7..16 of them: two or three staging cells)
+        const uint32_t n_entries = std::min<uint32_t>(pd.start[1] - pd.start[0], kEntries);
+        for (uint32_t i = std::max<uint32_t>(2, hot_k[0]); i < n_entries; ++i) {
+            const uint32_t pw = entry_payload_words(pd, 0, i);
+            if (pw > 6 && !entry_is_wide(pd, 0, i)) halves[kZeroHalves + 2 * (i >> 5) + ((i >> 4) & 1u)] |= uint16_t(1u << (i & 15u));
+        }
+    }
     out.descs.assign(nd, dict_desc{});
     out.hot_entries = 0;
     for (uint32_t d = 0; d != nd; ++d) {
@@ -335,6 +347,7 @@ int upload_hot_set(dint_dict& dd, hot_layout const& lay) {
     HIP_TRY(hipMemcpy(dd.d_descs, lay.descs.data(), lay.descs.size() * sizeof(dict_desc), hipMemcpyHostToDevice));
     dd.view.hot_words = uint32_t(lay.image.size());
     dd.view.first = lay.descs[0];
+    dd.view.long_bitmap_word = lay.long_bitmap_word;
     dd.hot_entries = lay.hot_entries;
     dd.h_hot_k.clear();
     for (auto const& d : lay.descs) dd.h_hot_k.push_back(d.hot_k);

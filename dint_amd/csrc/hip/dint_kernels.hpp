@@ -63,10 +63,9 @@ namespace dint_dev {
 #define DINT_FF_OPEN 4  // bundles the multi-dictionary schedule keeps open while it packs a chunk (first fit)
 #endif
 #ifndef DINT_LEAN_SEGMENT
-#define DINT_LEAN_SEGMENT 0  // 1: decode_single_kernel's long units through decode_segment_lean (explicit vector-memory waits):
-                             // measured in round 3 — waves wait 27 % less on their counters, but the variant executes 24 %
-                             // more vector instructions and ends 2-3 % slower (profiles/r03_sq_lean.txt); kept as the
-                             // starting point for the next attempt, off by default
+#define DINT_LEAN_SEGMENT 0  // 2: decode_single_kernel's long units through decode_segment_v4 (explicit vector-memory waits, heads and
+                             // tails a tile ahead): measured in round 4 — as fast as decode_segment, no faster (profiles/r04_v4_ab.txt);
+                             // off by default
 #endif
 #ifndef DINT_GATHER_AUX
 #define DINT_GATHER_AUX 0  // cache policy of the metadata / row gathers (L2-resident tables, no reuse in L1)
@@ -109,6 +108,11 @@ constexpr uint32_t kClassTableWords = 328 + 24;       // slot classification tab
 constexpr uint32_t kDescWordAt = 328;
 constexpr uint32_t kHotImageWords = kLdsWords - kClassTableWords - kWavesPerBlock * kScratchWords;
 constexpr uint32_t kZeroHalves = 256;                 // longest run codeword, in u16
+// Single-dictionary images carry, right behind the zeros, one bit per codeword: "a COLD codeword whose integers do not fit its
+// 16-byte head" (more than 6: it needs its 32-byte tail too). The slot value alone then says whether to ask for the tail,
+// so decode_segment_v4 requests heads AND tails a tile ahead and a tile has ONE wait for the dictionary, not two.
+constexpr uint32_t kLongBitmapWords = 65536 / 32;
+constexpr uint32_t kLongBitmapWordAt = kZeroHalves / 2;
 // metadata word of a codeword: (size - 1) << 24 | kMetaCold | kMetaSlow | cells << 20 | LDS byte offset
 constexpr uint32_t kMetaCold = 1u << 23;              // the integers come through staging cells (row table)
 constexpr uint32_t kMetaSlow = 1u << 22;              // ... or, with this bit, from gtable through slow_stores
@@ -141,6 +145,7 @@ struct dict_view {
     uint32_t gtable_base;       // ... of gtable
     uint32_t hot_words;         // multiple of 4
     dict_desc first;            // descs[0], for the single-dictionary kernel
+    uint32_t long_bitmap_word;  // single-dictionary images: LDS word offset of the "long entry" bitmap (0: the image has none)
 };
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -1047,7 +1052,7 @@ __device__ __forceinline__ uint64_t decode_segment(const decode_args& a, const w
     return tile_base + uint64_t(kSlotBytes) * end_slot;
 }
 
-// One dword now: load and wait in one asm statement (the rare paths of decode_segment_lean: a load the compiler keeps
+// One dword now: load and wait in one asm statement (the rare paths of decode_segment_v4: a load the compiler keeps
 // books on, even on a path taken once in a million tiles, makes it place waits for "everything in flight" all over the
 // loop — where control flow merges, its books take the rare path's registers for pending).
 __device__ __forceinline__ uint32_t load_b32_now(const __amdgpu_buffer_rsrc_t rs, uint32_t byte_off) {
@@ -1055,7 +1060,7 @@ __device__ __forceinline__ uint32_t load_b32_now(const __amdgpu_buffer_rsrc_t rs
     asm volatile("buffer_load_dword %0, %1, %2, 0 offen\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(byte_off), "s"(rs) : "memory");
     return v;
 }
-// slow_stores for decode_segment_lean: the slots' values and the exception literals come in registers.
+// slow_stores for decode_segment_v4: the slots' values and the exception literals come in registers.
 __device__ __forceinline__ void slow_stores_lean(const wave_ctx& c, const tile_slots& t, uint32_t slowb, uint32_t pos0, uint32_t seg_n,
                                                  const uint32_t (&sv)[kSPL], const uint32_t (&lit)[kSPL], uint32_t hot_base, uint32_t hot_k,
                                                  uint32_t meta_base, const __amdgpu_buffer_rsrc_t rs_out) {
@@ -1082,22 +1087,13 @@ __device__ __forceinline__ void slow_stores_lean(const wave_ctx& c, const tile_s
     }
 }
 
-// ---- the vroom kernel's segment: the same tile, its vector-memory traffic under EXPLICIT waits ---------------------
-// decode_segment above leaves the waits to the compiler, and every one it places is a wait for everything the wave
-// has in flight — the previous tile's stores, the far prefetch issued a moment ago (profiles/r03: a fifth of a wave's
-// cycles). gfx950 completes a wave's buffer loads and stores in issue order and s_waitcnt vmcnt(N) waits for all but
-// the N youngest (MI355X_MICROARCH.md), so here every load whose result outlives a phase is ISSUED in inline asm (the
-// compiler does not know its destination is pending and adds no wait of its own) and waited for by a counted
-// s_waitcnt, also in asm:
-//   C  heads of tile t+1 (L2), slots of tile t+3 (HBM)                 issued behind the previous tile's last wait
-//   A  expansion of tile t: gathers, S = ceil(total / 256) stores
-//   B  front end of tile t+1: vmcnt(S + 1) — the heads are there, the slots and the stores stay in flight —
-//      classification, sizes, cells, heads land, TAILS issued, flag / delta tables, vmcnt(0): the tails are there (and,
-//      in order, everything older: the slots have had a whole tile, the stores most of one), tails land
-// One loop iteration is C A B: nothing is in flight across the back-edge, no register that a load is writing is
-// live into a phi (a copy of such a register would read it too early; tools/check_inflight.py looks for any). A tile
-// that cannot be expanded in one batch, or holds a slow codeword, is finished inside B the old way.
-// Single-dictionary streams of 16-bit slots, plain d-gaps (no docIDs, no + 1): decode_single_kernel's long units.
+// ---- loads issued in inline asm, waited for by counted s_waitcnt (decode_segment_v4) ----------------------------------
+// decode_segment leaves the waits to the compiler, and every one it places is a wait for everything the wave has in
+// flight — the previous tile's stores, the far prefetch issued a moment ago. gfx950 completes a wave's buffer loads and
+// stores in issue order and s_waitcnt vmcnt(N) waits for all but the N youngest (MI355X_MICROARCH.md), so a segment can
+// ISSUE every load whose result outlives a phase in inline asm (the compiler does not know its destination is pending
+// and adds no wait of its own) and wait for it with a counted s_waitcnt, also in asm. No register that a load is still
+// writing may be touched in between (a copy would read it too early): tools/check_inflight.py scans the assembly.
 __device__ __forceinline__ void issue_b128(u32x4& q, const __amdgpu_buffer_rsrc_t rs, uint32_t byte_off) {
     asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(q) : "v"(byte_off), "s"(rs) : "memory");
 }
@@ -1110,41 +1106,84 @@ __device__ __forceinline__ void issue_b64(u32x2& q, const __amdgpu_buffer_rsrc_t
 __device__ __forceinline__ void issue_b32(uint32_t& q, const __amdgpu_buffer_rsrc_t rs, uint32_t byte_off, uint32_t) {
     asm volatile("buffer_load_dword %0, %1, %2, 0 offen offset:16" : "=v"(q) : "v"(byte_off), "s"(rs) : "memory");
 }
-// "all but the N youngest are done", N = stores + 1 (1..5; more stores than four: the oldest are waited for too). ONE asm
-// statement, so that the four head registers are the same physical registers on every path to it (an asm per case
-// made the compiler copy them — in flight — into each case's own).
-__device__ __forceinline__ void wait_for_heads(head_regs& hr, uint32_t stores) {
+// ---- decode_segment_v4: the vroom kernel's segment (round 4) --------------------------------------------------------
+// The same tile as decode_segment, its vector-memory traffic under explicit waits. A loop iteration is
+//   C  heads AND tails of the tile whose front end runs next, the slots two tiles on   (requests only)
+//   A  expansion and stores of the tile before
+//   B  that front end: ONE wait for the dictionary — vmcnt(stores + 1): the far slots and this iteration's stores stay
+//      in flight — classification (a tile ahead: payload slots ask for no head), sizes, cells, tables; at its end
+//      vmcnt(0): the far slots have had a whole tile, the stores most of one — nothing is in flight across the back-edge.
+// Whether a cold codeword needs its tail (more than 6 integers) is read in C from the long-entry bitmap of the LDS image,
+// by the slot value alone, so both requests cross the whole expansion. (Round 3's first version of this, "lean", asked for
+// the tails in the middle of B and drained everything at B's end, with a front end of its own: 4 % slower than this.)
+// MEASURED (profiles/r04_v4_ab.txt, 1e9 postings, same process): 1.675 ms against decode_segment's 1.668 — the waits are
+// gone from the wave and the kernel is no faster: it is bound by what the CU's waves share, not by what one
+// wave waits for. Off by default (DINT_LEAN_SEGMENT=2 selects it; it costs the image 8 KB for the bitmap).
+// A codeword of 15 or 16 integers that is cold (three staging cells) is written by slow_stores here: its last two
+// integers would be a third request per slot.
+struct tail_regs {
+    u32x4 q[kSPL];   // integers 6..13
+    uint32_t w[kSPL];  // integers 14 and 15
+};
+// all but the `keep` youngest vector-memory operations of this wave are done (keep <= 9; more: a longer wait)
+__device__ __forceinline__ void wait_vmcnt_all_but(uint32_t keep, head_regs& hr, tail_regs& tr) {
     asm volatile(
-        "s_cmp_ge_u32 %4, 4\n\t"
-        "s_cbranch_scc0 .Ldint_w3_%=\n\t"
+        "s_cmp_lt_u32 %12, 4\n\t"
+        "s_cbranch_scc1 .Ldv4_lo_%=\n\t"
+        "s_cmp_lt_u32 %12, 6\n\t"
+        "s_cbranch_scc1 .Ldv4_45_%=\n\t"
+        "s_cmp_lt_u32 %12, 8\n\t"
+        "s_cbranch_scc1 .Ldv4_67_%=\n\t"
+        "s_cmp_eq_u32 %12, 8\n\t"
+        "s_cbranch_scc1 .Ldv4_8_%=\n\t"
+        "s_waitcnt vmcnt(9)\n\t"
+        "s_branch .Ldv4_e_%=\n"
+        ".Ldv4_8_%=:\n\t"
+        "s_waitcnt vmcnt(8)\n\t"
+        "s_branch .Ldv4_e_%=\n"
+        ".Ldv4_67_%=:\n\t"
+        "s_cmp_eq_u32 %12, 6\n\t"
+        "s_cbranch_scc1 .Ldv4_6_%=\n\t"
+        "s_waitcnt vmcnt(7)\n\t"
+        "s_branch .Ldv4_e_%=\n"
+        ".Ldv4_6_%=:\n\t"
+        "s_waitcnt vmcnt(6)\n\t"
+        "s_branch .Ldv4_e_%=\n"
+        ".Ldv4_45_%=:\n\t"
+        "s_cmp_eq_u32 %12, 4\n\t"
+        "s_cbranch_scc1 .Ldv4_4_%=\n\t"
         "s_waitcnt vmcnt(5)\n\t"
-        "s_branch .Ldint_we_%=\n"
-        ".Ldint_w3_%=:\n\t"
-        "s_cmp_eq_u32 %4, 3\n\t"
-        "s_cbranch_scc0 .Ldint_w2_%=\n\t"
+        "s_branch .Ldv4_e_%=\n"
+        ".Ldv4_4_%=:\n\t"
         "s_waitcnt vmcnt(4)\n\t"
-        "s_branch .Ldint_we_%=\n"
-        ".Ldint_w2_%=:\n\t"
-        "s_cmp_eq_u32 %4, 2\n\t"
-        "s_cbranch_scc0 .Ldint_w1_%=\n\t"
+        "s_branch .Ldv4_e_%=\n"
+        ".Ldv4_lo_%=:\n\t"
+        "s_cmp_lt_u32 %12, 2\n\t"
+        "s_cbranch_scc1 .Ldv4_01_%=\n\t"
+        "s_cmp_eq_u32 %12, 2\n\t"
+        "s_cbranch_scc1 .Ldv4_2_%=\n\t"
         "s_waitcnt vmcnt(3)\n\t"
-        "s_branch .Ldint_we_%=\n"
-        ".Ldint_w1_%=:\n\t"
-        "s_cmp_eq_u32 %4, 1\n\t"
-        "s_cbranch_scc0 .Ldint_w0_%=\n\t"
+        "s_branch .Ldv4_e_%=\n"
+        ".Ldv4_2_%=:\n\t"
         "s_waitcnt vmcnt(2)\n\t"
-        "s_branch .Ldint_we_%=\n"
-        ".Ldint_w0_%=:\n\t"
+        "s_branch .Ldv4_e_%=\n"
+        ".Ldv4_01_%=:\n\t"
+        "s_cmp_eq_u32 %12, 1\n\t"
+        "s_cbranch_scc1 .Ldv4_1_%=\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "s_branch .Ldv4_e_%=\n"
+        ".Ldv4_1_%=:\n\t"
         "s_waitcnt vmcnt(1)\n"
-        ".Ldint_we_%=:"
-        : "+v"(hr.q[0]), "+v"(hr.q[1]), "+v"(hr.q[2]), "+v"(hr.q[3])
-        : "s"(stores)
+        ".Ldv4_e_%=:"
+        : "+v"(hr.q[0]), "+v"(hr.q[1]), "+v"(hr.q[2]), "+v"(hr.q[3]), "+v"(tr.q[0]), "+v"(tr.q[1]), "+v"(tr.q[2]), "+v"(tr.q[3]),
+          "+v"(tr.w[0]), "+v"(tr.w[1]), "+v"(tr.w[2]), "+v"(tr.w[3])
+        : "s"(keep)
         : "scc", "memory");
 }
 
 template <uint32_t ROUNDS, uint32_t GROUPS>
-__device__ __forceinline__ uint64_t decode_segment_lean(const decode_args& a, const wave_ctx& c, const dict_desc& dd, uint64_t in_off,
-                                                        uint32_t n, uint32_t* const out, prof_t& pf) {
+__device__ __forceinline__ uint64_t decode_segment_v4(const decode_args& a, const wave_ctx& c, const dict_desc& dd, uint64_t in_off,
+                                                      uint32_t n, uint32_t* const out, prof_t& pf) {
     SECTION(pf, 11, "segment_prologue");
     constexpr uint32_t kCap = ROUNDS * GROUPS * 256;
     constexpr uint32_t kTileBytes = 2 * kTileSlots;
@@ -1159,65 +1198,59 @@ __device__ __forceinline__ uint64_t decode_segment_lean(const decode_args& a, co
     uint8_t* const fw = reinterpret_cast<uint8_t*>(fw_of(c.scratch));
     uint8_t* const delta = reinterpret_cast<uint8_t*>(delta_of(c.scratch));
     const uint32_t stage_byte0 = uint32_t(reinterpret_cast<const uint8_t*>(stage_of(c.scratch)) - lds_rw);
+    const uint32_t* const long_bits = c.lds + a.dict.long_bitmap_word;
     const uint64_t in_off_u = uniform64(in_off);
-    // the stream from this segment's first byte on (a segment's bytes are far below 2 GB: at most 6 per integer)
     const uint64_t seg_room = in_off_u <= a.enc_bytes ? a.enc_bytes - in_off_u : 0;
     const __amdgpu_buffer_rsrc_t rs_seg = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint8_t*>(a.enc) + (in_off_u <= a.enc_bytes ? in_off_u : a.enc_bytes), 0,
         int(seg_room < 0x7FFFFFF0ull ? uint32_t(seg_room) : 0x7FFFFFF0u), 0x00020000);
-    // a tile's slots, 8 bytes a lane: ONE buffer load whose result nobody looks at until a counted wait says so. A tile
-    // that is not wholly inside the buffer (the stream's last ones) reads zeros for the dwords past the end — the
-    // descriptor clips per dword — and is loaded again, exactly, behind that wait (fix_slots: load_lane_slots, which
-    // waits on the spot; one definition in flight, the other after it: no copy of a register a load is writing)
     auto whole = [&](uint64_t tile_byte) { return tile_byte <= a.enc_bytes && a.enc_bytes - tile_byte >= kTileBytes; };  // wave-uniform
     auto issue_slots = [&](u32x2& raw, uint64_t tile_byte) { issue_b64(raw, rs_seg, uint32_t(tile_byte - in_off_u) + 8 * lane); };
+    // A tile that is not wholly inside the buffer (the stream's last ones) reads zeros for the dwords past the end — the
+    // descriptor clips per dword — and is read again, exactly, by load_lane_slots: compiler-tracked loads, waited for on the
+    // spot. Every call sits right behind a wait for everything in flight, so the wait the compiler adds costs nothing.
     auto fix_slots = [&](u32x2& raw, uint64_t tile_byte) {
         if (__builtin_expect(!whole(tile_byte), 0)) {
-            // (three ALIGNED dwords around the lane's 8 bytes — a buffer load's offset must be dword-aligned — from a
-            // descriptor that starts on a dword boundary at or below the buffer's last 2 GB and ends on the one at or above
-            // its end: a dword that holds a valid byte is read whole (it cannot cross a page), what lies past the
-            // buffer's end is masked off, a dword wholly past it reads as zero. Loads and their wait in ONE asm: a load
-            // the compiler keeps books on would make it wait for "everything" at unrelated places of the loop. Only the
-            // stream's last tiles come here.)
-            const uint64_t enc_addr = reinterpret_cast<uint64_t>(a.enc);
-            const uint64_t tail0 = a.enc_bytes > 0x7FFFF000ull ? a.enc_bytes - 0x7FFFF000ull : 0;
-            const uint64_t base_al = (enc_addr + tail0) & ~3ull;                      // descriptor base, dword-aligned
-            const uint32_t lead = uint32_t((enc_addr + tail0) - base_al);             // 0..3 bytes in front of the window
-            const uint32_t span = (lead + uint32_t(a.enc_bytes - tail0) + 3u) & ~3u;  // window bytes, whole dwords
-            const __amdgpu_buffer_rsrc_t rs_tail = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(base_al), 0, int(span), 0x00020000);
-            const uint64_t byte_off = tile_byte + 8ull * lane;  // (a tile starts at most 3 tiles past the end)
-            const uint64_t rel64 = byte_off - tail0 + lead;
-            const uint32_t rel = rel64 < 0x7FFFFFE0ull ? uint32_t(rel64) : 0x7FFFFFE0u;
-            const uint32_t dw = rel & ~3u;
-            uint32_t w0, w1, w2;
-            asm volatile(
-                "buffer_load_dword %0, %3, %4, 0 offen\n\t"
-                "buffer_load_dword %1, %3, %4, 0 offen offset:4\n\t"
-                "buffer_load_dword %2, %3, %4, 0 offen offset:8\n\t"
-                "s_waitcnt vmcnt(0)"
-                : "=&v"(w0), "=&v"(w1), "=&v"(w2)
-                : "v"(dw), "s"(rs_tail)
-                : "memory");
-            const uint32_t sh = rel & 3u;
-            uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, sh), hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
-            // bytes of this lane that lie inside the buffer: 0..8
-            const uint64_t left = byte_off < a.enc_bytes ? a.enc_bytes - byte_off : 0;
-            const uint32_t vb = left < 8 ? uint32_t(left) : 8u;
-            lo = vb >= 4 ? lo : (vb == 0 ? 0u : lo & ((1u << (8 * vb)) - 1u));
-            hi = vb >= 8 ? hi : (vb <= 4 ? 0u : hi & ((1u << (8 * (vb - 4))) - 1u));
-            raw.x = lo, raw.y = hi;
+            const uint64_t q = load_lane_slots(false, a.enc, tile_byte, lane, a.enc_bytes);
+            raw.x = uint32_t(q), raw.y = uint32_t(q >> 32);
         }
     };
-    auto issue_heads = [&](const u32x2& raw, head_regs& hr) {
+    auto slot_of = [](const u32x2& raw, uint32_t k) { return ((k < 2 ? raw.x : raw.y) >> (16 * (k & 1))) & 0xFFFFu; };
+    // classification of a tile's slots (decode_segment): its row per lane, the carry it hands on, what kind of tile it is
+    struct tile_class {
+        uint32_t row;
+        uint32_t carry_out;
+        bool special, tile_exc;
+    };
+    auto classify = [&](const u32x2& raw, uint32_t carry_in) -> tile_class {
+        tile_class k{kPlainRow, 0u, false, false};
+        uint32_t sv[kSPL];
 #pragma unroll
-        for (uint32_t k = 0; k != kSPL; ++k) {
-            const uint32_t sv = ((k < 2 ? raw.x : raw.y) >> (16 * (k & 1))) & 0xFFFFu;
-            if (sv >= hot_k) issue_b128(hr.q[k], c.rs_dict, c.heads_base + 16 * (meta_base + sv));
+        for (uint32_t j = 0; j != kSPL; ++j) sv[j] = slot_of(raw, j);
+        uint32_t smin = sv[0];
+#pragma unroll
+        for (uint32_t j = 1; j != kSPL; ++j) smin = smin < sv[j] ? smin : sv[j];
+        k.special = __builtin_expect(__ballot(smin < 2) != 0 || carry_in != 0, 0);
+        if (k.special) {
+            uint32_t lo = 0;
+#pragma unroll
+            for (uint32_t j = kSPL; j-- != 0;) lo = 3 * lo + (2u - (sv[j] < 2 ? sv[j] : 2u));
+            uint32_t st_in = lane == 0 ? carry_in : 0u;
+            uint32_t row;
+            for (;;) {
+                row = rows[st_in * 81 + lo];
+                uint32_t prev = from_lane_below((row >> 8) & 7u);
+                if (lane == 0) prev = carry_in;
+                if (__ballot(prev != st_in) == 0) break;
+                st_in = prev;
+            }
+            k.row = row;
+            k.carry_out = readlane((row >> 8) & 7u, 63);
+            k.tile_exc = __ballot((row & 0xF0u) != 0) != 0;
         }
+        return k;
     };
 
-    // slots of the tile whose front end runs next (A), of the one after (B), of the one after that (C: in flight
-    // from phase C of an iteration to the vmcnt(0) of the next one's phase B)
     u32x2 rawA, rawB;
     uint64_t slot_byte = in_off_u;  // first byte of the tile whose slots were requested last (wave-uniform)
     issue_slots(rawA, slot_byte);
@@ -1226,25 +1259,56 @@ __device__ __forceinline__ uint64_t decode_segment_lean(const decode_args& a, co
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(rawA), "+v"(rawB) : : "memory");
     fix_slots(rawA, in_off_u);
     fix_slots(rawB, slot_byte);
+    tile_class kc = classify(rawA, 0u);
 
-    uint32_t produced = 0, carry = 0, end_slot = 0;
+    uint32_t produced = 0, end_slot = 0;
     uint64_t tile_base = in_off_u;  // byte offset of slot 0 of the tile in the front end (wave-uniform)
     bool pending = false;           // a tile's tables are built, its expansion is due
     uint32_t pend_total = 0, pend_out = 0;
     bool more = true;
     MARK("loop_top");
     for (;;) {
-        // ---- C: behind the previous tile's last wait — this tile's heads (its slots: rawA), the slots two tiles on ----
+        // ---- C: this tile's heads and tails, the slots two tiles on -------------------------------------------------
         head_regs hr;   // (deliberately uninitialised: each register is written and read under the same lane predicate)
-        uint32_t t3[kSPL];
+        tail_regs tr;
         u32x2 rawC;
+        uint32_t loads = 0;  // vector-memory loads this C issued (wave-uniform): the slots' and one per slot position that has any
         if (more) {
             SECTION(pf, 3, "3_prefetch");
-            issue_heads(rawA, hr);
+            uint32_t sv[kSPL];
+            bool cold[kSPL];
+#pragma unroll
+            for (uint32_t k = 0; k != kSPL; ++k) {
+                sv[k] = slot_of(rawA, k);
+                cold[k] = sv[k] >= hot_k && ((kc.row >> k) & 1u) == 0;  // (a payload slot asks for nothing)
+            }
+#pragma unroll
+            for (uint32_t k = 0; k != kSPL; ++k) {
+                if (__ballot(cold[k]) != 0) {  // wave-uniform: the count below is exact
+                    if (cold[k]) issue_b128(hr.q[k], c.rs_dict, c.heads_base + 16 * (meta_base + sv[k]));
+                    ++loads;
+                }
+            }
+            // which of the cold codewords have a tail: one bit per codeword in the image
+            uint32_t bw[kSPL];
+#pragma unroll
+            for (uint32_t k = 0; k != kSPL; ++k) bw[k] = long_bits[sv[k] >> 5];
+#pragma unroll
+            for (uint32_t k = 0; k != kSPL; ++k) {
+                const bool lng = cold[k] && ((bw[k] >> (sv[k] & 31u)) & 1u) != 0;
+                if (__ballot(lng) != 0) {
+                    // (integers 6..13, and 14..15 — the same 64-byte line: the second request rides on the first's)
+                    if (lng) {
+                        issue_b128(tr.q[k], c.rs_dict, c.tails_base + 32 * (meta_base + sv[k]));
+                        issue_b32(tr.w[k], c.rs_dict, c.tails_base + 32 * (meta_base + sv[k]), 16);
+                    }
+                    loads += 2;
+                }
+            }
             slot_byte += kTileBytes;
             issue_slots(rawC, slot_byte);
         }
-        // ---- A: expansion of the tile whose tables phase B built -------------------------------------------------
+        // ---- A: expansion of the tile whose tables phase B built ---------------------------------------------------
         uint32_t stores = 0;
         if (pending) {
             SECTION(pf, 9, "9_expand");
@@ -1256,105 +1320,115 @@ __device__ __forceinline__ uint64_t decode_segment_lean(const decode_args& a, co
         }
         if (!more) break;
 
-        // ---- B: front end of the next tile ---------------------------------------------------------------------
+        // ---- B: front end of the tile ------------------------------------------------------------------------------
         SECTION(pf, 1, "1_classify");
         tile_regs cur;
-        cur.s[0] = rawA.x & 0xFFFFu, cur.s[1] = rawA.x >> 16, cur.s[2] = rawA.y & 0xFFFFu, cur.s[3] = rawA.y >> 16;
+#pragma unroll
+        for (uint32_t k = 0; k != kSPL; ++k) cur.s[k] = slot_of(rawA, k);
         meta_regs mr;
 #pragma unroll
         for (uint32_t k = 0; k != kSPL; ++k) mr.h[k] = c.lds[hot_base + (cur.s[k] < hot_k ? cur.s[k] : hot_k)];
-        // the heads are there: all but the slots requested behind them and this iteration's stores may stay in flight
-        // (fewer than counted is only a longer wait)
-        wait_for_heads(hr, uniform(stores));
+        // heads and tails are there: the slots requested behind them and this iteration's stores may stay in flight
+        wait_vmcnt_all_but(uniform(stores) + 1u, hr, tr);
+        (void)loads;
 #pragma unroll
         for (uint32_t k = 0; k != kSPL; ++k) cur.m[k] = cur.s[k] < hot_k ? mr.h[k] : hr.q[k].x;
-        // ---- classification: table lookup, repeated until the lane-to-lane carries agree (decode_segment, step 1) ----
-        const bool tile_slow_dict = __ballot(((cur.m[0] | cur.m[1] | cur.m[2] | cur.m[3]) & kMetaSlow) != 0) != 0;
-        uint32_t row;
-        {
-            uint32_t lo = 0;
-#pragma unroll
-            for (uint32_t k = kSPL; k-- != 0;) lo = 3 * lo + (2u - (cur.s[k] < 2 ? cur.s[k] : 2u));
-            uint32_t st_in = lane == 0 ? carry : 0u;
-            for (;;) {
-                row = rows[st_in * 81 + lo];
-                uint32_t prev = from_lane_below((row >> 8) & 7u);
-                if (lane == 0) prev = carry;
-                if (__ballot(prev != st_in) == 0) break;
-                st_in = prev;
-            }
-        }
-        const uint32_t carry_out = readlane((row >> 8) & 7u, 63);
+        const bool special = kc.special;
+        const uint32_t row = kc.row;
+        const uint32_t carry_out = kc.carry_out;
+        const bool tile_exc = kc.tile_exc;
 
         SECTION(pf, 2, "2_sizes");
         tile_slots t;
-        uint32_t e[kSPL];  // size - 1
-        uint32_t excval[kSPL];
-        {
-            // the literal behind an exception header: the next slot, or the next two (the lane's own, the next lane's
-            // first two, the next tile's first two for lane 63 — read with every lane enabled)
-            const uint32_t next0 = readlane(rawB.x, 0);
-            uint32_t nlo = from_lane_above(rawA.x);
-            if (lane == 63) nlo = next0;
-            uint32_t v[kSPL + 2];
+        uint32_t lv1[kSPL] = {1u, 1u, 1u, 1u};
+        if (special) {
 #pragma unroll
-            for (uint32_t k = 0; k != kSPL; ++k) v[k] = cur.s[k];
-            v[kSPL] = nlo & 0xFFFFu;
-            v[kSPL + 1] = nlo >> 16;
-#pragma unroll
-            for (uint32_t k = 0; k != kSPL; ++k) excval[k] = v[k] == 0 ? v[k + 1] : (v[k + 1] | (v[k + 2] << 16));
+            for (uint32_t k = 0; k != kSPL; ++k) {
+                cur.m[k] &= uint32_t(__builtin_amdgcn_sbfe(~row, k, 1));
+                lv1[k] = __builtin_amdgcn_ubfe(~row, k, 1);
+            }
         }
+        const bool tile_slow_dict = __ballot(((cur.m[0] | cur.m[1] | cur.m[2] | cur.m[3]) & kMetaSlow) != 0) != 0;
+        uint32_t e[kSPL];  // size - 1
 #pragma unroll
         for (uint32_t k = 0; k != kSPL; ++k) {
-            const bool pay = ((row >> k) & 1u) != 0, exc = ((row >> (4 + k)) & 1u) != 0;
-            e[k] = pay ? ~0u : (exc ? 0u : cur.m[k] >> 24);  // payload slots decode to nothing and take nothing
-            t.need[k] = pay ? 0u : (exc ? 1u : __builtin_amdgcn_ubfe(cur.m[k], 20, 2));
-            t.src2[k] = cur.m[k] & kMetaOffMask;  // hot: the image (runs: the zeros); cold, slow: zero for now
+            e[k] = cur.m[k] >> 24;
+            t.need[k] = __builtin_amdgcn_ubfe(cur.m[k], 20, 2);
+            t.src2[k] = cur.m[k] & kMetaOffMask;
+        }
+        bool wide[kSPL] = {false, false, false, false};
+        if (tile_exc) {  // the literals ride into their cells in the second word of the slots' head registers (decode_segment)
+            const uint32_t p01 = rawA.x, p23 = rawA.y;
+            const uint32_t next0 = readlane(rawB.x, 0);
+            uint32_t nlo = from_lane_above(p01);
+            if (lane == 63) nlo = next0;
+            uint32_t w32[kSPL];
+            w32[0] = __builtin_amdgcn_alignbit(p23, p01, 16);
+            w32[1] = p23;
+            w32[2] = __builtin_amdgcn_alignbit(nlo, p23, 16);
+            w32[3] = nlo;
+#pragma unroll
+            for (uint32_t k = 0; k != kSPL; ++k) {
+                const uint32_t excM = uint32_t(__builtin_amdgcn_sbfe(row, 4 + k, 1));
+                const uint32_t lit = w32[k] & ((0u - cur.s[k]) | 0xFFFFu) & excM;
+                hr.q[k].y = (hr.q[k].y & ~excM) | lit;
+                wide[k] = lit > 0xFFFFu;
+            }
         }
         t.off[0] = 0;
-        t.off[1] = e[0] + 1u;
-        t.off[2] = t.off[1] + e[1] + 1u;
-        t.off[3] = t.off[2] + e[2] + 1u;
-        t.lsum = t.off[3] + e[3] + 1u;
-        const uint32_t hdrcnt = uint32_t(__builtin_popcount(~row & 15u));
-        const uint32_t mine = (hdrcnt << 24) | t.lsum;
-        const uint32_t pincl = wave_inclusive_sum(mine);
-        t.obase = (pincl & 0xFFFFFFu) - t.lsum;  // first output of this lane's codewords
+        t.off[1] = e[0] + lv1[0];
+        t.off[2] = t.off[1] + e[1] + lv1[1];
+        t.off[3] = t.off[2] + e[2] + lv1[2];
+        t.lsum = t.off[3] + e[3] + lv1[3];
+        uint32_t hdrcnt = 4;
+        uint32_t pincl;
+        if (special) {
+            hdrcnt = uint32_t(__builtin_popcount(~row & 15u));
+            pincl = wave_inclusive_sum((hdrcnt << 24) | t.lsum);
+        } else {
+            pincl = wave_inclusive_sum(t.lsum);
+        }
+        t.obase = (pincl & 0xFFFFFFu) - t.lsum;
         const uint32_t remaining = n - produced;
         t.total = readlane(pincl, 63) & 0xFFFFFFu;
         const bool last_tile = t.total >= remaining;
-        t.row = row;
-        t.liveb = ~row & 15u;
-        t.rbase = (pincl - mine) >> 24;  // ordinal of this lane's first codeword (exclusive before the shift: the inclusive count can be 256)
-        t.nlive = hdrcnt;
+        const bool plain = !special && !last_tile && t.total <= kCap;
         uint32_t slowb = 0;  // bit k: slot k goes through slow_stores
-        if (last_tile) {     // last tile of the segment: clamp, and find where the stream ends (decode_segment)
-            t.total = remaining;
-            uint32_t cand = 0, lb = 0;
-            t.nlive = 0;
+        if (!plain) {
+            t.row = row;
+            t.liveb = ~row & 15u;
+            t.rbase = special ? (pincl - ((hdrcnt << 24) | t.lsum)) >> 24 : 4 * lane;
+            t.nlive = hdrcnt;
+            if (last_tile) {
+                t.total = remaining;
+                uint32_t cand = 0, lb = 0;
+                t.nlive = 0;
 #pragma unroll
-            for (uint32_t k = 0; k != kSPL; ++k) {
-                const uint32_t pos = t.obase + t.off[k];
-                const bool act = ((t.liveb >> k) & 1u) != 0 && pos < remaining;
-                if (act) {
-                    const bool exc = ((row >> (4 + k)) & 1u) != 0;
-                    cand = kSPL * lane + k + 1 + (exc ? cur.s[k] + 1 : 0u);
-                    ++t.nlive;
-                    lb |= 1u << k;
-                } else {
-                    t.need[k] = 0;
+                for (uint32_t k = 0; k != kSPL; ++k) {
+                    const uint32_t pos = t.obase + t.off[k];
+                    const bool act = ((t.liveb >> k) & 1u) != 0 && pos < remaining;
+                    if (act) {
+                        const bool exc = ((row >> (4 + k)) & 1u) != 0;
+                        cand = kSPL * lane + k + 1 + (exc ? cur.s[k] + 1 : 0u);
+                        ++t.nlive;
+                        lb |= 1u << k;
+                    } else {
+                        t.need[k] = 0;
+                    }
                 }
+                t.liveb = lb;
+                t.lsum = t.obase < remaining ? (t.obase + t.lsum < remaining ? t.lsum : remaining - t.obase) : 0u;
+                const uint64_t am = __ballot(cand != 0);
+                end_slot = readlane(cand, 63u - uint32_t(__builtin_clzll(am | 1ull)));
             }
-            t.liveb = lb;
-            t.lsum = t.obase < remaining ? (t.obase + t.lsum < remaining ? t.lsum : remaining - t.obase) : 0u;
-            const uint64_t am = __ballot(cand != 0);
-            end_slot = readlane(cand, 63u - uint32_t(__builtin_clzll(am | 1ull)));
-        }
-        if (tile_slow_dict) {
+            if (tile_slow_dict) {
 #pragma unroll
-            for (uint32_t k = 0; k != kSPL; ++k) slowb |= ((cur.m[k] >> 22) & (t.liveb >> k) & ~(row >> (4 + k)) & 1u) << k;
+                for (uint32_t k = 0; k != kSPL; ++k) slowb |= ((cur.m[k] >> 22) & (t.liveb >> k) & ~(row >> (4 + k)) & 1u) << k;
+            }
+        } else if (tile_slow_dict) {
+#pragma unroll
+            for (uint32_t k = 0; k != kSPL; ++k) slowb |= ((cur.m[k] >> 22) & 1u) << k;
         }
-        // ---- staging cells: exception literals and cold codewords ----------------------------------------------
         uint32_t cell_addr[kSPL];
         const uint32_t cells = allocate_cells(t, stage_byte0, cell_addr);
         if (cells > kStageCells) {  // wave-uniform; what lies past the staging area turns slow: zeros, then slow_stores
@@ -1367,72 +1441,54 @@ __device__ __forceinline__ uint64_t decode_segment_lean(const decode_args& a, co
         }
 #pragma unroll
         for (uint32_t k = 0; k != kSPL; ++k) t.src2[k] = t.need[k] != 0 ? cell_addr[k] : t.src2[k];
-#pragma unroll
-        for (uint32_t k = 0; k != kSPL; ++k)
-            if (((row >> (4 + k)) & 1u) != 0 && t.need[k] != 0) {  // an exception's literal into its cell, 32 bits
-                *reinterpret_cast<uint32_t*>(lds_rw + cell_addr[k]) = excval[k];
-                t.src2[k] |= excval[k] > 0xFFFFu ? 1u : 0u;
-                t.need[k] = 0;  // (no row lands there)
-            }
         const bool tile_slow = __ballot(slowb != 0) != 0;
         const bool tile_big = __ballot((t.need[0] | t.need[1] | t.need[2] | t.need[3]) > 1u) != 0;
         SECTION(pf, 8, "8_wait");
-        // the heads of this tile's cold codewords into their cells (the integers start 4 bytes in); the tails of the
-        // large ones requested: integers 6..13 into the same registers, 14 and 15 into one more each
+        // heads (the integers start 4 bytes into a cell) and tails (integers 6..13 behind them) into their cells
 #pragma unroll
         for (uint32_t k = 0; k != kSPL; ++k)
             if (t.need[k] != 0) {
                 *reinterpret_cast<u32x4*>(lds_rw + t.src2[k]) = hr.q[k];
-                t.src2[k] += 4;
+                t.src2[k] += 4u + (wide[k] ? 1u : 0u);
             }
         if (tile_big) {
 #pragma unroll
             for (uint32_t k = 0; k != kSPL; ++k) {
-                const uint32_t tail = c.tails_base + 32 * (meta_base + cur.s[k]);
-                if (t.need[k] > 1u) reissue_b128(hr.q[k], c.rs_dict, tail);
-                if (t.need[k] > 2u) issue_b32(t3[k], c.rs_dict, tail, 16);
+                if (t.need[k] > 1u) *reinterpret_cast<u32x4*>(lds_rw + t.src2[k] + 12) = tr.q[k];
+                if (t.need[k] > 2u) *reinterpret_cast<uint32_t*>(lds_rw + t.src2[k] + 28) = tr.w[k];
             }
         }
-        auto land_tails = [&]() {
-            // everything in flight is there: the tails, and — older — the far slots and the previous tile's stores
-            asm volatile("s_waitcnt vmcnt(0)"
-                         : "+v"(hr.q[0]), "+v"(hr.q[1]), "+v"(hr.q[2]), "+v"(hr.q[3]), "+v"(t3[0]), "+v"(t3[1]), "+v"(t3[2]), "+v"(t3[3]), "+v"(rawC)
-                         :
-                         : "memory");
-            if (tile_big) {
-#pragma unroll
-                for (uint32_t k = 0; k != kSPL; ++k) {
-                    if (t.need[k] > 1u) *reinterpret_cast<u32x4*>(lds_rw + t.src2[k] + 12) = hr.q[k];
-                    if (t.need[k] > 2u) *reinterpret_cast<uint32_t*>(lds_rw + t.src2[k] + 28) = t3[k];
-                }
-            }
-            wave_lds_fence();
-        };
         SECTION(pf, 4, "4_tables");
         const bool one_batch = !tile_slow && t.total <= kCap;  // wave-uniform
         if (__builtin_expect(one_batch, 1)) {
-            tables_general(t, fw, delta, t.lsum != 0, 0u, 0u, lane);
+            if (plain) tables_plain(t, fw, delta, lane);
+            else tables_general(t, fw, delta, t.lsum != 0, 0u, 0u, lane);
             wave_lds_fence();
-        }
-        SECTION(pf, 7, "7_rows2");
-        land_tails();
-        if (__builtin_expect(one_batch, 1)) {
             pending = true;
             pend_total = t.total;
             pend_out = produced;
         } else {
             // more than one expansion batch (a tile full of long runs), or a slow codeword: finished here, the old way
-            expand_tile<ROUNDS, GROUPS>(t, false, true, 0u, nullptr, produced, c.lds, c.scratch, rs_out, lane, pf, []() {});
+            wave_lds_fence();
+            expand_tile<ROUNDS, GROUPS>(t, plain, true, 0u, nullptr, produced, c.lds, c.scratch, rs_out, lane, pf, []() {});
             SECTION(pf, 10, "10_tail");
-            if (tile_slow) slow_stores_lean(c, t, slowb, produced, n, cur.s, excval, hot_base, hot_k, meta_base, rs_out);
+            if (tile_slow) {
+                uint32_t lit[kSPL];
+#pragma unroll
+                for (uint32_t k = 0; k != kSPL; ++k) lit[k] = hr.q[k].y;  // (an exception's literal rode in here)
+                slow_stores_lean(c, t, slowb, produced, n, cur.s, lit, hot_base, hot_k, meta_base, rs_out);
+            }
         }
         SECTION(pf, 5, "10_rotate");
         produced += t.total;
-        carry = carry_out;
         more = produced < n;
-        if (more) tile_base += kTileBytes;
-
-        if (more) {  // (phase C's slots are there: land_tails waited for everything)
+        if (more) {
+            tile_base += kTileBytes;
+            kc = classify(rawB, carry_out);
+        }
+        // everything in flight is there: the far slots (a tile old) and the previous tile's stores (most of a tile old)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rawC) : : "memory");
+        if (more) {
             fix_slots(rawC, slot_byte);
             rawA = rawB;
             rawB = rawC;
@@ -1446,7 +1502,7 @@ __device__ __forceinline__ uint64_t decode_segment_lean(const decode_args& a, co
 // only the dictionary source layout differed on the host) is one 16-bit segment.
 // (Chaining such units like the blocks of a multi-dictionary unit — the next unit's first tiles
 // requested while the current one is expanded — was measured in round 1: 5 % slower.)
-template <bool LEAN>
+template <int LEAN>  // 0: decode_segment; 2: decode_segment_v4 (the vroom kernel only)
 __device__ __forceinline__ void decode_unit_single(const decode_args& a, const wave_ctx& c, uint64_t unit_index, prof_t& pf) {
     const dint_unit* up = a.units + unit_index;
     const uint64_t out_off = up->out_off;
@@ -1454,7 +1510,7 @@ __device__ __forceinline__ void decode_unit_single(const decode_args& a, const w
     if (n == 0 || n > kMaxUnitInts || out_off > a.out_capacity || a.out_capacity - out_off < n || (a.only_full && n != 256)) return;
     const uint64_t in_off = uniform64(up->in_off);
     if (LEAN) {  // (the vroom kernel: plain d-gaps)
-        const uint64_t end = decode_segment_lean<kRounds, kGroups>(a, c, a.dict.first, in_off, n, a.out + out_off, pf);
+        const uint64_t end = decode_segment_v4<kRounds, kGroups>(a, c, a.dict.first, in_off, n, a.out + out_off, pf);
         if (a.end_off && c.lane == 0) a.end_off[unit_index] = end;
         return;
     }
@@ -2262,6 +2318,7 @@ __device__ __forceinline__ decode_args own_scalars(const decode_args& k) {
     asm volatile("" : "+s"(a.dict.tables), "+s"(a.dict.lds_image), "+s"(a.dict.descs), "+s"(a.dict.tables_bytes),
                  "+s"(a.dict.heads_base), "+s"(a.dict.tails_base), "+s"(a.dict.goff_base), "+s"(a.dict.gtable_base), "+s"(a.dict.hot_words),
                  "+s"(a.dict.first.meta_base), "+s"(a.dict.first.hot_base), "+s"(a.dict.first.hot_k));
+    if (DINT_LEAN_SEGMENT == 2) asm volatile("" : "+s"(a.dict.long_bitmap_word));
     asm volatile("" : "+s"(a.enc), "+s"(a.enc_bytes), "+s"(a.units), "+s"(a.n_units), "+s"(a.out),
                  "+s"(a.out_capacity), "+s"(a.end_off), "+s"(a.queue), "+s"(a.n_shards), "+s"(a.only_full));
     asm volatile("" : "+s"(a.sched), "+s"(a.items), "+s"(a.item_cnt), "+s"(a.n_items), "+s"(a.urec), "+s"(a.cbase), "+s"(a.chunk_queue), "+s"(a.spans),
@@ -2392,7 +2449,7 @@ __device__ __forceinline__ void decode_kernel_body(const decode_args& kernarg, c
         } else {
             const uint32_t cc = uniform(a.sched ? uint32_t(a.item_cnt[w]) : 1u);
             if (__builtin_expect(cc > 1, 0)) decode_bundle_listed<false>(a, c, uu, cc, pf);
-            else decode_unit_single<DINT_LEAN_SEGMENT && !INDEX && !QUERY>(a, c, uu, pf);
+            else decode_unit_single<(!INDEX && !QUERY) ? DINT_LEAN_SEGMENT : 0>(a, c, uu, pf);
         }
         asm volatile("" : "+v"(ticket));
         w = take(ticket);
