@@ -5,7 +5,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step is one pass of the decode kernel over the rank's whole resident
-collection (every unit of every posting list). Inputs (encoded stream, unit
+collection (every unit of every posting list; one GPU, default workload: 5e9
+distinct postings, generated, encoded and uploaded in pieces during set-up). Inputs (encoded stream, unit
 table, dictionary) are in HBM before the timed region starts. Posting lists
 are partitioned statically across ranks, the dictionary is replicated, and
 there is no data-path collective: the only collectives are the dictionary
@@ -35,7 +36,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 WORKLOADS = {
     # config 2 (Gov2-shaped: 25 M documents) and config 4 (ClueWeb09-shaped: 50 M documents,
     # 1e10 postings over 8 GPUs = 1.25e9 per GPU)
-    "gov2": dict(universe=25_000_000, postings=1.0e9, replicate=5),
+    # gov2, one GPU: 5e9 DISTINCT postings (generated and encoded in chunks of --chunk-postings, set-up ~ 1.5 min). With more
+    # ranks the host's cores are shared between them during set-up: 1e9 distinct postings per GPU, decoded x5 from five
+    # device-side copies at distinct addresses — the same integers and bytes per step and GPU.
+    "gov2": dict(universe=25_000_000, postings=5.0e9, replicate=1, multi_rank=dict(postings=1.0e9, replicate=5)),
     "clueweb": dict(universe=50_000_000, postings=1.25e9, replicate=1),
 }
 KERNEL_BY_TYPE = {"single_rect_dint": "decode_single_kernel", "single_packed_dint": "decode_single_kernel",
@@ -49,8 +53,11 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=10)  # (the shader clock is still ramping for the first few launches)
     ap.add_argument("--type", default="single_packed_dint", choices=sorted(KERNEL_BY_TYPE))
     ap.add_argument("--workload", default="gov2", choices=sorted(WORKLOADS),
-                    help="gov2: universe 25M, 1e9 postings encoded per GPU, decoded x5 from distinct addresses (5e9 integers "
-                         "per step: SURVEY §8d config 2); clueweb: universe 50M, 1.25e9 postings per GPU (config 4 at 8 GPUs)")
+                    help="gov2: universe 25M, 5e9 distinct postings encoded per GPU (SURVEY §8d config 2; with --gpus > 1: 1e9 per GPU "
+                         "decoded x5 from distinct addresses); clueweb: universe 50M, 1.25e9 postings per GPU (config 4 at 8 GPUs)")
+    ap.add_argument("--chunk-postings", type=float, default=1.0e9,
+                    help="set-up generates, encodes and uploads the rank's shard in pieces of about this many postings (host memory: "
+                         "one piece at a time)")
     ap.add_argument("--postings", type=float, default=None, help="postings encoded per GPU (weak scaling: fixed per GPU)")
     ap.add_argument("--placement-trials", type=int, default=6,
                     help="candidate output buffers, then candidate stream buffers, allocated during set-up; the pair the decode "
@@ -108,24 +115,8 @@ def launch_ranks(args) -> int:
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=out0 if rank == 0 else subprocess.DEVNULL, start_new_session=True))
-    deadline = time.monotonic() + args.rank_timeout
-    failed = None
-    while failed is None and any(p.poll() is None for p in procs):
-        for rank, p in enumerate(procs):
-            if p.poll() not in (None, 0):
-                failed = f"rank {rank} exited with code {p.returncode}"
-                break
-        else:
-            if time.monotonic() > deadline:
-                failed = f"no result after {args.rank_timeout:.0f}s"
-            else:
-                time.sleep(0.2)
-    if failed is None:
-        bad = [(r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0]
-        if bad:
-            failed = f"rank {bad[0][0]} exited with code {bad[0][1]}"
-    if failed is not None:
-        for p in procs:  # exactly the process groups started above
+    def stop_all():  # exactly the process groups started above
+        for p in procs:
             if p.poll() is None:
                 try:
                     os.killpg(p.pid, signal.SIGTERM)
@@ -141,6 +132,38 @@ def launch_ranks(args) -> int:
                 except ProcessLookupError:
                     pass
                 p.wait()
+
+    # The ranks run in sessions of their own (a rank that hangs in a collective is stopped by process group), so a signal to
+    # THIS process no longer reaches them: SIGTERM / SIGINT here (a `timeout` wrapper, Ctrl-C) stop them first.
+    def on_signal(signum, _frame):
+        stop_all()
+        signal.signal(signum, signal.SIG_DFL)
+        os.kill(os.getpid(), signum)
+
+    old_handlers = {sig: signal.signal(sig, on_signal) for sig in (signal.SIGTERM, signal.SIGINT)}
+    deadline = time.monotonic() + args.rank_timeout
+    failed = None
+    try:
+        while failed is None and any(p.poll() is None for p in procs):
+            for rank, p in enumerate(procs):
+                if p.poll() not in (None, 0):
+                    failed = f"rank {rank} exited with code {p.returncode}"
+                    break
+            else:
+                if time.monotonic() > deadline:
+                    failed = f"no result after {args.rank_timeout:.0f}s"
+                else:
+                    time.sleep(0.2)
+        if failed is None:
+            bad = [(r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0]
+            if bad:
+                failed = f"rank {bad[0][0]} exited with code {bad[0][1]}"
+    finally:
+        if failed is not None or any(p.poll() is None for p in procs):  # (the second: an exception on the way)
+            stop_all()
+        for sig, h in old_handlers.items():
+            signal.signal(sig, h)
+    if failed is not None:
         print(f"[bench] {failed}: all ranks stopped", file=sys.stderr, flush=True)
         return 1
     out0.seek(0)
@@ -228,7 +251,9 @@ def cpu_baseline(kind, dict_file, enc, list_byte_starts, seconds):
 
 def main():
     args = parse_args()
-    w = WORKLOADS[args.workload]
+    w = dict(WORKLOADS[args.workload])
+    if max(args.gpus, int(os.environ.get("WORLD_SIZE", "1"))) > 1 or args.as_rank is not None:
+        w.update(w.get("multi_rank", {}))
     postings = int(args.postings if args.postings is not None else w["postings"])
     R = max(1, args.replicate if args.replicate is not None else w["replicate"])
     universe = args.universe if args.universe is not None else w["universe"]
@@ -293,12 +318,23 @@ def main():
     lens_all = host.synth_lengths(p, postings * shard_world)
     lo, hi = sharding.partition_lists(lens_all, shard_world)[shard_rank]
     lens = lens_all[lo:hi]
-    gaps = host.synth_gaps(p, lens, first_list_id=lo, threads=threads)
-    coll = host.Collection(gaps, lens)
-    log(rank, f"rank shard: lists [{lo},{hi}) = {coll.num_postings} postings, generated in {time.time() - t0:.1f}s")
-    if coll.num_postings == 0:
+    n_shard = int(lens.sum(dtype=np.uint64))
+    if n_shard == 0:
         raise SystemExit(f"shard {shard_rank} of {shard_world} is empty: {postings * shard_world} postings are too few for "
                          f"{shard_world} ranks (the longest list alone holds {int(lens_all.max())})")
+    # pieces of the shard: contiguous list ranges of about --chunk-postings postings. A list's gaps depend on the seed and
+    # the list's ordinal alone (synth_gaps' first_list_id), so the pieces ARE the shard, generated one at a time.
+    cum = np.cumsum(lens, dtype=np.uint64)
+    n_pieces = max(1, int(round(n_shard / max(1.0, args.chunk_postings))))
+    cuts = [0] + [int(np.searchsorted(cum, n_shard * k // n_pieces, side="left")) + 1 for k in range(1, n_pieces)] + [len(lens)]
+    cuts = sorted(set(min(c, len(lens)) for c in cuts))
+
+    def piece(i):
+        a, b = cuts[i], cuts[i + 1]
+        return host.Collection(host.synth_gaps(p, lens[a:b], first_list_id=lo + a, threads=threads), lens[a:b])
+
+    coll0 = piece(0)
+    log(rank, f"rank shard: lists [{lo},{hi}) = {n_shard} postings in {len(cuts) - 1} piece(s); the first generated in {time.time() - t0:.1f}s")
 
     def build_dictionary(sample_of):
         # n-gram counting and selection on the device (byte-identical to the host construction, 7 s -> 0.2 s of set-up)
@@ -311,14 +347,14 @@ def main():
         # --as-rank K/W, K != 0: the job's dictionary comes from RANK 0's first lists, not from this shard's —
         # regenerate that prefix sample (the lists build_dictionary would take from rank 0's shard)
         hi0 = sharding.partition_lists(lens_all, shard_world)[0][1]
-        cum = np.cumsum(lens_all[:hi0], dtype=np.uint64)
-        j = max(1, int(np.searchsorted(cum, int(args.dict_sample), side="right"))) if args.dict_sample else hi0
+        cum0 = np.cumsum(lens_all[:hi0], dtype=np.uint64)
+        j = max(1, int(np.searchsorted(cum0, int(args.dict_sample), side="right"))) if args.dict_sample else hi0
         sample = host.Collection(host.synth_gaps(p, lens_all[:j], first_list_id=0, threads=threads), lens_all[:j])
         dict_file = build_dictionary(sample)
         del sample
     elif rank == 0:
         # dictionary statistics from a prefix sample of the collection (rank 0's first lists)
-        dict_file = build_dictionary(coll)
+        dict_file = build_dictionary(coll0)
     else:
         dict_file = None
     if distributed:
@@ -327,27 +363,56 @@ def main():
         dict_file = box[0]
     log(rank, f"dictionary: {len(dict_file)} B in {time.time() - t0:.1f}s")
 
-    t0 = time.time()
-    enc, units = host.encode_vroom(kind, dict_file, coll, unit_ints=args.unit_ints, threads=threads)
-    bpi = enc.size * 8 / coll.num_postings
-    log(rank, f"encoded: {enc.size} B ({bpi:.3f} bits/int), {len(units)} units in {time.time() - t0:.1f}s")
-
+    # every piece: encode on the host, upload the stream, the unit table (offsets moved to the piece's place in the shard) and
+    # — for the bit-exact check at the end — the gaps themselves (the expected output stays on the device)
     d = device.Dictionary(kind, dict_file, device=local_rank)
     info = d.info()
-    n_ints = coll.num_postings * R
-    enc_one = torch.from_numpy(enc).to(dev)
-    units_all = np.tile(units, R)
+    t0 = time.time()
+    enc_parts, unit_parts, expect_parts = [], [], []
+    enc_bytes_one = ints_done = lists_done = 0
+    enc = units = None  # the FIRST piece's stream and unit table stay on the host: the CPU baseline's sample
+    for i in range(len(cuts) - 1):
+        c = coll0 if i == 0 else piece(i)
+        e_i, u_i = host.encode_vroom(kind, dict_file, c, unit_ints=args.unit_ints, threads=threads)
+        u_i = u_i.copy()
+        if i == 0:
+            enc, units = e_i, u_i.copy()
+        u_i["in_off"] += np.uint64(enc_bytes_one)
+        u_i["out_off"] += np.uint64(ints_done)
+        u_i["list"] += np.uint32(lists_done)
+        enc_parts.append(torch.from_numpy(e_i).to(dev))
+        unit_parts.append(u_i)
+        if not args.no_verify:
+            expect_parts.append(torch.from_numpy(np.ascontiguousarray(c.gaps).view(np.int32)).to(dev))
+        enc_bytes_one += e_i.size
+        ints_done += c.num_postings
+        lists_done += len(c.lens)
+        log(rank, f"piece {i}: {c.num_postings} postings -> {e_i.size} B, {len(u_i)} units ({time.time() - t0:.1f}s)")
+        del c, e_i
+    del coll0
+    assert ints_done == n_shard
+    bpi = enc_bytes_one * 8 / n_shard
+    units_one = np.concatenate(unit_parts)
+    del unit_parts
+    log(rank, f"encoded: {enc_bytes_one} B ({bpi:.3f} bits/int), {len(units_one)} units in {time.time() - t0:.1f}s")
+    expect_dev = torch.cat(expect_parts) if len(expect_parts) > 1 else (expect_parts[0] if expect_parts else None)
+    del expect_parts
+
+    n_ints = n_shard * R
+    enc_one = torch.cat(enc_parts) if len(enc_parts) > 1 else enc_parts[0]
+    del enc_parts
+    units_all = np.tile(units_one, R)
     for r in range(R):
-        sl = slice(r * len(units), (r + 1) * len(units))
-        units_all["in_off"][sl] += np.uint64(r * enc.size)
-        units_all["out_off"][sl] += np.uint64(r * coll.num_postings)
+        sl = slice(r * len(units_one), (r + 1) * len(units_one))
+        units_all["in_off"][sl] += np.uint64(r * enc_bytes_one)
+        units_all["out_off"][sl] += np.uint64(r * n_shard)
     units_dev = device.units_to_device(units_all, dev)
     n_units = len(units_all)
 
     def allocate_stream():
-        e = torch.empty(enc.size * R, dtype=torch.uint8, device=dev)
+        e = torch.empty(enc_bytes_one * R, dtype=torch.uint8, device=dev)
         for r in range(R):
-            e[r * enc.size:(r + 1) * enc.size].copy_(enc_one)
+            e[r * enc_bytes_one:(r + 1) * enc_bytes_one].copy_(enc_one)
         return e
 
     def allocate_output():
@@ -360,7 +425,8 @@ def main():
     # the stream, then a few candidate copies of the stream for the output buffer that won, two launches each; the
     # fastest pair stays, the others are freed before the timed region.
     trials = max(1, args.placement_trials) if dev.type == "cuda" and not os.environ.get("DINT_BENCH_STUB") else 1
-    enc_dev, out_dev = allocate_stream(), allocate_output()
+    enc_dev = allocate_stream() if (R > 1 or trials > 1) else enc_one  # (one copy, no candidates: the uploaded stream itself)
+    out_dev = allocate_output()
     placement_ms = None
 
     def kernel_ms(e, o):
@@ -445,13 +511,14 @@ def main():
     # ---- correctness: bit-exact against the encoder's input -------------------------
     ends = end_dev.cpu().numpy().view(np.uint64)
     payload_bytes = int((ends - units_all["in_off"]).sum())
+    first_alloc_ms = placement_ms["output_buffers"][0] if placement_ms else None
     bit_exact = None
     if not args.no_verify:
         bit_exact = True
-        for r in range(R):  # one replica at a time: the output is 4 bytes x 5e9 at the default size
-            got = out_dev[r * coll.num_postings:(r + 1) * coll.num_postings].cpu().numpy().view(np.uint32)
-            bit_exact = bit_exact and bool(np.array_equal(got, coll.gaps))
-            del got
+        for r in range(R):  # replica by replica, piece-sized slices, on the device (the expected gaps were uploaded during set-up)
+            for a in range(0, n_shard, 1 << 28):
+                b = min(n_shard, a + (1 << 28))
+                bit_exact = bit_exact and bool(torch.equal(out_dev[r * n_shard + a:r * n_shard + b], expect_dev[a:b]))
         if distributed:
             ok = torch.tensor([1 if bit_exact else 0], dtype=torch.int32, device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -500,7 +567,7 @@ def main():
 
     if rank == 0:
         # ---- what the stream is made of (host pre-pass over one replica) -------------
-        st = d.stream_stats(enc)
+        st = d.stream_stats(enc)  # (the first piece of the shard: a sample)
         slots = st.codewords + st.exceptions16 + st.exceptions32
         stream = {
             "ints_per_codeword": round(st.ints / max(1, slots), 3),
@@ -517,7 +584,7 @@ def main():
         if world == 1 and args.cpu_seconds > 0:
             first = np.r_[True, units["list"][1:] != units["list"][:-1]]
             # a list's header starts where the previous list's payload ended
-            prev_end = np.r_[np.uint64(0), ends[: len(units)][np.flatnonzero(np.r_[first[1:], True])][:-1]]
+            prev_end = np.r_[np.uint64(0), ends[: len(units)][np.flatnonzero(np.r_[first[1:], True])][:-1]]  # (the first piece's lists)
             cpu = cpu_baseline(kind, dict_file, enc, prev_end.astype(np.int64), args.cpu_seconds)
 
         algo_bytes = 4 * n_ints + payload_bytes  # per launch, this rank
@@ -544,6 +611,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
+            # what the same launches reach on the process's first allocation of the two big buffers (kernel time of the set-up
+            # trial on it; `value` is the timed region on the pair the set-up kept: config.placement)
+            "value_first_allocation": (round(n_ints / (first_alloc_ms * 1e-3) / 1e6 * world, 1) if first_alloc_ms else round(value, 1)),
             "dtype": "u32",
             "data": "synthetic" if not stub else "stub",
             **({"stub": stub, "stub_note": "the device layer was replaced by a test stand-in: nothing was decoded, value and "
@@ -555,10 +625,12 @@ def main():
             "bit_exact": bit_exact,
             "config": {
                 "workload": f"{args.type} decode, DSF-65536-16 dictionary (hot set in LDS), {args.workload}-shaped synthetic "
-                            f"docIDs: universe {universe}, {postings} postings encoded per GPU"
+                            f"docIDs: universe {universe}, {n_shard} distinct postings encoded per GPU"
                             + (f", decoded x{R} per step from {R} device-side copies at distinct addresses" if R > 1 else ""),
+                "distinct_postings_per_gpu": n_shard,
                 "ints_per_gpu_per_step": n_ints,
                 "lists_per_gpu": int(np.count_nonzero(lens)) * R,
+                "stream_statistics_sample": f"the first {int(st.ints)} postings of the shard",
                 "units_per_gpu": n_units,
                 "unit_ints": args.unit_ints,
                 "schedule": "prepared unit table (set-up)" if unit_table is not None else "per launch (timed)",
@@ -579,6 +651,10 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
+                # the same launch on the process's FIRST allocation of the two buffers, before any candidate was tried (set-up)
+                "frac_first_allocation": (round(algo_bytes / (first_alloc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                          if first_alloc_ms else round(achieved / HBM_PEAK_GBS, 4)),
+                "kernel_ms_first_allocation": first_alloc_ms if first_alloc_ms else round(k_mean, 4),
                 "traffic": traffic,
                 "traffic_note": traffic_note,
                 "kernel": KERNEL_BY_TYPE[args.type],

@@ -2487,6 +2487,7 @@ int dint_list_cache_decode(const dint_list_cache* c, size_t in_offset, uint32_t*
     size_t b = size_t(it - c->blocks.begin());
     if (b < c->n_blocks && c->blocks[b].in_off == in_offset) {
         if (n != c->blocks[b].n) return DINT_ERR_ARG;
+        if (c->docs_end[b] < in_offset) return DINT_ERR_FORMAT;  // (a block the decode did not reach: its end was never written)
         std::memcpy(out, c->gaps.data() + c->blocks[b].out_off, n * 4);
         if (consumed) *consumed = size_t(c->docs_end[b] - in_offset);
         return DINT_OK;
@@ -2494,6 +2495,7 @@ int dint_list_cache_decode(const dint_list_cache* c, size_t in_offset, uint32_t*
     if (!c->with_freqs || b == 0) return DINT_ERR_ARG;
     b -= 1;  // the last block that starts before in_offset
     if (c->docs_end[b] != in_offset || n != c->blocks[b].n) return DINT_ERR_ARG;
+    if (c->freqs_end[b] < in_offset) return DINT_ERR_FORMAT;
     std::memcpy(out, c->freqs.data() + c->blocks[b].out_off, n * 4);
     if (consumed) *consumed = size_t(c->freqs_end[b] - in_offset);
     return DINT_OK;

@@ -590,13 +590,14 @@ __device__ __forceinline__ void expand_batch(uint32_t bt, uint32_t out_int, cons
                     for (int k = 0; k != 4; ++k) {
                         d[k] = *reinterpret_cast<const uint32_t*>(delta + 4 * r[k]);
                         ad[k] = (d[k] + posb) << 1;  // (bit 31 of the entry — "the upper half follows" — is shifted out)
-                        x[g][k] = *reinterpret_cast<const uint16_t*>(lds_bytes + ad[k] + gbyte + 2 * k);
+                        // (the whole offset in 32 bits before it meets the pointer: ad is routinely a wrapped negative)
+                        x[g][k] = *reinterpret_cast<const uint16_t*>(lds_bytes + uint32_t(ad[k] + gbyte + 2 * k));
                     }
                     // a 32-bit exception literal among the four (a few per tile): its upper half follows the lower one
                     if (__builtin_expect(__ballot(int32_t(d[0] | d[1] | d[2] | d[3]) < 0) != 0, 0)) {
 #pragma unroll
                         for (int k = 0; k != 4; ++k) {
-                            const uint32_t hi = *reinterpret_cast<const uint16_t*>(lds_bytes + ad[k] + gbyte + 2 * k + 2);
+                            const uint32_t hi = *reinterpret_cast<const uint16_t*>(lds_bytes + uint32_t(ad[k] + gbyte + 2 * k + 2));
                             x[g][k] |= (int32_t(d[k]) < 0 ? hi : 0u) << 16;
                         }
                     }

@@ -171,7 +171,11 @@ public:
     list_scope_base(list_scope_base const&) = delete;
     list_scope_base& operator=(list_scope_base const&) = delete;
     ~list_scope_base() {
-        head() = m_prev;
+        // unlink from wherever this scope sits: scopes held in a container are not destroyed innermost first
+        // (a vector<unique_ptr<list_scope>> goes front to back)
+        list_scope_base const** link = &head();
+        while (*link && *link != this) link = &const_cast<list_scope_base*>(*link)->m_prev;
+        if (*link == this) *link = m_prev;
         dint_list_cache_destroy(m_cache);
     }
     // the scope of this thread whose list holds `in`, or null
@@ -180,9 +184,13 @@ public:
             if (in >= s->m_begin && in < s->m_end) return s;
         return nullptr;
     }
+    // nullptr: the decoded list does not serve this call — `in` is not the start of a block's part, or it is a freqs
+    // part and the scope was made without a freqs dictionary (DINT_ERR_ARG) — and the caller decodes the block itself
     uint8_t const* decode(uint8_t const* in, uint32_t* out, size_t n) const {
         size_t consumed = 0;
-        check(dint_list_cache_decode(m_cache, size_t(in - m_begin), out, n, &consumed), "dint_list_cache_decode");
+        const int st = dint_list_cache_decode(m_cache, size_t(in - m_begin), out, n, &consumed);
+        if (st == DINT_ERR_ARG) return nullptr;
+        check(st, "dint_list_cache_decode");
         return in + consumed;
     }
     uint8_t const* end() const { return m_end; }
@@ -202,7 +210,7 @@ private:
     uint8_t const* m_begin;
     uint8_t const* m_end;
     dint_list_cache* m_cache = nullptr;
-    list_scope_base const* m_prev = nullptr;
+    mutable list_scope_base const* m_prev = nullptr;
 };
 
 template <typename HostBlockCoder>
@@ -224,7 +232,8 @@ struct dint_block_device : HostBlockCoder {
     }
     template <typename Dictionary>
     static uint8_t const* decode(Dictionary const& dict, uint8_t const* in, uint32_t* out, uint32_t sum_of_values, size_t n) {
-        if (list_scope_base const* s = list_scope_base::find(in)) return s->decode(in, out, n);
+        if (list_scope_base const* s = list_scope_base::find(in))
+            if (uint8_t const* served = s->decode(in, out, n)) return served;
         uint8_t const* end = in + detail::worst_case_bytes(n);
         if (readable_end() && readable_end() > in && readable_end() < end) end = readable_end();
         return detail::decode_block(dict, in, end, out, sum_of_values, n);
@@ -232,7 +241,8 @@ struct dint_block_device : HostBlockCoder {
     template <typename Dictionary>
     static uint8_t const* decode(Dictionary const& dict, uint8_t const* in, uint8_t const* in_end, uint32_t* out,
                                  uint32_t sum_of_values, size_t n) {
-        if (list_scope_base const* s = list_scope_base::find(in)) return s->decode(in, out, n);
+        if (list_scope_base const* s = list_scope_base::find(in))
+            if (uint8_t const* served = s->decode(in, out, n)) return served;
         return detail::decode_block(dict, in, in_end, out, sum_of_values, n);
     }
 };

@@ -27,7 +27,8 @@ UNIT_DTYPE = np.dtype(
 assert UNIT_DTYPE.itemsize == 24
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libdint_host.so")
+# DINT_HOST_LIB: another build of the same library (the sanitizer build, `make -C dint_amd/csrc host-asan`; README "Sanitizers")
+_LIB_PATH = os.environ.get("DINT_HOST_LIB") or os.path.join(_HERE, "libdint_host.so")
 
 
 class SynthParams(C.Structure):

@@ -232,8 +232,12 @@ void dint_block_table_destroy(dint_block_table* table);
  * freq = value + 1 is added where the values are stored — blocks shorter than 256 through the
  * binary-interpolative decoder (whose code is the prefix sums already). From a table's second decode on, the freqs
  * launch and the short blocks' decoder run on streams the table owns, beside the docs launch, forked from and joined
- * to `stream` inside the call: to the caller everything is ordered on `stream` as before (dint_set_option(DINT_OPT_INDEX_CONCURRENT, 0) in
- * the environment: one stream).
+ * to `stream` inside the call: to the caller everything is ordered on `stream` as before
+ * (dint_set_option(DINT_OPT_INDEX_CONCURRENT, 0): one stream).
+ * CONTENT STABILITY: what the table learns in its first complete decode (exact byte spans, the freqs parts' units, both
+ * bundle schedules — which bake in the blocks' selector bytes of a multi-dictionary index) is kept and keyed by the
+ * dictionaries, the index POINTER and its size, not by the bytes: while the table lives, the index at d_index must keep
+ * its contents, like the stream under a dint_unit_table. An index shard reloaded into the same buffer needs a new table.
  * Replaces: see dint_decode_posting_blocks. */
 int dint_decode_block_table(const dint_dict* docs_dict, const dint_dict* freqs_dict, const uint8_t* d_index,
                             size_t index_bytes, dint_block_table* table, uint32_t* d_docids, uint32_t* d_freqs,

@@ -130,33 +130,61 @@ int run(char** argv, const char* mode) {
     if (scoped) {  // warm the dictionaries' host-call workspaces (their first use allocates): a scope over the same list
         typename Coder::list_scope warm(docs_dict, &freqs_dict, list.data(), list.data() + list_bytes);
     }
-    if (noend) Coder::readable_end() = list.data() + list.size();
+    const bool scopes = std::strcmp(mode, "scopes") == 0;
+    if (noend || scopes) Coder::readable_end() = list.data() + list.size();
     uint64_t allocs0 = 0, allocs1 = 0;
     dint_debug_alloc_count(&allocs0);
     const auto t0 = std::chrono::steady_clock::now();
     std::unique_ptr<typename Coder::list_scope> scope;
     if (scoped) scope.reset(new typename Coder::list_scope(docs_dict, &freqs_dict, list.data(), list.data() + list_bytes));
-    enumerator<Dictionary, Coder> e(&docs_dict, &freqs_dict, list.data(), list.data() + list.size(), scoped || noend);
-    if (e.size() != want_docs.size()) {
-        std::cerr << "list holds " << e.size() << " postings, expected " << want_docs.size() << "\n";
-        return 1;
+    auto walk = [&](bool endless) -> int {
+        enumerator<Dictionary, Coder> e(&docs_dict, &freqs_dict, list.data(), list.data() + list.size(), endless);
+        if (e.size() != want_docs.size()) {
+            std::cerr << "list holds " << e.size() << " postings, expected " << want_docs.size() << "\n";
+            return 1;
+        }
+        for (size_t i = 0; i != want_docs.size(); ++i) {
+            if (e.docid() != want_docs[i] || e.freq() != want_freqs[i]) {
+                std::cerr << "posting " << i << ": (" << e.docid() << ", " << e.freq() << ") expected (" << want_docs[i] << ", "
+                          << want_freqs[i] << ")\n";
+                return 1;
+            }
+            if ((!scoped || i % 256 == 0) && !e.poisoned()) {  // (a timed walk looks once per block)
+                std::cerr << "posting " << i << ": the decoder wrote past the block\n";
+                return 1;
+            }
+            const bool more = e.next();
+            if (more != (i + 1 != want_docs.size())) {
+                std::cerr << "next() at posting " << i << " returned " << more << "\n";
+                return 1;
+            }
+        }
+        return 0;
+    };
+    if (scopes) {
+        // Scopes held in a container die front to back, not innermost first; a scope without a freqs dictionary serves the
+        // docs parts and leaves the freqs parts to the per-block call (the cache answers DINT_ERR_ARG: no exception).
+        using scope_t = typename Coder::list_scope;
+        std::vector<std::unique_ptr<scope_t>> held;
+        held.emplace_back(new scope_t(docs_dict, static_cast<Dictionary const*>(nullptr), list.data(), list.data() + list_bytes));
+        if (walk(true)) return 1;  // docs from the scope, freqs decoded block by block
+        held.emplace_back(new scope_t(docs_dict, &freqs_dict, list.data(), list.data() + list_bytes));
+        held.emplace_back(new scope_t(docs_dict, static_cast<Dictionary const*>(nullptr), list.data(), list.data() + list_bytes));
+        if (walk(true)) return 1;
+        held.erase(held.begin());      // the OUTERMOST first ...
+        if (walk(true)) return 1;      // ... the other two still serve
+        held.erase(held.begin() + 1);  // then the innermost
+        if (walk(true)) return 1;
+        held.clear();
+        if (Coder::list_scope::find(list.data() + 1) != nullptr) {
+            std::cerr << "a destroyed scope is still on this thread's list\n";
+            return 1;
+        }
+        if (walk(true)) return 1;      // no scope at all: every block through the per-block call
+        std::cout << "ok\n";
+        return 0;
     }
-    for (size_t i = 0; i != want_docs.size(); ++i) {
-        if (e.docid() != want_docs[i] || e.freq() != want_freqs[i]) {
-            std::cerr << "posting " << i << ": (" << e.docid() << ", " << e.freq() << ") expected (" << want_docs[i] << ", "
-                      << want_freqs[i] << ")\n";
-            return 1;
-        }
-        if ((!scoped || i % 256 == 0) && !e.poisoned()) {  // (a timed walk looks once per block)
-            std::cerr << "posting " << i << ": the decoder wrote past the block\n";
-            return 1;
-        }
-        const bool more = e.next();
-        if (more != (i + 1 != want_docs.size())) {
-            std::cerr << "next() at posting " << i << " returned " << more << "\n";
-            return 1;
-        }
-    }
+    if (walk(scoped || noend)) return 1;
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     dint_debug_alloc_count(&allocs1);
     std::cout << "ok\n";

@@ -118,6 +118,11 @@ def test_block_coder_under_a_posting_list_walker(walker_binary, small_corpus, tm
                             str(tmp_path / "list.bin"), str(tmp_path / "docids.bin"), str(tmp_path / "freqs.bin")],
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and r.stdout.strip() == "ok", f"list {i} (n={lens[i]}): " + r.stdout + r.stderr
+        # scopes destroyed out of order (a container's order), a docs-only scope falling back for the freqs parts
+        r = subprocess.run([walker_binary, str(kind), str(tmp_path / "docs.dict"), str(tmp_path / "freqs.dict"),
+                            str(tmp_path / "list.bin"), str(tmp_path / "docids.bin"), str(tmp_path / "freqs.bin"), "scopes"],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and r.stdout.strip() == "ok", f"list {i} (n={lens[i]}) scopes: " + r.stdout + r.stderr
 
 
 def test_decode_block_host_call_shape(small_corpus):
