@@ -420,7 +420,7 @@ def main():
 
     # Placement (set-up, untimed): the decode kernel's time depends on WHERE the driver puts the stream it reads and the
     # output it writes — 10-17 % between two pairs of buffers in one process, stable for the life of a pair, and nothing
-    # a plain fill / copy / gather notices (tools/box_spread/realloc_probe.py). A caller who keeps its
+    # a plain fill / copy / gather notices (tools/archive/box_spread/realloc_probe.py). A caller who keeps its
     # buffers for many decodes picks them once; so does the bench: a few candidate output buffers for the first copy of
     # the stream, then a few candidate copies of the stream for the output buffer that won, two launches each; the
     # fastest pair stays, the others are freed before the timed region.

@@ -419,3 +419,45 @@ def test_prepared_unit_table_decodes_like_decode_units(device, small_corpus, kin
     with pytest.raises(device.DintError):
         table.decode(small)
     table.close()
+
+
+@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
+def test_two_shards_two_handles_two_streams(device, kind):
+    """The closest a one-GPU box gets to the multi-GPU layout (one dint_dict handle per device): the two
+    list-range shards of partition_lists(lens, 2) of ONE collection, each with a dictionary handle of its own (the
+    replicated dictionary, built from shard 0's lists like bench.py does) and a prepared unit table, decoded at the same
+    time on two streams of device 0, three times; every shard bit-exact, and together they are the collection."""
+    import torch
+    from dint_amd import sharding
+
+    p = host.synth_params(universe=2_000_000, seed=77)
+    lens_all = host.synth_lengths(p, 5_000_000)
+    parts = sharding.partition_lists(lens_all, 2)
+    colls = [host.Collection(host.synth_gaps(p, lens_all[lo:hi], first_list_id=lo), lens_all[lo:hi]) for lo, hi in parts]
+    assert sum(c.num_postings for c in colls) == int(lens_all.sum())
+    dict_file = host.build_dictionary(kind, colls[0], max_sample_ints=1_000_000)
+    dev = torch.device("cuda", 0)
+    jobs = []
+    for c in colls:
+        d = device.Dictionary(kind, dict_file)  # a handle per shard: its own queue slots, events, schedule workspaces
+        enc, units = host.encode_vroom(kind, dict_file, c, unit_ints=256 if kind == host.MULTI_PACKED else 4096)
+        enc_dev = torch.from_numpy(enc).to(dev)
+        units_dev = device.units_to_device(units, dev)
+        table = device.UnitTable(d, enc_dev, units_dev, len(units), c.num_postings)
+        jobs.append(dict(d=d, c=c, enc_dev=enc_dev, units_dev=units_dev, table=table, stream=torch.cuda.Stream(dev),
+                         out=torch.empty(c.num_postings, dtype=torch.int32, device=dev), n_units=len(units)))
+    torch.cuda.synchronize(dev)
+    for rep in range(3):
+        for j in jobs:
+            j["out"].fill_(-1)
+        torch.cuda.synchronize(dev)
+        for j in jobs:  # both launches are in flight together
+            with torch.cuda.stream(j["stream"]):
+                j["table"].decode(j["out"], None, stream=j["stream"].cuda_stream)
+        for j in jobs:
+            j["stream"].synchronize()
+            assert np.array_equal(j["out"].cpu().numpy().view(np.uint32), j["c"].gaps), rep
+    whole = host.synth_gaps(p, lens_all, first_list_id=0)
+    assert np.array_equal(np.concatenate([j["out"].cpu().numpy().view(np.uint32) for j in jobs]), whole)
+    for j in jobs:
+        j["table"].close()

@@ -156,3 +156,35 @@ def test_bench_help_renders():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "--placement-trials" in r.stdout
+
+
+def test_bench_at_world_size_8_through_its_own_launcher():
+    """The dress rehearsal of `python bench.py --gpus 8` without a node: eight ranks started by bench.py's own launcher,
+    rendezvous on 127.0.0.1 over gloo, the eight list-range shards of ONE collection (every list in exactly one shard,
+    the shards' postings within a list's length of each other), the dictionary broadcast from rank 0, the reductions —
+    with the stubbed device layer. The line reports the whole job: 8 x the per-GPU integers per step."""
+    import json
+
+    env = dict(os.environ, DINT_BENCH_STUB="bench_stub", PYTHONPATH=os.path.join(ROOT, "tests"))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--postings", "100000", "--universe", "300000",
+                        "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-verify", "--dict-sample", "50000",
+                        "--rank-timeout", "240"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert line["n_gpus"] == 8 and line["data"] == "stub" and line["scaling"] == "weak"
+    assert line["config"]["process_group"] == "gloo" and line["config"]["parallelism"] == "list-range x8"
+    per_gpu = line["config"]["ints_per_gpu_per_step"]
+    # (gov2 with more than one rank: the shard decoded x5 from five copies — here rank 0's share of 8 x 100000 postings)
+    assert per_gpu % 5 == 0 and abs(per_gpu // 5 - 100000) < 100000 // 3
+    assert line["value"] > 0 and line["steps"] == 2
+    from dint_amd import host, sharding
+
+    lens = host.synth_lengths(host.synth_params(universe=300000, seed=12345), 100000 * 8)
+    parts = sharding.partition_lists(lens, 8)
+    assert parts[0][0] == 0 and parts[-1][1] == len(lens) and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+    sizes = [int(lens[a:b].sum()) for a, b in parts]
+    assert sum(sizes) == int(lens.sum()) and max(sizes) - min(sizes) <= 2 * int(lens.max())
+    assert per_gpu == 5 * sizes[0]

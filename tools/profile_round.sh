@@ -1,7 +1,8 @@
 #!/bin/bash
 # GPU box: the judged artefacts of a round — GPU tests, bench.py (default command), rocprofv3 kernel stats, the
 # FETCH_SIZE / WRITE_SIZE passes and one SQ pass of the same bench command, then the bench line again with the
-# measured traffic attached. usage: [SKIP_TESTS=1] tools/profile_round.sh r03 [extra bench args]
+# measured traffic attached. Every profiler pass runs under its own `timeout` (a pass that aborts can hang until the box's limit).
+# usage: [SKIP_TESTS=1] tools/profile_round.sh r04 [extra bench args]
 TAG=${1:-r03}; shift
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd $R
@@ -9,11 +10,11 @@ if [ -z "$SKIP_TESTS" ]; then python -m pytest tests -m gpu -x -q > $OUT/pytest_
 python3 bench.py "$@" > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $R/bench.py --steps 5 --warmup 2 --cpu-seconds 0 --no-verify $*"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $BENCH > $OUT/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $BENCH > $OUT/write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/sq1 -- $BENCH > $OUT/sq1.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_FLAT SQ_ACTIVE_INST_SCA --output-format csv -d $OUT/sq2 -- $BENCH > $OUT/sq2.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $BENCH > $OUT/fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $BENCH > $OUT/write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/sq1 -- $BENCH > $OUT/sq1.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_FLAT SQ_ACTIVE_INST_SCA --output-format csv -d $OUT/sq2 -- $BENCH > $OUT/sq2.log 2>&1
 cd $R
 INTS=$(python3 -c "import json; print(json.load(open('$OUT/bench.json'))['config']['ints_per_gpu_per_step'])")
 TYPE=$(python3 -c "import json; print(json.load(open('$OUT/bench.json'))['metric'].split('vroom ')[1].rstrip(')'))")
