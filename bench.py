@@ -10,11 +10,11 @@ distinct postings, generated, encoded and uploaded in pieces during set-up). Inp
 table, dictionary) are in HBM before the timed region starts. Posting lists
 are partitioned statically across ranks, the dictionary is replicated, and
 there is no data-path collective: the only collectives are the dictionary
-broadcast during set-up and the max-over-ranks of the elapsed time. Set-up also
-picks the two big buffers (the encoded stream, the output) among a few candidate
-allocations by decoding into each (--placement-trials: the kernel's time depends
-by 10-17 % on where the driver puts the pair); the losers
-are freed before the warm-up.
+broadcast during set-up and the max-over-ranks of the elapsed time. The two big
+buffers (the encoded stream, the output) are the process's first allocation of
+them, the output a few GB apart from the stream (--apart-gb); --placement-trials
+N > 1 tries candidate pairs during set-up instead (the kernel's time depends by
+10-17 % on where the driver puts the pair).
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
 """
@@ -59,10 +59,16 @@ def parse_args(argv=None):
                     help="set-up generates, encodes and uploads the rank's shard in pieces of about this many postings (host memory: "
                          "one piece at a time)")
     ap.add_argument("--postings", type=float, default=None, help="postings encoded per GPU (weak scaling: fixed per GPU)")
-    ap.add_argument("--placement-trials", type=int, default=6,
-                    help="candidate output buffers, then candidate stream buffers, allocated during set-up; the pair the decode "
-                         "kernel runs fastest on is kept (the kernel's time differs by 10-17 %% with WHERE the driver puts the "
-                         "two buffers: DESIGN.md section 4e). 1: the first allocation, as before")
+    ap.add_argument("--placement-trials", type=int, default=1,
+                    help="1 (default): the process's first allocation of the two big buffers, no selection. N > 1: N candidate output "
+                         "buffers, then N candidate stream buffers, allocated during set-up; the pair the decode kernel runs fastest on "
+                         "is kept (the kernel's time differs by 10-17 %% with WHERE the driver puts the two buffers: DESIGN.md section "
+                         "4e) — round 3's default was 6; the first allocation of THIS set-up has been the fast level in every fresh "
+                         "process measured (profiles/r04_first_allocation.txt)")
+    ap.add_argument("--apart-gb", type=float, default=24.0,
+                    help="the stream and the output are not allocated next to each other: this much device memory is allocated between "
+                         "them and freed again (two big buffers allocated one after the other usually land in the same kind of physical "
+                         "stretch, the slow placement of DESIGN.md section 4e). 0: no spacer")
     ap.add_argument("--replicate", type=int, default=None,
                     help="device-side copies of the encoded shard at distinct addresses, all decoded in one step")
     ap.add_argument("--universe", type=int, default=None, help="documents")
@@ -73,9 +79,10 @@ def parse_args(argv=None):
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--cpu-seconds", type=float, default=10.0,
                     help="decode time budget of each leg of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--traffic-file", default=None,
-                    help="JSON written by tools/pmc_traffic.py from rocprofv3 --pmc passes of THIS command; without it "
-                         "roofline.traffic is null (HBM counters cannot be read from inside the run)")
+    ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
+                    help="JSON written by tools/pmc_traffic.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS command "
+                         "(HBM counters cannot be read from inside the run). Default: the round's committed measurement, used only "
+                         "if it was taken for the same type and the same integers per launch; otherwise roofline.traffic is null")
     ap.add_argument("--no-verify", action="store_true", help="skip the full bit-exact output check")
     ap.add_argument("--per-launch-schedule", action="store_true",
                     help="decode through dint_decode_units (the bundle schedule rebuilt before every launch, and timed) instead "
@@ -426,7 +433,18 @@ def main():
     # fastest pair stays, the others are freed before the timed region.
     trials = max(1, args.placement_trials) if dev.type == "cuda" and not os.environ.get("DINT_BENCH_STUB") else 1
     enc_dev = allocate_stream() if (R > 1 or trials > 1) else enc_one  # (one copy, no candidates: the uploaded stream itself)
+    # the output is allocated APART from the stream: a spacer between the two allocations, freed right away
+    spacer = None
+    if dev.type == "cuda" and args.apart_gb > 0:
+        try:
+            free_b = torch.cuda.mem_get_info(dev)[0]
+            want = int(min(args.apart_gb * 1e9, max(0, free_b - 4 * n_ints - (8 << 30))))
+            if want > (1 << 30):
+                spacer = torch.empty(want, dtype=torch.uint8, device=dev)
+        except RuntimeError:
+            spacer = None
     out_dev = allocate_output()
+    del spacer
     placement_ms = None
 
     def kernel_ms(e, o):
@@ -595,8 +613,10 @@ def main():
             if tf.get("type") == args.type and tf.get("ints_per_launch") == n_ints:
                 traffic = {"write_gb": tf["write_gb"], "fetch_gb_raw": tf["fetch_gb_raw"],
                            "fetch_gb_corrected": tf["fetch_gb_corrected"],
-                           "total_gb": round(tf["write_gb"] + tf["fetch_gb_corrected"], 3)}
-                traffic_note = tf.get("note", "")
+                           "total_gb": round(tf["write_gb"] + tf["fetch_gb_corrected"], 3),
+                           "total_bytes": int(round((tf["write_gb"] + tf["fetch_gb_corrected"]) * 1e9)),
+                           "over_algorithmic": round((tf["write_gb"] + tf["fetch_gb_corrected"]) * 1e9 / algo_bytes, 4)}
+                traffic_note = tf.get("note", "") + f" [{os.path.relpath(args.traffic_file, ROOT)}: separate profiler passes of this command, not this process]"
         k_mean = float(kernel_ms.mean())
         achieved = algo_bytes / (k_mean * 1e-3) / 1e9
         value = total_ints * args.steps / elapsed / 1e6
@@ -636,7 +656,8 @@ def main():
                 "schedule": "prepared unit table (set-up)" if unit_table is not None else "per launch (timed)",
                 "placement": (f"fastest of {len(placement_ms['output_buffers'])} candidate output buffers, then of "
                               f"{len(placement_ms['stream_buffers'])} candidate stream buffers, chosen during set-up"
-                              if placement_ms else "first allocation"),
+                              if placement_ms else "first allocation"
+                              + (f" (output allocated {args.apart_gb:g} GB apart from the stream)" if args.apart_gb > 0 else "")),
                 "placement_trial_kernel_ms": placement_ms,
                 "bits_per_int": round(bpi, 3),
                 **stream,

@@ -26,11 +26,10 @@ def test_bench_line_contract(extra):
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["bit_exact"] is True and d["value"] > 0 and d["higher_is_better"] is True and d["dtype"] == "u32"
     assert "workload" in d["config"] and "model" not in d["config"]
-    # the buffers were picked during set-up among candidate allocations, and the line says which and how they timed
-    trials = d["config"]["placement_trial_kernel_ms"]
-    assert "candidate output buffers" in d["config"]["placement"] and len(trials["output_buffers"]) == 6
-    assert len(trials["stream_buffers"]) == 6 and min(trials["stream_buffers"]) <= min(trials["output_buffers"])
-    assert d["config"]["ints_per_gpu_per_step"] >= 6_000_000 * 0.9
+    # by default nothing is selected: the two big buffers are the process's first allocation, and the line says so
+    assert d["config"]["placement"].startswith("first allocation") and d["config"]["placement_trial_kernel_ms"] is None
+    assert d["value_first_allocation"] == d["value"] and d["roofline"]["frac_first_allocation"] == d["roofline"]["frac"]
+    assert d["config"]["ints_per_gpu_per_step"] >= 6_000_000 * 0.9 and d["config"]["distinct_postings_per_gpu"] * 2 == d["config"]["ints_per_gpu_per_step"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["kernel_launches_timed"] == 3
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["kernel_ms"] > 0
@@ -39,6 +38,21 @@ def test_bench_line_contract(extra):
     assert rf["traffic"] is None  # not measured in this process: only a same-command PMC file may fill it
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["all_cores"]["cores"] >= 1 and cb["cpu_model"]
+
+
+def test_bench_placement_trials_are_in_the_line():
+    """--placement-trials N > 1: candidate output buffers, then candidate stream buffers, decoded into during set-up; the line
+    carries every candidate's kernel time, which pair was kept, and what the FIRST allocation reached."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--postings", "3e6",
+           "--chunk-postings", "1e6", "--dict-sample", "1e6", "--cpu-seconds", "0", "--placement-trials", "3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    trials = d["config"]["placement_trial_kernel_ms"]
+    assert "candidate output buffers" in d["config"]["placement"] and len(trials["output_buffers"]) == 3
+    assert len(trials["stream_buffers"]) == 3 and min(trials["stream_buffers"]) <= min(trials["output_buffers"])
+    assert d["roofline"]["kernel_ms_first_allocation"] == trials["output_buffers"][0] and d["value_first_allocation"] > 0
+    assert d["bit_exact"] is True and d["config"]["distinct_postings_per_gpu"] == d["config"]["ints_per_gpu_per_step"]  # three pieces, one copy
 
 
 @pytest.mark.parametrize("k", [0, 3, 7])

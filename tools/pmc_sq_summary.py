@@ -10,7 +10,7 @@ agg = collections.defaultdict(lambda: [0.0, 0])
 kernel = None
 for f in sorted(glob.glob(os.path.join(out, "sq*", "**", "*counter_collection.csv"), recursive=True)):
     for row in csv.DictReader(open(f)):
-        if not row["Kernel_Name"].startswith(("dint_dev::decode_single_kernel", "dint_dev::decode_multi_kernel")):
+        if not row["Kernel_Name"].startswith(("dint_dev::decode_single_kernel", "dint_dev::decode_multi_kernel", "dint_dev::decode_multi_bundles_kernel")):
             continue
         kernel = row["Kernel_Name"].split("(")[0]
         a = agg[row["Counter_Name"]]
