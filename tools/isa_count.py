@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Development aid: static instruction counts of the decode kernel per source section.
 Compiles dint_hip.hip with -DDINT_MARKS (the MARK() comments survive into the assembly) and counts the
-instructions between marks, by issue class. usage: tools/isa_count.py [single|multi] [--dump SECTION]"""
+instructions between marks, by issue class. usage: tools/isa_count.py [single|multi|<kernel name, e.g. decode_multi_bundles_kernel>] [--dump SECTION]"""
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-kernel = "decode_multi_kernel" if "multi" in sys.argv[1:2] else "decode_single_kernel"
+kernel = {"multi": "decode_multi_kernel", "single": "decode_single_kernel"}.get((sys.argv[1:2] or ["single"])[0], (sys.argv[1:2] or ["single"])[0])
 dump = sys.argv[sys.argv.index("--dump") + 1] if "--dump" in sys.argv else None
 os.makedirs("/tmp/isa", exist_ok=True)
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", "-DDINT_MARKS",

@@ -32,6 +32,8 @@ stream = torch.cuda.current_stream(dev).cuda_stream
 names = {0: "outside (queue, exit)", 1: "classify", 2: "sizes + scans", 3: "metas + heads of the next tile", 4: "flag/delta/rank tables",
          5: "rotate + far prefetch", 7: "tails land", 8: "wait point + heads land + tails requested", 9: "expand + stores", 10: "slow stores", 11: "segment prologue",
          12: "bundle front end", 13: "epilogue", 14: "queue ticket", 15: "rows of the next tile"}
+if "multi" in typ or unit_ints <= 256:  # bundle_process's own marks (bundles.inc)
+    names.update({1: "bundle: classify", 3: "bundle: metas + literals", 2: "bundle: sizes + scans + cells", 11: "bundle: cells, tails asked", 15: "bundle: next bundle mapped + asked"})
 for it in range(4):
     assert lib.dint_decode_units(h, enc_dev.data_ptr(), enc.size, units_dev.data_ptr(), len(units), out_dev.data_ptr(),
                                  coll.num_postings, None, stream) == 0
