@@ -122,6 +122,9 @@ constexpr uint32_t kMetaException = 1u << 20;         // what the two exception 
                                                       // staging cell — the literal that follows the marker in the stream goes there
 constexpr uint32_t kQueueShards = 8;                  // dynamic unit queue: one counter per shard
 constexpr uint32_t kQueueStride = 32;                 // words between counters (own 128-byte line each)
+constexpr uint32_t kChunkShards = 32;                 // the bundle path's chunk tickets: counters (a line each), four to an XCD's workgroups
+constexpr uint32_t kChunkCounterLineAt = 1;           // ... which begin this many lines behind decode_args::chunk_queue
+constexpr uint32_t kQueueLines = kQueueShards + 1 + kChunkShards;  // a launch's counters: unit-queue shards | the clock's line | chunk shards
 constexpr uint32_t kClockWordAt = 16;                 // in the chunk counter's line: shader-clock cycles of the launch's first wave (u64)
 constexpr uint32_t kMaxUnitInts = 1u << 28;           // byte offsets inside a unit's output stay 32-bit
 
@@ -135,8 +138,8 @@ constexpr uint32_t kMaxUnitInts = 1u << 28;           // byte offsets inside a u
 #include "dint_query_kernels.hpp"  // round_tail: what a query round does behind its decode
 namespace dint_dev {
 
-#include "kernels/kernel_body.inc"
 #include "kernels/index.inc"
+#include "kernels/kernel_body.inc"
 #include "kernels/query_pages.inc"
 
 // test hook: out[i] = inclusive prefix sum of in[0..i] over one wave

@@ -87,7 +87,9 @@ typedef enum dint_option {
     DINT_OPT_QUERY_LEAN_PAGES = 2,    /* page decodes of at least this many pages take the three-launch form; -1 (default): none */
     DINT_OPT_QUERY_TAIL_PAGES = 3,    /* calls of at most this many candidate pages run a round per launch; default 4            */
     DINT_OPT_QUERY_FUSED_PAGES = 4,   /* ... of at most this many run as ONE launch; default 2, 0: never                         */
-    DINT_OPT_COUNT_ = 5
+    DINT_OPT_INDEX_INLINE_TAILS = 5,  /* 1 (default): a created block table's short blocks are decoded inside its docs launch;   */
+                                      /* 0: by a launch of their own                                                             */
+    DINT_OPT_COUNT_ = 6
 } dint_option;
 int dint_set_option(int option, long long value);
 int dint_get_option(int option, long long* value);
