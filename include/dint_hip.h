@@ -89,7 +89,9 @@ typedef enum dint_option {
     DINT_OPT_QUERY_FUSED_PAGES = 4,   /* ... of at most this many run as ONE launch; default 2, 0: never                         */
     DINT_OPT_INDEX_INLINE_TAILS = 5,  /* 1 (default): a created block table's short blocks are decoded inside its docs launch;   */
                                       /* 0: by a launch of their own                                                             */
-    DINT_OPT_COUNT_ = 6
+    DINT_OPT_CHUNK_SPLIT = 6,         /* the bundle path hands out 1/2^n of a 64-unit chunk per ticket, n = 0..4; -1 (default):  */
+                                      /* by the launch's size                                                                   */
+    DINT_OPT_COUNT_ = 7
 } dint_option;
 int dint_set_option(int option, long long value);
 int dint_get_option(int option, long long* value);

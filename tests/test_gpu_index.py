@@ -177,3 +177,39 @@ def test_block_table_keeps_nothing_from_a_decode_that_skipped_blocks(device, sma
     check_short(*run(cut))
     docids, freqs = run(total)
     assert np.array_equal(docids[:total].view(np.uint32), ix.docids) and np.array_equal(freqs[:total].view(np.uint32), ix.freqs)
+
+
+@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
+@pytest.mark.parametrize("inline_tails", [0, 1])
+def test_short_blocks_inside_the_docs_launch_or_in_their_own(device, small_corpus, kind, inline_tails):
+    """A created block table carries its short blocks as tickets (longest first, one lane per block, as many as fit a
+    wave's LDS scratch) that the docs launch's waves decode before their DINT work; dint_set_option(index_inline_tails, 0)
+    brings the launch of their own back. Both ways, five decodes (the first learns the spans, the second builds the
+    schedules, from the third on the kernels compiled without the unit queue run), with and without freqs, into poisoned
+    buffers with canaries behind them: bit-exact, nothing written past the last posting."""
+    import torch
+
+    ix = get_index(small_corpus, kind)
+    blocks, total = device.index_posting_lists(ix.bytes, ix.offsets)
+    assert (blocks["n"] < 256).sum() > 64 and (blocks["n"] < 256).sum() < len(blocks)
+    dd, fd = device.Dictionary(kind, ix.docs_dict), device.Dictionary(kind, ix.freqs_dict)
+    dev = torch.device("cuda", 0)
+    padded = np.concatenate([ix.bytes, np.zeros(16, np.uint8)])
+    index_dev = torch.from_numpy(padded).to(dev)
+    with device.options(index_inline_tails=inline_tails):
+        table = device.BlockTable(dd, blocks, padded.size)
+        for i in range(5):
+            with_freqs = i != 3
+            docids_dev = torch.full((total + 512,), -9, dtype=torch.int32, device=dev)
+            freqs_dev = torch.full((total + 512,), -9, dtype=torch.int32, device=dev)
+            table.decode(dd, fd if with_freqs else None, index_dev, padded.size, docids_dev[:total], freqs_dev[:total] if with_freqs else None)
+            torch.cuda.synchronize()
+            d, f = docids_dev.cpu().numpy(), freqs_dev.cpu().numpy()
+            assert np.array_equal(d[:total].view(np.uint32), ix.docids), i
+            assert (d[total:] == -9).all()
+            if with_freqs:
+                assert np.array_equal(f[:total].view(np.uint32), ix.freqs), i
+                assert (f[total:] == -9).all()
+            else:
+                assert (f == -9).all()
+        table.close()
