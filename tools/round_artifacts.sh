@@ -1,20 +1,10 @@
 #!/bin/bash
 # GPU box: everything a round's profiles/ is made of, after tools/profile_round.sh (the headline's artefacts): config 3
-# (multi_packed_dint, block-granular units) with its kernel stats and SQ counters, the in-index decode, the query timings,
-# and the headline on the process's FIRST allocation in three consecutive fresh processes.
+# (multi_packed_dint, block-granular units) with its kernel stats and SQ counters, the in-index decode and its launches side by
+# side (rocprofv3 kernel trace -> tools/kernel_timeline.py), the query timings.
 # usage: tools/round_artifacts.sh r04   -> gpurun_out/<tag>x/
 TAG=${1:-r04}; R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/${TAG}x; mkdir -p $OUT
 cd $R
-for i in 1 2 3; do
-  timeout 400 python3 bench.py --placement-trials 1 --cpu-seconds 0 --steps 20 --warmup 5 > $OUT/first_alloc_$i.json 2> $OUT/first_alloc_$i.err
-done
-python3 - <<PY | tee $OUT/first_allocation_x3.txt
-import json
-for i in (1, 2, 3):
-    d = json.load(open("$OUT/first_alloc_%d.json" % i))
-    print("fresh process %d, --placement-trials 1: %.1f G ints/s, roofline.frac %.4f, kernel ms min/median/max %s, bit_exact %s"
-          % (i, d["value"] / 1e3, d["roofline"]["frac"], d["roofline"]["kernel_ms_min_median_max"], d["bit_exact"]))
-PY
 MULTI="--type multi_packed_dint --unit-ints 256"
 timeout 600 python3 bench.py $MULTI --steps 20 --warmup 5 > $OUT/bench_multi.json 2> $OUT/bench_multi.err; cat $OUT/bench_multi.json | cut -c1-300
 cd /tmp && export TMPDIR=/tmp
@@ -28,5 +18,7 @@ INTS=$(python3 -c "import json; print(json.load(open('$OUT/bench_multi.json'))['
 python3 tools/pmc_traffic.py $OUT/fetch $OUT/write multi_packed_dint $INTS $OUT/traffic_multi.json decode_multi | tee $OUT/traffic_multi.log
 cp $OUT/bench_multi.json $OUT/bench.json; python3 tools/pmc_sq_summary.py $OUT $INTS | tee $OUT/sq_multi.txt
 find $OUT/stats_multi -name "*kernel_stats.csv" -exec cat {} \; | head -8 | tee $OUT/kernel_stats_multi_head.csv
-timeout 300 python3 tools/inindex_bench.py > $OUT/inindex.json 2> $OUT/inindex.err; cat $OUT/inindex.json | cut -c1-300
+timeout 300 python3 tools/inindex_bench.py 1e8 $OUT/inindex.json > $OUT/inindex.log 2> $OUT/inindex.err; cut -c1-300 $OUT/inindex.log
+(cd /tmp && PLACEMENT_TRIALS=1 timeout 400 rocprofv3 --kernel-trace --output-format csv -d $OUT/inindex_trace -- python3 $R/tools/inindex_bench.py > $OUT/inindex_trace.log 2>&1)
+python3 tools/kernel_timeline.py $OUT/inindex_trace --calls 400 --gap-us 40 --match decode_single_index,interpolative,finalize_flagged,fillBuffer > $OUT/inindex_timeline_all.txt 2>&1
 timeout 900 python3 tests/query_timing.py --forms > $OUT/queries_1e8.json 2> $OUT/queries.err; cat $OUT/queries_1e8.json | cut -c1-600
