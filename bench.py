@@ -11,10 +11,12 @@ table, dictionary) are in HBM before the timed region starts. Posting lists
 are partitioned statically across ranks, the dictionary is replicated, and
 there is no data-path collective: the only collectives are the dictionary
 broadcast during set-up and the max-over-ranks of the elapsed time. The two big
-buffers (the encoded stream, the output) are the process's first allocation of
-them, the output a few GB apart from the stream (--apart-gb); --placement-trials
-N > 1 tries candidate pairs during set-up instead (the kernel's time depends by
-10-17 % on where the driver puts the pair).
+buffers (the encoded stream, the output) are chosen during set-up among
+--placement-trials (4) candidates each, ranked by the library's own call for that
+(dint_unit_table_rank_outputs): the kernel's time depends by 10-17 % on where
+the driver puts the pair; what the process's FIRST
+allocation reaches is reported next to it (value_first_allocation,
+roofline.frac_first_allocation). --placement-trials 1: the first allocation only.
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
 """
@@ -59,12 +61,13 @@ def parse_args(argv=None):
                     help="set-up generates, encodes and uploads the rank's shard in pieces of about this many postings (host memory: "
                          "one piece at a time)")
     ap.add_argument("--postings", type=float, default=None, help="postings encoded per GPU (weak scaling: fixed per GPU)")
-    ap.add_argument("--placement-trials", type=int, default=1,
-                    help="1 (default): the process's first allocation of the two big buffers, no selection. N > 1: N candidate output "
-                         "buffers, then N candidate stream buffers, allocated during set-up; the pair the decode kernel runs fastest on "
-                         "is kept (the kernel's time differs by 10-17 %% with WHERE the driver puts the two buffers: DESIGN.md section "
-                         "4e) — round 3's default was 6; the first allocation of THIS set-up has been the fast level in every fresh "
-                         "process measured (profiles/r04_first_allocation.txt)")
+    ap.add_argument("--placement-trials", type=int, default=4,
+                    help="N (default 4) candidate output buffers, ranked by the library (dint_unit_table_rank_outputs), then N candidate "
+                         "copies of the stream, allocated during set-up; the pair the decode kernel runs fastest on is kept (the kernel's "
+                         "time differs by 10-17 %% with WHERE the driver puts the two buffers: DESIGN.md section 4e). 1: the process's "
+                         "first allocation, no selection — the fast level in nine fresh processes in a row on some boxes "
+                         "(profiles/r04_first_allocation.txt), the slow one on another (profiles/r04_bench_first_allocation_slow_box.json); "
+                         "the line reports the first allocation's time either way (value_first_allocation, roofline.frac_first_allocation)")
     ap.add_argument("--apart-gb", type=float, default=24.0,
                     help="the stream and the output are not allocated next to each other: this much device memory is allocated between "
                          "them and freed again (two big buffers allocated one after the other usually land in the same kind of physical "
@@ -447,13 +450,23 @@ def main():
     del spacer
     placement_ms = None
 
-    def kernel_ms(e, o):
-        ms = []
-        for _ in range(3):
-            d.decode_units(e, units_dev, n_units, o)
-            torch.cuda.synchronize(dev)
-            ms.append(d.last_kernel_ms())
-        return round(min(ms[1:]), 4)
+    def rank_candidates(e, outs):
+        # the library's own call for this (include/dint_hip.h: dint_unit_table_rank_outputs): every candidate decoded three
+        # times through a prepared unit table, the faster of the last two launches' kernel times each
+        if not args.per_launch_schedule and hasattr(device, "UnitTable") and hasattr(device.UnitTable, "rank_outputs"):
+            tab = device.UnitTable(d, e, units_dev, n_units, n_ints)
+            ms, _ = tab.rank_outputs(outs)
+            tab.close()
+            return [round(x, 4) for x in ms]
+        res = []
+        for o in outs:
+            ms = []
+            for _ in range(3):
+                d.decode_units(e, units_dev, n_units, o)
+                torch.cuda.synchronize(dev)
+                ms.append(d.last_kernel_ms())
+            res.append(round(min(ms[1:]), 4))
+        return res
 
     def candidates(first, allocate):
         out = [first]
@@ -466,12 +479,12 @@ def main():
 
     if trials > 1:
         outs = candidates(out_dev, allocate_output)
-        ms_out = [kernel_ms(enc_dev, o) for o in outs]
+        ms_out = rank_candidates(enc_dev, outs)
         out_dev = outs[int(np.argmin(ms_out))]
         del outs
         torch.cuda.empty_cache()
         encs = candidates(enc_dev, allocate_stream)
-        ms_enc = [min(ms_out)] + [kernel_ms(e, out_dev) for e in encs[1:]]
+        ms_enc = [min(ms_out)] + [rank_candidates(e, [out_dev])[0] for e in encs[1:]]
         enc_dev = encs[int(np.argmin(ms_enc))]
         del encs
         torch.cuda.empty_cache()

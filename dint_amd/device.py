@@ -29,7 +29,7 @@ _LIB_PATH = os.environ.get("DINT_HIP_LIB") or os.path.join(_HERE, "libdint_hip.s
 ABI_SYMBOLS = (
     "dint_abi_version", "dint_set_option", "dint_get_option", "dint_option_name", "dint_reset_options", "dint_strerror", "dint_last_hip_error", "dint_device_count",
     "dint_dict_create", "dint_dict_destroy", "dint_dict_info_get", "dint_index_stream", "dint_free",
-    "dint_decode_units", "dint_unit_table_create", "dint_unit_table_destroy", "dint_decode_unit_table", "dint_decode_list_host", "dint_last_kernel_ms", "dint_recent_kernel_ms",
+    "dint_decode_units", "dint_unit_table_create", "dint_unit_table_destroy", "dint_decode_unit_table", "dint_unit_table_rank_outputs", "dint_decode_list_host", "dint_last_kernel_ms", "dint_recent_kernel_ms",
     "dint_stream_stats_get",
     "dint_decode_block_host", "dint_index_posting_lists", "dint_decode_posting_blocks",
     "dint_list_cache_create", "dint_list_cache_decode", "dint_list_cache_destroy",
@@ -87,6 +87,7 @@ def _load():
     lib.dint_unit_table_destroy.restype = None
     lib.dint_unit_table_destroy.argtypes = [vp]
     lib.dint_decode_unit_table.argtypes = [vp, vp, vp, sz, vp, vp]
+    lib.dint_unit_table_rank_outputs.argtypes = [vp, vp, C.POINTER(vp), sz, sz, vp, C.POINTER(C.c_float), C.POINTER(sz)]
     lib.dint_decode_list_host.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
     lib.dint_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.dint_last_kernel_clock_mhz.argtypes = [vp, C.POINTER(C.c_float)]
@@ -311,6 +312,20 @@ class UnitTable:
         _check(_lib.dint_decode_unit_table(self._dict._h, self._h, out_dev.data_ptr(), out_dev.numel(),
                                            end_off_dev.data_ptr() if end_off_dev is not None else None, stream),
                "dint_decode_unit_table")
+
+    def rank_outputs(self, outs, stream=None):
+        """dint_unit_table_rank_outputs: decode into every candidate output tensor, -> (kernel ms of each, index of the
+        fastest). The kernel's time depends on where the output lies relative to the stream."""
+        import torch
+
+        if stream is None:
+            stream = torch.cuda.current_stream(outs[0].device).cuda_stream
+        ptrs = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+        ms = (C.c_float * len(outs))()
+        best = C.c_size_t(0)
+        _check(_lib.dint_unit_table_rank_outputs(self._dict._h, self._h, ptrs, len(outs), min(o.numel() for o in outs), stream, ms,
+                                                 C.byref(best)), "dint_unit_table_rank_outputs")
+        return [float(x) for x in ms], int(best.value)
 
 
 def decode_block(dictionary: "Dictionary", buf: np.ndarray, offset: int, sum_of_values: int, n: int):

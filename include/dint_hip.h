@@ -91,7 +91,9 @@ typedef enum dint_option {
                                       /* 0: by a launch of their own                                                             */
     DINT_OPT_CHUNK_SPLIT = 6,         /* the bundle path hands out 1/2^n of a 64-unit chunk per ticket, n = 0..4; -1 (default):  */
                                       /* by the launch's size                                                                   */
-    DINT_OPT_COUNT_ = 7
+    DINT_OPT_INDEX_PAIR = 7,          /* 1 (default): once a table's schedules are known, docs parts, short blocks and freqs     */
+                                      /* parts of a decode are ONE launch; 0: a launch each                                      */
+    DINT_OPT_COUNT_ = 8
 } dint_option;
 int dint_set_option(int option, long long value);
 int dint_get_option(int option, long long* value);
@@ -155,6 +157,15 @@ void dint_unit_table_destroy(dint_unit_table* table);
  * table's (DINT_ERR_ARG otherwise). Results are identical to dint_decode_units'. */
 int dint_decode_unit_table(const dint_dict* dict, dint_unit_table* table, uint32_t* d_out, size_t out_capacity,
                            uint64_t* d_end_off, void* stream);
+/* Where to put the output. The decode kernels run 10-17 % faster or slower depending on where the driver put the
+ * stream they read relative to the output they write — a property of the PAIR of buffers, stable while both live,
+ * which nothing but the decode kernel itself can see. A caller whose
+ * output buffer lives for many decodes allocates a few candidates and lets this rank them: the table is decoded into
+ * every candidate three times, kernel_ms[i] = the faster of the last two launches' kernel times, *fastest = the index
+ * of the smallest. Synchronises `stream`; every candidate holds the decoded integers afterwards.
+ * Replaces: nothing in the reference. */
+int dint_unit_table_rank_outputs(const dint_dict* dict, dint_unit_table* table, uint32_t* const* d_outs, size_t n_outs,
+                                 size_t out_capacity, void* stream, float* kernel_ms, size_t* fastest);
 
 /* Host-pointer convenience with the reference's call shape: decode ONE
  * sequence of n integers starting at in[0]; *consumed = bytes read. Uploads,

@@ -26,9 +26,11 @@ def test_bench_line_contract(extra):
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["bit_exact"] is True and d["value"] > 0 and d["higher_is_better"] is True and d["dtype"] == "u32"
     assert "workload" in d["config"] and "model" not in d["config"]
-    # by default nothing is selected: the two big buffers are the process's first allocation, and the line says so
-    assert d["config"]["placement"].startswith("first allocation") and d["config"]["placement_trial_kernel_ms"] is None
-    assert d["value_first_allocation"] == d["value"] and d["roofline"]["frac_first_allocation"] == d["roofline"]["frac"]
+    # by default the pair of big buffers is chosen among four candidates each (the library's dint_unit_table_rank_outputs);
+    # the line says so, carries every candidate's kernel time and what the process's first allocation reached
+    trials = d["config"]["placement_trial_kernel_ms"]
+    assert "candidate output buffers" in d["config"]["placement"] and len(trials["output_buffers"]) == 4 and len(trials["stream_buffers"]) == 4
+    assert d["roofline"]["kernel_ms_first_allocation"] == trials["output_buffers"][0] and d["value_first_allocation"] > 0
     assert d["config"]["ints_per_gpu_per_step"] >= 6_000_000 * 0.9 and d["config"]["distinct_postings_per_gpu"] * 2 == d["config"]["ints_per_gpu_per_step"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["kernel_launches_timed"] == 3
@@ -41,8 +43,9 @@ def test_bench_line_contract(extra):
 
 
 def test_bench_placement_trials_are_in_the_line():
-    """--placement-trials N > 1: candidate output buffers, then candidate stream buffers, decoded into during set-up; the line
-    carries every candidate's kernel time, which pair was kept, and what the FIRST allocation reached."""
+    """--placement-trials N: candidate output buffers, then candidate stream buffers, decoded into during set-up; the line
+    carries every candidate's kernel time, which pair was kept, and what the FIRST allocation reached. --placement-trials 1:
+    the first allocation and nothing else."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--postings", "3e6",
            "--chunk-postings", "1e6", "--dict-sample", "1e6", "--cpu-seconds", "0", "--placement-trials", "3"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
@@ -53,6 +56,37 @@ def test_bench_placement_trials_are_in_the_line():
     assert len(trials["stream_buffers"]) == 3 and min(trials["stream_buffers"]) <= min(trials["output_buffers"])
     assert d["roofline"]["kernel_ms_first_allocation"] == trials["output_buffers"][0] and d["value_first_allocation"] > 0
     assert d["bit_exact"] is True and d["config"]["distinct_postings_per_gpu"] == d["config"]["ints_per_gpu_per_step"]  # three pieces, one copy
+    r = subprocess.run(cmd[:-1] + ["1"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["config"]["placement"].startswith("first allocation") and d["config"]["placement_trial_kernel_ms"] is None
+    assert d["value_first_allocation"] == d["value"] and d["roofline"]["frac_first_allocation"] == d["roofline"]["frac"]
+
+
+def test_rank_outputs_is_a_library_call(tmp_path):
+    """dint_unit_table_rank_outputs: candidate output buffers for a prepared unit table, each decoded, timed and left holding
+    the decoded integers; the fastest is named."""
+    import numpy as np
+    import torch
+    from dint_amd import device, host
+
+    coll = host.synth_collection(2_000_000, universe=2_000_000, seed=5)
+    kind = host.SINGLE_PACKED
+    dict_file = host.build_dictionary(kind, coll, max_sample_ints=1_000_000)
+    enc, units = host.encode_vroom(kind, dict_file, coll, unit_ints=4096)
+    dev = torch.device("cuda", 0)
+    d = device.Dictionary(kind, dict_file)
+    enc_dev = torch.from_numpy(enc).to(dev)
+    units_dev = device.units_to_device(units, dev)
+    table = device.UnitTable(d, enc_dev, units_dev, len(units), coll.num_postings)
+    outs = [torch.full((coll.num_postings,), -1, dtype=torch.int32, device=dev) for _ in range(3)]
+    ms, best = table.rank_outputs(outs)
+    assert len(ms) == 3 and all(m > 0 for m in ms) and ms[best] == min(ms)
+    for o in outs:
+        assert np.array_equal(o.cpu().numpy().view(np.uint32), coll.gaps)
+    with pytest.raises(device.DintError):
+        table.rank_outputs([torch.empty(coll.num_postings - 1, dtype=torch.int32, device=dev)])
+    table.close()
 
 
 @pytest.mark.parametrize("k", [0, 3, 7])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """In-index decode: every posting of an index in the dict_posting_list layout
 -> docIDs and freqs on the device, through a prepared block table (dint_block_table), timed with HIP events
-around the enqueued launches. usage: tools/inindex_bench.py [postings] [out.json]"""
+around the enqueued launches. usage: tools/inindex_bench.py [postings] [out.json] [option=value ...]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT]
@@ -10,6 +10,9 @@ from dint_amd import host, device
 
 postings = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100_000_000
 out_path = sys.argv[2] if len(sys.argv) > 2 else None
+for kv in sys.argv[3:]:  # library options, e.g. index_pair=1 index_inline_tails=0 (dint_set_option)
+    k, v = kv.split("=")
+    device.set_option(k, int(v))
 TRIALS = int(os.environ.get("PLACEMENT_TRIALS", "4"))
 dev = torch.device("cuda:0")
 sub = host.synth_collection(postings, universe=25_000_000, seed=777)
