@@ -213,3 +213,58 @@ def test_short_blocks_inside_the_docs_launch_or_in_their_own(device, small_corpu
             else:
                 assert (f == -9).all()
         table.close()
+
+
+@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
+def test_blocks_that_fit_no_tile_take_the_second_launch(device, small_corpus, kind):
+    """A full block whose 256 postings are nearly all exceptions is more than 504 bytes and fits no tile: the bundle schedule
+    leaves it to the unit queue, and once a prepared table's schedules are known such stragglers go through a small second
+    launch of the general kernel while everything else runs the kernels compiled without the queue (one launch for docs +
+    short blocks + freqs). Three lists of 700 gaps of 70 000 and more each — 32-bit literals, six bytes a posting — among an
+    ordinary collection; five decodes (the pair launch from the third), against the encoder's input and the oracle's walk."""
+    import torch
+
+    coll = small_corpus.coll
+    r = np.random.default_rng(99)
+    extra = [r.integers(70_000, 400_000, 700, dtype=np.uint64).astype(np.uint32) for _ in range(3)]
+    where = [5, len(coll.lens) // 2, len(coll.lens) - 3]   # the stragglers' lists among the others
+    b = coll.list_bounds()
+    gaps_parts, lens = [], []
+    for i in range(len(coll.lens)):
+        for w, e in zip(where, extra):
+            if i == w:
+                gaps_parts.append(e)
+                lens.append(len(e))
+        gaps_parts.append(coll.gaps[int(b[i]):int(b[i + 1])])
+        lens.append(int(coll.lens[i]))
+    big = host.Collection(np.concatenate(gaps_parts), np.asarray(lens, dtype=coll.lens.dtype))
+    docids = host.gaps_to_docids(big)
+    freqs = host.synth_freqs(big.num_postings, 4)
+    docs_dict = small_corpus.dict_file(kind)
+    freqs_dict = host.build_dictionary(kind, host.Collection(freqs - 1, big.lens))
+    idx, offs = host.build_index(kind, docs_dict, freqs_dict, docids, freqs, big.lens)
+    blocks, total = device.index_posting_lists(idx, offs)
+    spans = np.diff(np.r_[blocks["in_off"], idx.size].astype(np.int64))
+    assert ((blocks["n"] == 256) & (spans > 1200)).sum() >= 6, "no block too long for a tile in this index"
+    dd, fd = device.Dictionary(kind, docs_dict), device.Dictionary(kind, freqs_dict)
+    dev = torch.device("cuda", 0)
+    padded = np.concatenate([idx, np.zeros(16, np.uint8)])
+    index_dev = torch.from_numpy(padded).to(dev)
+    table = device.BlockTable(dd, blocks, padded.size)
+    for i in range(5):
+        docids_dev = torch.full((total + 256,), -3, dtype=torch.int32, device=dev)
+        freqs_dev = torch.full((total + 256,), -3, dtype=torch.int32, device=dev)
+        table.decode(dd, fd, index_dev, padded.size, docids_dev[:total], freqs_dev[:total])
+        torch.cuda.synchronize()
+        d, f = docids_dev.cpu().numpy(), freqs_dev.cpu().numpy()
+        assert np.array_equal(d[:total].view(np.uint32), docids), i
+        assert np.array_equal(f[:total].view(np.uint32), freqs), i
+        assert (d[total:] == -3).all() and (f[total:] == -3).all()
+    table.close()
+    od, of = oracle.OracleDict(kind, docs_dict), oracle.OracleDict(kind, freqs_dict)
+    bounds = big.list_bounds()
+    for w in where:  # (the inserted lists sit at positions where[k] + k)
+        i = w + where.index(w)
+        dl, fl = oracle.posting_list_decode(od, of, idx, int(offs[i]))
+        lo, hi = int(bounds[i]), int(bounds[i + 1])
+        assert hi - lo == 700 and np.array_equal(docids[lo:hi], dl) and np.array_equal(freqs[lo:hi], fl)
