@@ -268,3 +268,57 @@ def test_blocks_that_fit_no_tile_take_the_second_launch(device, small_corpus, ki
         dl, fl = oracle.posting_list_decode(od, of, idx, int(offs[i]))
         lo, hi = int(bounds[i]), int(bounds[i + 1])
         assert hi - lo == 700 and np.array_equal(docids[lo:hi], dl) and np.array_equal(freqs[lo:hi], fl)
+
+
+@pytest.mark.parametrize("inline_tails", [0, 1])
+@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
+def test_blocks_the_expansion_leaves_as_gaps_become_docids_on_the_spot(device, kind, inline_tails):
+    """Blocks the expansion cannot turn into docIDs on the fly — a dictionary entry holding a value >= 65536 (a constant
+    stride of 70000: the dictionary learns runs of 69999: slow codewords), or more than 256 slots in the block (every gap a
+    32-bit exception: two tiles) — are summed by the wave that decoded them, behind its own stores (gaps_to_docids_here):
+    in a bundle, in a segment, in the stragglers' launch. No flags are left, no fix-up launch follows. Five decodes of a
+    prepared table (the one launch from the third), docs + freqs and docs only."""
+    import torch
+
+    r = np.random.default_rng(77)
+    stride = (np.arange(700, dtype=np.uint64) * 70000).astype(np.uint32)
+    wild = np.cumsum(r.integers(100000, 3000000, 700, dtype=np.uint64)).astype(np.uint32)
+    both = np.union1d(stride, wild).astype(np.uint32)
+    dense = np.arange(0, 2_000_000, 7, dtype=np.uint32)
+    mixed = np.union1d(stride[:300], np.arange(5, 40_000, 3, dtype=np.uint32)).astype(np.uint32)  # slow codewords among ordinary ones
+    lists = [stride, wild, both, dense, mixed, stride[:256], wild[:255]]
+    docids = np.concatenate(lists)
+    lens = np.array([len(x) for x in lists], dtype=np.uint32)
+    gaps = np.concatenate([host.docids_to_gaps(x) for x in lists])
+    coll = host.Collection(gaps, lens)
+    freqs = (1 + (np.arange(docids.size, dtype=np.uint32) % 3)).astype(np.uint32)
+    dd_file = host.build_dictionary(kind, coll)
+    fd_file = host.build_dictionary(kind, host.Collection(freqs - 1, lens))
+    idx, offs = host.build_index(kind, dd_file, fd_file, docids, freqs, lens)
+    blocks, total = device.index_posting_lists(idx, offs)
+    assert total == docids.size
+    dd, fd = device.Dictionary(kind, dd_file), device.Dictionary(kind, fd_file)
+    dev = torch.device("cuda", 0)
+    padded = np.concatenate([idx, np.zeros(16, np.uint8)])
+    index_dev = torch.from_numpy(padded).to(dev)
+    with device.options(index_inline_tails=inline_tails):
+        table = device.BlockTable(dd, blocks, padded.size)
+        for i in range(5):
+            with_freqs = i != 1
+            docids_dev = torch.full((total + 256,), -3, dtype=torch.int32, device=dev)
+            freqs_dev = torch.full((total + 256,), -3, dtype=torch.int32, device=dev)
+            table.decode(dd, fd if with_freqs else None, index_dev, padded.size, docids_dev[:total], freqs_dev[:total] if with_freqs else None)
+            torch.cuda.synchronize()
+            d, f = docids_dev.cpu().numpy(), freqs_dev.cpu().numpy()
+            assert np.array_equal(d[:total].view(np.uint32), docids), i
+            assert (d[total:] == -3).all()
+            if with_freqs:
+                assert np.array_equal(f[:total].view(np.uint32), freqs), i
+        table.close()
+    # the one-shot call (no prepared table: general kernels, the short blocks by a launch of their own)
+    d1, f1 = device.decode_posting_lists(dd, fd, idx, blocks, total)
+    assert np.array_equal(d1, docids) and np.array_equal(f1, freqs)
+    od, of = oracle.OracleDict(kind, dd_file), oracle.OracleDict(kind, fd_file)
+    for i in range(len(lists)):
+        dl, fl = oracle.posting_list_decode(od, of, idx, int(offs[i]))
+        assert np.array_equal(dl, lists[i])
