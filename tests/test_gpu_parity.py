@@ -461,3 +461,45 @@ def test_two_shards_two_handles_two_streams(device, kind):
     assert np.array_equal(np.concatenate([j["out"].cpu().numpy().view(np.uint32) for j in jobs]), whole)
     for j in jobs:
         j["table"].close()
+
+
+@pytest.mark.parametrize("split", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("kind", [host.MULTI_PACKED, host.SINGLE_PACKED])
+def test_every_ticket_size_decodes_the_same(device, small_corpus, kind, split):
+    """The bundle path hands out 1/2^n of a 64-unit chunk per ticket (32 counters, contiguous ranges, stealing); n follows the
+    launch's size unless dint_set_option(chunk_split) says otherwise. Every n decodes a block-granular multi-dictionary
+    stream (bundles and nothing else) and an in-index table (three decodes: general kernel, then the kernels without the
+    unit queue) to the same integers."""
+    import torch
+    from test_index_cpu import get_index
+
+    dev = torch.device("cuda", 0)
+    with device.options(chunk_split=split):
+        if kind == host.MULTI_PACKED:
+            dict_file = small_corpus.dict_file(kind)
+            enc, units = host.encode_vroom(kind, dict_file, small_corpus.coll, unit_ints=256)
+            d = device.Dictionary(kind, dict_file)
+            enc_dev = torch.from_numpy(enc).to(dev)
+            units_dev = device.units_to_device(units, dev)
+            table = device.UnitTable(d, enc_dev, units_dev, len(units), small_corpus.coll.num_postings)
+            for _ in range(2):
+                out_dev = torch.full((small_corpus.coll.num_postings + 64,), -1, dtype=torch.int32, device=dev)
+                table.decode(out_dev[:small_corpus.coll.num_postings], None)
+                torch.cuda.synchronize()
+                got = out_dev.cpu().numpy()
+                assert np.array_equal(got[:-64].view(np.uint32), small_corpus.coll.gaps) and (got[-64:] == -1).all()
+            table.close()
+        ix = get_index(small_corpus, kind)
+        blocks, total = device.index_posting_lists(ix.bytes, ix.offsets)
+        dd, fd = device.Dictionary(kind, ix.docs_dict), device.Dictionary(kind, ix.freqs_dict)
+        padded = np.concatenate([ix.bytes, np.zeros(16, np.uint8)])
+        index_dev = torch.from_numpy(padded).to(dev)
+        bt = device.BlockTable(dd, blocks, padded.size)
+        for i in range(4):
+            docids_dev = torch.full((total,), -1, dtype=torch.int32, device=dev)
+            freqs_dev = torch.full((total,), -1, dtype=torch.int32, device=dev)
+            bt.decode(dd, fd, index_dev, padded.size, docids_dev, freqs_dev)
+            torch.cuda.synchronize()
+            assert np.array_equal(docids_dev.cpu().numpy().view(np.uint32), ix.docids), i
+            assert np.array_equal(freqs_dev.cpu().numpy().view(np.uint32), ix.freqs), i
+        bt.close()
