@@ -245,10 +245,13 @@ void dint_block_table_destroy(dint_block_table* table);
  * frequencies). ASYNCHRONOUS: enqueues on `stream` and returns. Full blocks go through the DINT kernels —
  * the docID prefix sums are formed in the expansion, one wave scan per block, the gaps never reach memory;
  * freq = value + 1 is added where the values are stored — blocks shorter than 256 through the
- * binary-interpolative decoder (whose code is the prefix sums already). From a table's second decode on, the freqs
- * launch and the short blocks' decoder run on streams the table owns, beside the docs launch, forked from and joined
- * to `stream` inside the call: to the caller everything is ordered on `stream` as before
- * (dint_set_option(DINT_OPT_INDEX_CONCURRENT, 0): one stream).
+ * binary-interpolative decoder (whose code is the prefix sums already). A table learns as it is used: its first decode
+ * finds where the docs parts end, its second builds the bundle schedules, and from the third on a decode is ONE launch
+ * for the docs parts, the short blocks (inside it, by the waves' first lanes) and the freqs parts
+ * (DINT_OPT_INDEX_PAIR, DINT_OPT_INDEX_INLINE_TAILS; plus a small launch for the few blocks that fit no tile). Before
+ * that — and with those options off — the freqs launch and the short blocks' decoder run on streams the table owns,
+ * beside the docs launch, forked from and joined to `stream` inside the call; to the caller everything is ordered on
+ * `stream` either way (dint_set_option(DINT_OPT_INDEX_CONCURRENT, 0): one stream, one launch after the other).
  * CONTENT STABILITY: what the table learns in its first complete decode (exact byte spans, the freqs parts' units, both
  * bundle schedules — which bake in the blocks' selector bytes of a multi-dictionary index) is kept and keyed by the
  * dictionaries, the index POINTER and its size, not by the bytes: while the table lives, the index at d_index must keep
