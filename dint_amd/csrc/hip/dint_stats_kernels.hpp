@@ -39,10 +39,11 @@ __device__ __forceinline__ uint64_t murmur64a_u32s(const uint32_t* p, uint32_t n
     return h;
 }
 
-// context of a block = ceil_log2(ceil_log2(max + 1)), 0 when max <= 1 (statistics_collectors.hpp:21-40)
+// context of a block = ceil_log2(ceil_log2(max + 1)), 0 when max <= 1 (statistics_collectors.hpp:21-40); the + 1 in 32 bits,
+// as there (:23,36): a block holding 0xFFFFFFFF is context 0
 __device__ __forceinline__ uint32_t ceil_log2_dev(uint64_t x) { return x <= 1 ? 0u : 64u - uint32_t(__builtin_clzll(x - 1)); }
 __device__ __forceinline__ uint32_t block_context(uint32_t max_value) {
-    return max_value > 1 ? ceil_log2_dev(ceil_log2_dev(uint64_t(max_value) + 1)) : 0u;
+    return max_value > 1 ? ceil_log2_dev(ceil_log2_dev(uint32_t(max_value + 1u))) : 0u;
 }
 
 struct ngram_table {

@@ -2,7 +2,7 @@
 //
 //   bit_writer::write / write_int / write_interpolative   reference include/ds2i/interpolative_coding.hpp:10-77
 //   interpolative_block::encode                            reference include/ds2i/block_codecs.hpp:104-128
-//   opt_dint_single_dict_block / opt_dint_multi_dict_block::encode (blocks of 256: the same optimal parse as
+//   opt_dint_single_dict_block / greedy_dint_single_dict_block / opt_dint_multi_dict_block::encode (blocks of 256: the same optimal parse as
 //     the whole-list coders; shorter blocks: interpolative)  reference include/dint/dint_codecs.hpp:145-267, 289-458
 //   dict_posting_list::write                               reference include/dint/dict_posting_list.hpp:10-56
 //
@@ -90,6 +90,20 @@ struct opt_dint_single_dict_block {
             return;
         }
         detail::optimal_parse([&](uint32_t const* p, uint32_t len) { return builder.lookup(p, len); }, in, n, 16, out);
+    }
+};
+
+// greedy_dint_single_dict_block (include/dint/dint_codecs.hpp:52-139): longest match first
+struct greedy_dint_single_dict_block {
+    static constexpr uint64_t block_size = kBlockSize;
+    template <typename Builder>
+    static void encode(Builder& builder, uint32_t const* in, uint32_t sum_of_values, uint32_t n,
+                       std::vector<uint8_t>& out) {
+        if (n < block_size) {
+            interpolative_block::encode(in, sum_of_values, n, out);
+            return;
+        }
+        detail::greedy_parse([&](uint32_t const* p, uint32_t len) { return builder.lookup(p, len); }, in, n, out);
     }
 };
 

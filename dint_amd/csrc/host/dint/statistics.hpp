@@ -17,6 +17,8 @@
 #include <cmath>
 #include <cstdint>
 #include <unordered_map>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "constants.hpp"
@@ -29,11 +31,13 @@ inline uint32_t ceil_log2_u64(uint64_t x) {  // util.hpp:61-64
     return 64 - uint32_t(__builtin_clzll(x - 1));
 }
 
-// context of a block = ceil_log2(ceil_log2(max + 1)), 0 when max <= 1
+// context of a block = ceil_log2(ceil_log2(max + 1)), 0 when max <= 1. The reference adds the 1 in 32 bits
+// (statistics_collectors.hpp:23,36): a block holding 0xFFFFFFFF wraps to ceil_log2(0) = 0 and is context 0 there,
+// so it is here.
 inline uint32_t block_selector(uint32_t const* p, size_t n) {
     uint32_t x = 0;
     for (size_t i = 0; i != n; ++i) x = std::max(x, p[i]);
-    return x > 1 ? ceil_log2_u64(ceil_log2_u64(uint64_t(x) + 1)) : 0;
+    return x > 1 ? ceil_log2_u64(ceil_log2_u64(uint32_t(x + 1u))) : 0;
 }
 
 struct ngram_stat {
@@ -145,6 +149,36 @@ void build_dsf(Builder& builder, ngram_statistics const& stats) {
             builder.append(picked[i].data.data(), uint32_t(picked[i].data.size()), c);
     }
     builder.build();
+}
+
+// block_statistics / block_multi_statistics construction (block_statistics.hpp:45-108, :201-279) over any list source,
+// in parallel: list i has len_of(i) integers, gaps_of(i, scratch) returns them. One collector per worker, merged at the end
+// (a count is a sum: the result does not depend on the split).
+template <typename LenOf, typename GapsOf>
+ngram_statistics collect_statistics(bool multi, uint64_t n_lists, LenOf&& len_of, GapsOf&& gaps_of, int threads) {
+    const uint32_t contexts = multi ? kNumSelectors : 1;
+    const int workers = std::max(1, threads);
+    std::vector<ngram_statistics> partial(static_cast<size_t>(workers), ngram_statistics{contexts});
+    std::atomic<uint64_t> next{0};
+    std::vector<std::thread> pool;
+    for (int w = 0; w != workers; ++w) {
+        pool.emplace_back([&, w] {
+            std::vector<uint32_t> scratch;
+            for (uint64_t i; (i = next.fetch_add(1)) < n_lists;) {
+                const size_t n = size_t(len_of(i));
+                if (n == 0) continue;  // constants::min_size = 0: n > 0 only
+                uint32_t const* g = gaps_of(i, scratch);
+                if (multi) partial[size_t(w)].collect_multi(g, n);
+                else partial[size_t(w)].collect_single(g, n);
+            }
+        });
+    }
+    for (auto& t : pool) t.join();
+    for (int w = 1; w < workers; ++w) {
+        partial[0].merge(partial[size_t(w)]);
+        partial[size_t(w)] = ngram_statistics(contexts);
+    }
+    return std::move(partial[0]);
 }
 
 inline std::string dsf_type_name() {

@@ -11,6 +11,7 @@
 #include <thread>
 #include <vector>
 
+#include "binary_collection.hpp"
 #include "dint_hip.h"
 #include "encoders.hpp"
 #include "vbyte.hpp"
@@ -39,13 +40,14 @@ void parallel_for(size_t n_tasks, int threads, Fn&& fn) {
     for (auto& th : pool) th.join();
 }
 
-// gaps: all lists back to back; lens[i] = length of list i (zero-length lists are
-// skipped, as binary_collection does — include/ds2i/binary_collection.hpp:138).
-template <typename Encoder, typename Builder>
-vroom_output encode_vroom(Builder& builder, uint32_t const* gaps, uint32_t const* lens, uint64_t n_lists,
-                          uint32_t unit_ints, int threads) {
+// The engine: list i has len_of(i) integers and gaps_of(i, scratch) returns them (a pointer into the caller's
+// memory, or into `scratch` after filling it). Zero-length lists are skipped, as binary_collection does
+// (include/ds2i/binary_collection.hpp:138).
+template <typename Encoder, typename Builder, typename LenOf, typename GapsOf>
+vroom_output encode_vroom_lists(Builder& builder, uint64_t n_lists, LenOf&& len_of, GapsOf&& gaps_of, uint32_t unit_ints,
+                                int threads) {
     struct task {
-        uint64_t first_list, last_list, first_int;
+        uint64_t first_list, last_list;
         std::vector<uint8_t> bytes;
         std::vector<dint_unit> units;  // offsets relative to the task
         uint64_t ints = 0;
@@ -53,26 +55,24 @@ vroom_output encode_vroom(Builder& builder, uint32_t const* gaps, uint32_t const
     std::vector<task> tasks;
     {
         const uint64_t ints_per_task = 1u << 20;
-        uint64_t pos = 0, acc = 0, first = 0, first_int = 0;
+        uint64_t acc = 0, first = 0;
         for (uint64_t i = 0; i != n_lists; ++i) {
-            acc += lens[i];
-            pos += lens[i];
+            acc += len_of(i);
             if (acc >= ints_per_task || i + 1 == n_lists) {
-                tasks.push_back({first, i + 1, first_int, {}, {}, 0});
+                tasks.push_back({first, i + 1, {}, {}, 0});
                 first = i + 1;
-                first_int = pos;
                 acc = 0;
             }
         }
     }
     parallel_for(tasks.size(), threads, [&](size_t t) {
         auto& tk = tasks[t];
-        uint64_t pos = tk.first_int;
         std::vector<sync_point> syncs;
+        std::vector<uint32_t> scratch;
         for (uint64_t i = tk.first_list; i != tk.last_list; ++i) {
-            uint32_t n = lens[i];
+            uint32_t n = uint32_t(len_of(i));
             if (n == 0) continue;
-            uint32_t const* in = gaps + pos;
+            uint32_t const* in = gaps_of(i, scratch);
             uint32_t universe = 0;
             for (uint32_t k = 0; k != n; ++k) universe += in[k];
             list_header::write(n, universe, tk.bytes);
@@ -89,7 +89,6 @@ vroom_output encode_vroom(Builder& builder, uint32_t const* gaps, uint32_t const
                 }
             }
             tk.ints += n;
-            pos += n;
         }
     });
     vroom_output out;
@@ -113,6 +112,35 @@ vroom_output encode_vroom(Builder& builder, uint32_t const* gaps, uint32_t const
         std::vector<dint_unit>().swap(tk.units);
     }
     return out;
+}
+
+// gaps: all lists back to back; lens[i] = length of list i.
+template <typename Encoder, typename Builder>
+vroom_output encode_vroom(Builder& builder, uint32_t const* gaps, uint32_t const* lens, uint64_t n_lists,
+                          uint32_t unit_ints, int threads) {
+    std::vector<uint64_t> starts(n_lists + 1, 0);
+    for (uint64_t i = 0; i != n_lists; ++i) starts[i + 1] = starts[i] + lens[i];
+    return encode_vroom_lists<Encoder>(
+        builder, n_lists, [&](uint64_t i) { return lens[i]; },
+        [&](uint64_t i, std::vector<uint32_t>&) { return gaps + starts[i]; }, unit_ints, threads);
+}
+
+// The vroom `encode` program's loop (vroom_env/encode.cpp:133-191, jobs.hpp:74-95) over a collection file:
+// docs = true: a .docs file — record 0 (the number of documents) is skipped, docIDs become d-gaps minus one;
+// docs = false: a .freqs file, every value minus one.
+template <typename Encoder, typename Builder>
+vroom_output encode_vroom_collection(Builder& builder, binary_collection const& input, bool docs, uint32_t unit_ints,
+                                     int threads) {
+    auto lists = input.sequences();
+    if (docs && !lists.empty()) lists.erase(lists.begin());
+    return encode_vroom_lists<Encoder>(
+        builder, lists.size(), [&](uint64_t i) { return lists[i].size(); },
+        [&](uint64_t i, std::vector<uint32_t>& scratch) {
+            scratch.resize(lists[i].size());
+            list_to_gaps(lists[i], docs, scratch.data());
+            return static_cast<uint32_t const*>(scratch.data());
+        },
+        unit_ints, threads);
 }
 
 }  // namespace dint

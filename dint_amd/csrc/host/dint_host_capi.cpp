@@ -4,8 +4,10 @@
 #include <cstring>
 #include <exception>
 #include <string>
+#include <utility>
 #include <vector>
 
+#include "dint/binary_collection.hpp"
 #include "dint/dictionaries.hpp"
 #include "dint/encoders.hpp"
 #include "dint/posting_list.hpp"
@@ -69,27 +71,11 @@ int build_dictionary(bool multi, uint32_t const* gaps, uint32_t const* lens, uin
     }
     std::vector<uint64_t> starts(n_sample_lists + 1, 0);
     for (uint64_t i = 0; i != n_sample_lists; ++i) starts[i + 1] = starts[i] + lens[i];
-    uint32_t contexts = multi ? kNumSelectors : 1;
-    int workers = std::max(1, threads);
-    std::vector<ngram_statistics> partial(workers, ngram_statistics(contexts));
-    std::atomic<uint64_t> next{0};
-    std::vector<std::thread> pool;
-    for (int w = 0; w != workers; ++w) {
-        pool.emplace_back([&, w] {
-            for (uint64_t i; (i = next.fetch_add(1)) < n_sample_lists;) {
-                if (lens[i] == 0) continue;  // constants::min_size = 0: n > 0 only
-                if (multi) partial[w].collect_multi(gaps + starts[i], lens[i]);
-                else partial[w].collect_single(gaps + starts[i], lens[i]);
-            }
-        });
-    }
-    for (auto& t : pool) t.join();
-    for (int w = 1; w < workers; ++w) {
-        partial[0].merge(partial[w]);
-        partial[w] = ngram_statistics(contexts);
-    }
+    auto stats = collect_statistics(
+        multi, n_sample_lists, [&](uint64_t i) { return lens[i]; },
+        [&](uint64_t i, std::vector<uint32_t>&) { return gaps + starts[i]; }, threads);
     Builder builder;
-    build_dsf(builder, partial[0]);
+    build_dsf(builder, stats);
     auto b = new dinth_blob;
     builder.write(b->bytes);
     *out = b;
@@ -156,25 +142,24 @@ int encode_with(void const* dict_file, size_t dict_len, uint32_t const* gaps, ui
 }  // namespace
 
 namespace {
-template <typename Coder, typename Builder>
-int build_index(const void* docs_dict, size_t docs_len, const void* freqs_dict, size_t freqs_len,
-                const uint32_t* docids, const uint32_t* freqs, const uint32_t* lens, uint64_t n_lists, int threads,
-                dinth_blob** index, dinth_blob** offsets) {
+// list i: n = len_of(i) postings, lists_of(i) -> (docIDs, freqs)
+template <typename Coder, typename Builder, typename LenOf, typename ListsOf>
+int build_index_lists(const void* docs_dict, size_t docs_len, const void* freqs_dict, size_t freqs_len, uint64_t n_lists,
+                      LenOf&& len_of, ListsOf&& lists_of, int threads, dinth_blob** index, dinth_blob** offsets) {
     Builder docs_builder, freqs_builder;
     docs_builder.load(static_cast<uint8_t const*>(docs_dict), docs_len);
     freqs_builder.load(static_cast<uint8_t const*>(freqs_dict), freqs_len);
     docs_builder.prepare_for_encoding();
     freqs_builder.prepare_for_encoding();
-    std::vector<uint64_t> starts(n_lists + 1, 0);
-    for (uint64_t i = 0; i != n_lists; ++i) starts[i + 1] = starts[i] + lens[i];
     std::vector<std::vector<uint8_t>> encoded(n_lists);
     const uint64_t group = 16;
     dint::parallel_for((n_lists + group - 1) / group, threads, [&](size_t g) {
         uint64_t end = std::min<uint64_t>(n_lists, (g + 1) * group);
         for (uint64_t i = g * group; i != end; ++i) {
-            if (lens[i] == 0) continue;
-            dint::write_posting_list<Coder>(docs_builder, freqs_builder, encoded[i], lens[i], docids + starts[i],
-                                            freqs + starts[i]);
+            const uint32_t n = uint32_t(len_of(i));
+            if (n == 0) continue;
+            auto lists = lists_of(i);
+            dint::write_posting_list<Coder>(docs_builder, freqs_builder, encoded[i], n, lists.first, lists.second);
         }
     });
     auto idx = new dinth_blob;
@@ -187,6 +172,77 @@ int build_index(const void* docs_dict, size_t docs_len, const void* freqs_dict, 
     offs[n_lists] = idx->bytes.size();
     *index = idx;
     *offsets = blob_of(offs);
+    return DINT_OK;
+}
+
+// the Coder / Builder pair of a dictionary kind (reference include/index_types.hpp:73-79; greedy: dint_codecs.hpp:52-139)
+template <typename LenOf, typename ListsOf>
+int build_index_kind(int kind, int greedy, const void* docs_dict, size_t docs_len, const void* freqs_dict, size_t freqs_len,
+                     uint64_t n_lists, LenOf&& len_of, ListsOf&& lists_of, int threads, dinth_blob** index, dinth_blob** offsets) {
+    using namespace dint;
+    switch (kind) {
+        case DINT_DICT_RECTANGULAR:
+            return greedy ? build_index_lists<greedy_dint_single_dict_block, rectangular_builder>(
+                                docs_dict, docs_len, freqs_dict, freqs_len, n_lists, len_of, lists_of, threads, index, offsets)
+                          : build_index_lists<opt_dint_single_dict_block, rectangular_builder>(
+                                docs_dict, docs_len, freqs_dict, freqs_len, n_lists, len_of, lists_of, threads, index, offsets);
+        case DINT_DICT_SINGLE_PACKED:
+            return greedy ? build_index_lists<greedy_dint_single_dict_block, single_packed_builder>(
+                                docs_dict, docs_len, freqs_dict, freqs_len, n_lists, len_of, lists_of, threads, index, offsets)
+                          : build_index_lists<opt_dint_single_dict_block, single_packed_builder>(
+                                docs_dict, docs_len, freqs_dict, freqs_len, n_lists, len_of, lists_of, threads, index, offsets);
+        case DINT_DICT_MULTI_PACKED:
+            return build_index_lists<opt_dint_multi_dict_block, multi_packed_builder>(
+                docs_dict, docs_len, freqs_dict, freqs_len, n_lists, len_of, lists_of, threads, index, offsets);
+        default:
+            return int(DINT_ERR_ARG);
+    }
+}
+
+template <typename Encoder, typename Builder>
+int encode_collection_with(void const* dict_file, size_t dict_len, dint::binary_collection const& input, bool docs,
+                           uint32_t unit_ints, int threads, dinth_blob** enc, dinth_blob** units, uint64_t* n_lists,
+                           uint64_t* n_ints) {
+    Builder builder;
+    builder.load(static_cast<uint8_t const*>(dict_file), dict_len);
+    builder.prepare_for_encoding();
+    auto out = dint::encode_vroom_collection<Encoder>(builder, input, docs, unit_ints, threads);
+    if (n_ints) *n_ints = out.total_ints;
+    if (n_lists) {
+        auto lists = input.sequences();
+        *n_lists = lists.size() - ((docs && !lists.empty()) ? 1 : 0);
+    }
+    auto e = new dinth_blob;
+    e->bytes.swap(out.bytes);
+    *enc = e;
+    if (units) *units = blob_of(out.units);
+    return DINT_OK;
+}
+
+template <typename Builder>
+int build_dictionary_collection(bool multi, dint::binary_collection const& input, bool docs, uint64_t max_sample_ints,
+                                int threads, dinth_blob** out) {
+    using namespace dint;
+    auto lists = input.sequences();
+    if (docs && !lists.empty()) lists.erase(lists.begin());  // the number of documents (block_statistics.hpp:57-60)
+    uint64_t n_sample = 0, ints = 0;
+    for (; n_sample != lists.size(); ++n_sample) {
+        if (max_sample_ints && n_sample && ints + lists[n_sample].size() > max_sample_ints) break;
+        ints += lists[n_sample].size();
+    }
+    auto stats = collect_statistics(
+        multi, n_sample, [&](uint64_t i) { return lists[i].size(); },
+        [&](uint64_t i, std::vector<uint32_t>& scratch) {
+            scratch.resize(lists[i].size());
+            list_to_gaps(lists[i], docs, scratch.data());
+            return static_cast<uint32_t const*>(scratch.data());
+        },
+        threads);
+    Builder builder;
+    build_dsf(builder, stats);
+    auto b = new dinth_blob;
+    builder.write(b->bytes);
+    *out = b;
     return DINT_OK;
 }
 }  // namespace
@@ -318,29 +374,93 @@ int dinth_encode_vroom(int kind, int greedy, const void* dict_file, size_t dict_
     });
 }
 
-int dinth_build_index(int kind, const void* docs_dict_file, size_t docs_dict_len, const void* freqs_dict_file,
-                      size_t freqs_dict_len, const uint32_t* docids, const uint32_t* freqs, const uint32_t* lens,
-                      uint64_t n_lists, int threads, dinth_blob** index, dinth_blob** offsets) {
+int dinth_build_index_coder(int kind, int greedy, const void* docs_dict_file, size_t docs_dict_len, const void* freqs_dict_file,
+                            size_t freqs_dict_len, const uint32_t* docids, const uint32_t* freqs, const uint32_t* lens,
+                            uint64_t n_lists, int threads, dinth_blob** index, dinth_blob** offsets) {
     if (!docs_dict_file || !freqs_dict_file || !index || !offsets || (n_lists && (!docids || !freqs || !lens)))
         return DINT_ERR_ARG;
     return guarded([&] {
+        std::vector<uint64_t> starts(n_lists + 1, 0);
+        for (uint64_t i = 0; i != n_lists; ++i) starts[i + 1] = starts[i] + lens[i];
+        return build_index_kind(
+            kind, greedy, docs_dict_file, docs_dict_len, freqs_dict_file, freqs_dict_len, n_lists,
+            [&](uint64_t i) { return lens[i]; },
+            [&](uint64_t i) { return std::make_pair(docids + starts[i], freqs + starts[i]); }, threads, index, offsets);
+    });
+}
+
+int dinth_build_index(int kind, const void* docs_dict_file, size_t docs_dict_len, const void* freqs_dict_file,
+                      size_t freqs_dict_len, const uint32_t* docids, const uint32_t* freqs, const uint32_t* lens,
+                      uint64_t n_lists, int threads, dinth_blob** index, dinth_blob** offsets) {
+    return dinth_build_index_coder(kind, 0, docs_dict_file, docs_dict_len, freqs_dict_file, freqs_dict_len, docids, freqs, lens,
+                                   n_lists, threads, index, offsets);
+}
+
+int dinth_encode_collection(int kind, int greedy, const void* dict_file, size_t dict_len, const uint32_t* words, size_t n_words,
+                            int docs, uint32_t unit_ints, int threads, dinth_blob** enc, dinth_blob** units, uint64_t* n_lists,
+                            uint64_t* n_ints) {
+    if (!dict_file || !enc || (n_words && !words)) return DINT_ERR_ARG;
+    return guarded([&] {
         using namespace dint;
+        binary_collection input(words, n_words);
         switch (kind) {
             case DINT_DICT_RECTANGULAR:
-                return build_index<opt_dint_single_dict_block, rectangular_builder>(
-                    docs_dict_file, docs_dict_len, freqs_dict_file, freqs_dict_len, docids, freqs, lens, n_lists,
-                    threads, index, offsets);
+                return greedy ? encode_collection_with<single_greedy_dint, rectangular_builder>(dict_file, dict_len, input, docs != 0,
+                                                                                                unit_ints, threads, enc, units, n_lists, n_ints)
+                              : encode_collection_with<single_opt_dint, rectangular_builder>(dict_file, dict_len, input, docs != 0,
+                                                                                             unit_ints, threads, enc, units, n_lists, n_ints);
             case DINT_DICT_SINGLE_PACKED:
-                return build_index<opt_dint_single_dict_block, single_packed_builder>(
-                    docs_dict_file, docs_dict_len, freqs_dict_file, freqs_dict_len, docids, freqs, lens, n_lists,
-                    threads, index, offsets);
+                return greedy ? encode_collection_with<single_greedy_dint, single_packed_builder>(dict_file, dict_len, input, docs != 0,
+                                                                                                  unit_ints, threads, enc, units, n_lists, n_ints)
+                              : encode_collection_with<single_opt_dint, single_packed_builder>(dict_file, dict_len, input, docs != 0,
+                                                                                               unit_ints, threads, enc, units, n_lists, n_ints);
             case DINT_DICT_MULTI_PACKED:
-                return build_index<opt_dint_multi_dict_block, multi_packed_builder>(
-                    docs_dict_file, docs_dict_len, freqs_dict_file, freqs_dict_len, docids, freqs, lens, n_lists,
-                    threads, index, offsets);
+                return encode_collection_with<multi_opt_dint, multi_packed_builder>(dict_file, dict_len, input, docs != 0, unit_ints,
+                                                                                    threads, enc, units, n_lists, n_ints);
             default:
                 return int(DINT_ERR_ARG);
         }
+    });
+}
+
+int dinth_build_dictionary_collection(int kind, const uint32_t* words, size_t n_words, int docs, uint64_t max_sample_ints,
+                                      int threads, dinth_blob** dict_file) {
+    if (!dict_file || (n_words && !words)) return DINT_ERR_ARG;
+    return guarded([&] {
+        dint::binary_collection input(words, n_words);
+        switch (kind) {
+            case DINT_DICT_RECTANGULAR:
+                return build_dictionary_collection<dint::rectangular_builder>(false, input, docs != 0, max_sample_ints, threads, dict_file);
+            case DINT_DICT_SINGLE_PACKED:
+                return build_dictionary_collection<dint::single_packed_builder>(false, input, docs != 0, max_sample_ints, threads, dict_file);
+            case DINT_DICT_MULTI_PACKED:
+                return build_dictionary_collection<dint::multi_packed_builder>(true, input, docs != 0, max_sample_ints, threads, dict_file);
+            default:
+                return int(DINT_ERR_ARG);
+        }
+    });
+}
+
+int dinth_build_index_collection(int kind, int greedy, const void* docs_dict_file, size_t docs_dict_len, const void* freqs_dict_file,
+                                 size_t freqs_dict_len, const uint32_t* docs_words, size_t n_docs_words, const uint32_t* freqs_words,
+                                 size_t n_freqs_words, int threads, dinth_blob** index, dinth_blob** offsets, uint64_t* num_docs) {
+    if (!docs_dict_file || !freqs_dict_file || !index || !offsets || !docs_words || !freqs_words) return DINT_ERR_ARG;
+    return guarded([&] {
+        dint::binary_collection docs(docs_words, n_docs_words), freqs(freqs_words, n_freqs_words);
+        auto d = docs.sequences();
+        auto f = freqs.sequences();
+        // binary_freq_collection (include/ds2i/binary_freq_collection.hpp:14-23)
+        if (d.empty() || d.front().size() != 1)
+            throw std::invalid_argument("First sequence should only contain number of documents");
+        if (num_docs) *num_docs = *d.front().begin();
+        d.erase(d.begin());
+        if (d.size() != f.size()) throw std::runtime_error("docs and freqs files do not match");
+        for (size_t i = 0; i != d.size(); ++i)
+            if (d[i].size() != f[i].size()) throw std::runtime_error("docs and freqs files do not match");
+        return build_index_kind(
+            kind, greedy, docs_dict_file, docs_dict_len, freqs_dict_file, freqs_dict_len, d.size(),
+            [&](uint64_t i) { return d[i].size(); }, [&](uint64_t i) { return std::make_pair(d[i].begin(), f[i].begin()); },
+            threads, index, offsets);
     });
 }
 

@@ -72,6 +72,13 @@ def _load():
                                        C.POINTER(vp), C.POINTER(vp)]
     lib.dinth_build_index.argtypes = [i32, vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp, u64, i32,
                                       C.POINTER(vp), C.POINTER(vp)]
+    lib.dinth_build_index_coder.argtypes = [i32, i32, vp, C.c_size_t, vp, C.c_size_t, vp, vp, vp, u64, i32,
+                                            C.POINTER(vp), C.POINTER(vp)]
+    lib.dinth_encode_collection.argtypes = [i32, i32, vp, C.c_size_t, vp, C.c_size_t, i32, u32, i32, C.POINTER(vp), C.POINTER(vp),
+                                            C.POINTER(u64), C.POINTER(u64)]
+    lib.dinth_build_dictionary_collection.argtypes = [i32, vp, C.c_size_t, i32, u64, i32, C.POINTER(vp)]
+    lib.dinth_build_index_collection.argtypes = [i32, i32, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, i32,
+                                                 C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
     lib.dinth_hash_u32s.restype = u64
     lib.dinth_hash_u32s.argtypes = [vp, C.c_size_t]
     lib.dinth_constants.argtypes = [vp, i32]
@@ -279,16 +286,96 @@ def synth_freqs(n: int, seed: int = 1) -> np.ndarray:
 
 
 def build_index(kind: int, docs_dict: bytes, freqs_dict: bytes, docids: np.ndarray, freqs: np.ndarray,
-                lens: np.ndarray, threads: int | None = None):
-    """In-index layout (dict_posting_list per list). -> (index bytes u8[], list offsets u64[n_lists + 1])"""
+                lens: np.ndarray, threads: int | None = None, greedy: bool = False):
+    """In-index layout (dict_posting_list per list). -> (index bytes u8[], list offsets u64[n_lists + 1]).
+    greedy: greedy_dint_single_dict_block instead of the optimal parse (single-dictionary kinds)."""
     idx, offs = C.c_void_p(), C.c_void_p()
     d, f, l = _u32(docids), _u32(freqs), _u32(lens)
     db = (C.c_char * len(docs_dict)).from_buffer_copy(docs_dict)
     fb = (C.c_char * len(freqs_dict)).from_buffer_copy(freqs_dict)
-    _check(_lib.dinth_build_index(kind, C.addressof(db), len(docs_dict), C.addressof(fb), len(freqs_dict),
-                                  d.ctypes.data, f.ctypes.data, l.ctypes.data, len(l),
-                                  threads or default_threads(), C.byref(idx), C.byref(offs)))
+    _check(_lib.dinth_build_index_coder(kind, int(greedy), C.addressof(db), len(docs_dict), C.addressof(fb), len(freqs_dict),
+                                        d.ctypes.data, f.ctypes.data, l.ctypes.data, len(l),
+                                        threads or default_threads(), C.byref(idx), C.byref(offs)))
     return _take_blob(idx, np.uint8), _take_blob(offs, np.uint64)
+
+
+# ---- ds2i collection files (reference include/ds2i/binary_collection.hpp; README.md:43-51) ----
+
+def collection_words(lists, num_docs: int | None = None) -> np.ndarray:
+    """The u32 words of a collection file: records `len, v[len]`; num_docs given -> a .docs file (record 0 = `1, num_docs`)."""
+    parts = [] if num_docs is None else [np.array([1, num_docs], dtype=np.uint32)]
+    for v in lists:
+        v = _u32(v)
+        parts.append(np.array([v.size], dtype=np.uint32))
+        parts.append(v)
+    return np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint32)
+
+
+def write_collection(basename: str, docid_lists, freq_lists, num_docs: int) -> None:
+    """<basename>.docs and <basename>.freqs as the reference's tools read them."""
+    collection_words(docid_lists, num_docs).tofile(basename + ".docs")
+    collection_words(freq_lists).tofile(basename + ".freqs")
+
+
+def encode_collection(kind: int, dict_file: bytes, words: np.ndarray, docs: bool, unit_ints: int = 4096, greedy: bool = False,
+                      threads: int | None = None):
+    """The vroom `encode` program over a collection file's words -> (stream u8[], units, lists, integers)."""
+    enc, units = C.c_void_p(), C.c_void_p()
+    w = _u32(words)
+    n_lists, n_ints = C.c_uint64(), C.c_uint64()
+    buf = (C.c_char * len(dict_file)).from_buffer_copy(dict_file)
+    _check(_lib.dinth_encode_collection(kind, int(greedy), C.addressof(buf), len(dict_file), w.ctypes.data, w.size, int(docs),
+                                        unit_ints, threads or default_threads(), C.byref(enc), C.byref(units),
+                                        C.byref(n_lists), C.byref(n_ints)))
+    return _take_blob(enc, np.uint8), _take_blob(units, UNIT_DTYPE), n_lists.value, n_ints.value
+
+
+def build_dictionary_collection(kind: int, words: np.ndarray, docs: bool, max_sample_ints: int = 0,
+                                threads: int | None = None) -> bytes:
+    """DSF-65536-16 over the statistics of a collection file's lists -> the dictionary file image."""
+    h = C.c_void_p()
+    w = _u32(words)
+    _check(_lib.dinth_build_dictionary_collection(kind, w.ctypes.data, w.size, int(docs), max_sample_ints,
+                                                  threads or default_threads(), C.byref(h)))
+    return _take_blob(h, np.uint8).tobytes()
+
+
+def build_index_collection(kind: int, docs_dict: bytes, freqs_dict: bytes, docs_words: np.ndarray, freqs_words: np.ndarray,
+                           greedy: bool = False, threads: int | None = None):
+    """dict_freq_index::builder over a .docs / .freqs pair -> (index bytes, list offsets, num_docs)."""
+    idx, offs = C.c_void_p(), C.c_void_p()
+    d, f = _u32(docs_words), _u32(freqs_words)
+    num_docs = C.c_uint64()
+    db = (C.c_char * len(docs_dict)).from_buffer_copy(docs_dict)
+    fb = (C.c_char * len(freqs_dict)).from_buffer_copy(freqs_dict)
+    _check(_lib.dinth_build_index_collection(kind, int(greedy), C.addressof(db), len(docs_dict), C.addressof(fb), len(freqs_dict),
+                                             d.ctypes.data, d.size, f.ctypes.data, f.size, threads or default_threads(),
+                                             C.byref(idx), C.byref(offs), C.byref(num_docs)))
+    return _take_blob(idx, np.uint8), _take_blob(offs, np.uint64), num_docs.value
+
+
+INDEX_FILE_HEADER = np.dtype([("magic", "S8"), ("kind", "<u4"), ("coder", "<u4"), ("num_docs", "<u8"), ("n_lists", "<u8"),
+                              ("docs_dict_bytes", "<u8"), ("freqs_dict_bytes", "<u8"), ("index_bytes", "<u8")])
+
+
+def read_index_file(path: str) -> dict:
+    """The container `dint_create_freq_index` writes (dint/index_file.hpp)."""
+    raw = np.fromfile(path, dtype=np.uint8)
+    h = raw[:INDEX_FILE_HEADER.itemsize].view(INDEX_FILE_HEADER)[0]
+    if h["magic"] != b"DINTIDX1":
+        raise ValueError("not a DINT index file")
+    pad8 = lambda n: (int(n) + 7) & ~7
+    p = INDEX_FILE_HEADER.itemsize
+    n = int(h["n_lists"])
+    offsets = raw[p:p + 8 * (n + 1)].view("<u8").copy()
+    p += 8 * (n + 1)
+    docs_dict = raw[p:p + int(h["docs_dict_bytes"])].tobytes()
+    p += pad8(h["docs_dict_bytes"])
+    freqs_dict = raw[p:p + int(h["freqs_dict_bytes"])].tobytes()
+    p += pad8(h["freqs_dict_bytes"])
+    index = raw[p:p + int(h["index_bytes"])].copy()
+    return {"kind": int(h["kind"]), "coder": int(h["coder"]), "num_docs": int(h["num_docs"]), "offsets": offsets,
+            "docs_dict": docs_dict, "freqs_dict": freqs_dict, "index": index}
 
 
 def hash_u32s(words) -> int:

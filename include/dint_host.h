@@ -95,6 +95,34 @@ int dinth_build_index(int kind, const void* docs_dict_file, size_t docs_dict_len
                       size_t freqs_dict_len, const uint32_t* docids, const uint32_t* freqs, const uint32_t* lens,
                       uint64_t n_lists, int threads, dinth_blob** index, dinth_blob** offsets);
 
+/* The same with the block coder named: greedy != 0 selects greedy_dint_single_dict_block (reference
+ * include/dint/dint_codecs.hpp:52-139) for the single-dictionary kinds; the multi kind has the optimal coder only. */
+int dinth_build_index_coder(int kind, int greedy, const void* docs_dict_file, size_t docs_dict_len, const void* freqs_dict_file,
+                            size_t freqs_dict_len, const uint32_t* docids, const uint32_t* freqs, const uint32_t* lens,
+                            uint64_t n_lists, int threads, dinth_blob** index, dinth_blob** offsets);
+
+/* ---- ingest of a real collection (reference include/ds2i/binary_collection.hpp:13-157) --------------------------------
+ * `words` / `n_words`: the u32 words of a ds2i collection file (records `len, v[len]`; empty records skipped, a truncated
+ * last record cut at the end). docs != 0: a .docs file — record 0 (`1, num_docs`) is skipped and docIDs become d-gaps
+ * minus one (first against -1); docs == 0: a .freqs file — every value minus one (vroom_env/jobs.hpp:74-84). */
+
+/* The vroom `encode` program (reference vroom_env/encode.cpp:133-191): one list per record -> the encoded stream (+ the
+ * unit-table sidecar, may be NULL). *n_lists / *n_ints (may be NULL): what the reference prints as num_sequences /
+ * num_integers. */
+int dinth_encode_collection(int kind, int greedy, const void* dict_file, size_t dict_len, const uint32_t* words, size_t n_words,
+                            int docs, uint32_t unit_ints, int threads, dinth_blob** enc, dinth_blob** units, uint64_t* n_lists,
+                            uint64_t* n_ints);
+/* decreasing_static_frequencies::build over the statistics of the file's lists (reference dict_freq_index.hpp:139-161,
+ * block_statistics.hpp:45-108 / :201-279, dictionary_builders.hpp:55-75) -> the dictionary file image. max_sample_ints: 0 =
+ * every list (the reference), otherwise the first lists whose lengths sum to at most that. */
+int dinth_build_dictionary_collection(int kind, const uint32_t* words, size_t n_words, int docs, uint64_t max_sample_ints,
+                                      int threads, dinth_blob** dict_file);
+/* dict_freq_index::builder over a .docs / .freqs pair (reference src/create_freq_index.cpp:54-110, dict_freq_index.hpp:30-49):
+ * -> the index bytes, the u64[n_lists + 1] list offsets, *num_docs from record 0 of the .docs words. */
+int dinth_build_index_collection(int kind, int greedy, const void* docs_dict_file, size_t docs_dict_len, const void* freqs_dict_file,
+                                 size_t freqs_dict_len, const uint32_t* docs_words, size_t n_docs_words, const uint32_t* freqs_words,
+                                 size_t n_freqs_words, int threads, dinth_blob** index, dinth_blob** offsets, uint64_t* num_docs);
+
 /* MurmurHash64A(seed 0) of n u32 words (reference include/dint/hash_utils.hpp:7-80). */
 uint64_t dinth_hash_u32s(const uint32_t* p, size_t n);
 

@@ -137,6 +137,51 @@ uint64_t oracle_stats_entries(const oracle_stats* st, uint32_t context, oracle_n
 /* dictionary_builders.hpp:15-38, :50-75: returns the number of entries that pass the filter; writes min(that, 65536, cap) */
 uint64_t oracle_stats_select(const oracle_stats* st, uint32_t context, oracle_ngram* out, uint64_t cap);
 
+/* ---- the ENCODE side and the dictionary packing (f2); dint_oracle_encode.c ---------------- */
+
+/* std::vector<uint8_t>: zero-initialise, pass to the calls below (they append), release with oracle_bytes_free. */
+typedef struct {
+    uint8_t* data;
+    size_t size, cap;
+} oracle_bytes;
+void oracle_bytes_free(oracle_bytes* b);
+
+/* Dictionary::builder after load(file) and prepare_for_encoding(): rectangular_dictionary.hpp:79-92, :112-123;
+ * single_dictionary.hpp:88-107, :154-165; multi_dictionary.hpp:93-121, :187-217 — with the hash-only maps of SURVEY H9. */
+typedef struct oracle_builder oracle_builder;
+oracle_builder* oracle_builder_load(int kind, const void* file_bytes, size_t len);
+void oracle_builder_free(oracle_builder* b);
+/* builder::lookup (single_dictionary.hpp:167-175, multi_dictionary.hpp:219-233): the codeword whose n-gram HASHES like
+ * begin[0, entry_size), or 0xFFFFFFFF. dictionary_id / log2_num_entries (16 or 8) matter for the multi kind only. */
+uint32_t oracle_builder_lookup(const oracle_builder* b, uint32_t dictionary_id, const uint32_t* begin, uint32_t entry_size,
+                               uint32_t log2_num_entries);
+
+/* The calls below return 1, or 0 when memory ran out / an argument is impossible. */
+
+/* Encoder::encode of the vroom environment for one list of gaps: single_opt_dint (vroom_env/dint_codecs.hpp:192-312),
+ * single_greedy_dint (:110-171, greedy != 0), multi_opt_dint (:334-518, picked by a multi builder; greedy ignored). */
+int oracle_encode_list(const oracle_builder* b, int greedy, const uint32_t* in, uint32_t n, oracle_bytes* out);
+/* TightVariableByte::encode_single (include/ds2i/block_codecs.hpp:35-85) */
+int oracle_vbyte_encode(uint32_t val, oracle_bytes* out);
+/* interpolative_block::encode (include/ds2i/block_codecs.hpp:104-128; bit_writer: interpolative_coding.hpp:10-77) */
+int oracle_interpolative_encode(const uint32_t* in, uint32_t sum_of_values, size_t n, oracle_bytes* out);
+/* Coder::encode of the index for one block of n <= 256 values: opt_dint_single_dict_block / greedy_dint_single_dict_block /
+ * opt_dint_multi_dict_block (include/dint/dint_codecs.hpp:56-124, :145-267, :289-458) */
+int oracle_block_encode(const oracle_builder* b, int greedy, const uint32_t* in, uint32_t sum_of_values, uint32_t n, oracle_bytes* out);
+/* dict_posting_list::write (include/dint/dict_posting_list.hpp:10-56): docs = strictly increasing docIDs, freqs >= 1 */
+int oracle_posting_list_write(const oracle_builder* docs_dict_builder, const oracle_builder* freqs_dict_builder, int greedy, uint32_t n,
+                              const uint32_t* docs_begin, const uint32_t* freqs_begin, oracle_bytes* out);
+/* The vroom `encode` program (vroom_env/encode.cpp:133-191 + jobs.hpp:74-95) over the u32 words of a collection file read as
+ * binary_collection does (include/ds2i/binary_collection.hpp:131-146). docs != 0: a .docs file (record 0 skipped, values to
+ * d-gaps); 0: a .freqs file (values minus one). */
+int oracle_encode_collection(const oracle_builder* b, int greedy, const uint32_t* data, size_t data_size, int docs, oracle_bytes* output,
+                             uint64_t* num_processed_lists, uint64_t* num_total_ints);
+/* builder::init + append per selected n-gram + build + write: the dictionary FILE of a selection (words back to back, lens[k]
+ * integers each, ctx[k] its dictionary — NULL for the single kinds). pack_policy::compact as written (O(n^2),
+ * dictionary_building_utils.hpp:241-292), one std::search per entry (single_dictionary.hpp:138-151, multi_dictionary.hpp:
+ * 165-181). */
+int oracle_pack_dictionary(int kind, const uint32_t* words, const uint32_t* lens, const uint32_t* ctx, size_t n_entries, oracle_bytes* file);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,13 +34,15 @@ static uint64_t ceil_log2_u64(uint64_t x) {
     return msb + 1;
 }
 
-/* statistics_collectors.hpp:21-40: selector::get — the block's maximum x; code = ceil_log2(ceil_log2(x + 1)), 0 if x <= 1 */
+/* statistics_collectors.hpp:21-40: selector::get — the block's maximum x; code = ceil_log2(ceil_log2(x + 1)), 0 if x <= 1.
+ * `x + 1` is uint32_t arithmetic there (:23, :36): at x = 0xFFFFFFFF it wraps to 0, ceil_log2(0) is 0 in a release build
+ * (util.hpp:67-70, the assert compiled out), and the block lands in context 0 — restated as written. */
 uint32_t oracle_selector_get(const uint32_t* entry, size_t n) {
     uint32_t x = 0;
     for (const uint32_t* p = entry; p != entry + n; ++p)
         if (*p > x) x = *p;
     uint32_t selector_code = 0;
-    if (x > 1) selector_code = (uint32_t)ceil_log2_u64(ceil_log2_u64((uint64_t)x + 1));
+    if (x > 1) selector_code = (uint32_t)ceil_log2_u64(ceil_log2_u64((uint32_t)(x + 1u)));
     return selector_code;
 }
 

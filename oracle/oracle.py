@@ -19,6 +19,10 @@ _LIB = os.environ.get("DINT_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")
 RECT, SINGLE_PACKED, MULTI_PACKED = 0, 1, 2
 
 
+class _Bytes(C.Structure):  # oracle_bytes
+    _fields_ = [("data", C.c_void_p), ("size", C.c_size_t), ("cap", C.c_size_t)]
+
+
 def build(quiet: bool = True) -> None:
     subprocess.run(["make", "-C", _HERE, "all"], check=True,
                    stdout=subprocess.DEVNULL if quiet else None)
@@ -73,6 +77,22 @@ def _load():
     lib.oracle_stats_entries.argtypes = [vp, C.c_uint32, vp, C.c_uint64]
     lib.oracle_stats_select.restype = C.c_uint64
     lib.oracle_stats_select.argtypes = [vp, C.c_uint32, vp, C.c_uint64]
+    bp = C.POINTER(_Bytes)
+    lib.oracle_bytes_free.restype = None
+    lib.oracle_bytes_free.argtypes = [bp]
+    lib.oracle_builder_load.restype = vp
+    lib.oracle_builder_load.argtypes = [C.c_int, vp, C.c_size_t]
+    lib.oracle_builder_free.restype = None
+    lib.oracle_builder_free.argtypes = [vp]
+    lib.oracle_builder_lookup.restype = C.c_uint32
+    lib.oracle_builder_lookup.argtypes = [vp, C.c_uint32, vp, C.c_uint32, C.c_uint32]
+    lib.oracle_encode_list.argtypes = [vp, C.c_int, vp, C.c_uint32, bp]
+    lib.oracle_vbyte_encode.argtypes = [C.c_uint32, bp]
+    lib.oracle_interpolative_encode.argtypes = [vp, C.c_uint32, C.c_size_t, bp]
+    lib.oracle_block_encode.argtypes = [vp, C.c_int, vp, C.c_uint32, C.c_uint32, bp]
+    lib.oracle_posting_list_write.argtypes = [vp, vp, C.c_int, C.c_uint32, vp, vp, bp]
+    lib.oracle_encode_collection.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_int, bp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.oracle_pack_dictionary.argtypes = [C.c_int, vp, vp, vp, C.c_size_t, bp]
     return lib
 
 
@@ -268,3 +288,94 @@ class Stats:
 
     def ngram(self, e) -> tuple:
         return tuple(int(x) for x in self.gaps[int(e["pos"]): int(e["pos"]) + int(e["len"])])
+
+
+# ---- the encode side (dint_oracle_encode.c) and the dictionary packing (f2) ----
+
+def _take(b: _Bytes, ok: int, what: str) -> np.ndarray:
+    try:
+        if not ok:
+            raise ValueError(f"oracle: {what} failed")
+        out = np.empty(b.size, dtype=np.uint8)
+        if b.size:
+            C.memmove(out.ctypes.data, b.data, b.size)
+        return out
+    finally:
+        _lib.oracle_bytes_free(C.byref(b))
+
+
+class OracleBuilder:
+    """Dictionary::builder after load(file) + prepare_for_encoding(), and the encoders that run against it."""
+
+    def __init__(self, kind: int, file_bytes: bytes):
+        self.kind = kind
+        buf = (C.c_char * len(file_bytes)).from_buffer_copy(file_bytes)
+        self._h = _lib.oracle_builder_load(kind, C.addressof(buf), len(file_bytes))
+        if not self._h:
+            raise ValueError("oracle: malformed dictionary file")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.oracle_builder_free(h)
+
+    def lookup(self, values, dictionary_id: int = 0, b: int = 16) -> int:
+        v = np.ascontiguousarray(values, dtype=np.uint32)
+        return int(_lib.oracle_builder_lookup(self._h, dictionary_id, v.ctypes.data, v.size, b))
+
+    def encode_list(self, gaps, greedy: bool = False) -> np.ndarray:
+        """Encoder::encode(builder, in, universe, n, out) of the vroom environment -> the list's payload bytes."""
+        g = np.ascontiguousarray(gaps, dtype=np.uint32)
+        b = _Bytes()
+        return _take(b, _lib.oracle_encode_list(self._h, int(greedy), g.ctypes.data, g.size, C.byref(b)), "encode_list")
+
+    def block_encode(self, values, sum_of_values: int, greedy: bool = False) -> np.ndarray:
+        """Coder::encode(builder, in, sum_of_values, n, out) of the index, one block."""
+        v = np.ascontiguousarray(values, dtype=np.uint32)
+        b = _Bytes()
+        return _take(b, _lib.oracle_block_encode(self._h, int(greedy), v.ctypes.data, sum_of_values & 0xFFFFFFFF, v.size,
+                                                 C.byref(b)), "block_encode")
+
+    def encode_collection(self, words, docs: bool, greedy: bool = False):
+        """The vroom `encode` program over a collection file's u32 words -> (stream bytes, lists, integers)."""
+        w = np.ascontiguousarray(words, dtype=np.uint32)
+        b = _Bytes()
+        lists, ints = C.c_uint64(), C.c_uint64()
+        ok = _lib.oracle_encode_collection(self._h, int(greedy), w.ctypes.data, w.size, int(docs), C.byref(b),
+                                           C.byref(lists), C.byref(ints))
+        return _take(b, ok, "encode_collection"), lists.value, ints.value
+
+
+def posting_list_write(docs_builder: OracleBuilder, freqs_builder: OracleBuilder, docids, freqs, greedy: bool = False) -> np.ndarray:
+    """dict_posting_list::write -> the list's bytes."""
+    d = np.ascontiguousarray(docids, dtype=np.uint32)
+    f = np.ascontiguousarray(freqs, dtype=np.uint32)
+    assert d.size == f.size and d.size > 0
+    b = _Bytes()
+    return _take(b, _lib.oracle_posting_list_write(docs_builder._h, freqs_builder._h, int(greedy), d.size, d.ctypes.data,
+                                                   f.ctypes.data, C.byref(b)), "posting_list_write")
+
+
+def interpolative_encode(values, sum_of_values: int) -> np.ndarray:
+    v = np.ascontiguousarray(values, dtype=np.uint32)
+    b = _Bytes()
+    return _take(b, _lib.oracle_interpolative_encode(v.ctypes.data, sum_of_values & 0xFFFFFFFF, v.size, C.byref(b)),
+                 "interpolative_encode")
+
+
+def vbyte_encode(val: int) -> bytes:
+    b = _Bytes()
+    return _take(b, _lib.oracle_vbyte_encode(val & 0xFFFFFFFF, C.byref(b)), "vbyte_encode").tobytes()
+
+
+def pack_dictionary(kind: int, entries, contexts=None) -> bytes:
+    """builder::init / append / build / write over a selection: entries = sequences of integers in dictionary order,
+    contexts[k] = the dictionary entry k goes to (multi) -> the dictionary file."""
+    lens = np.array([len(e) for e in entries], dtype=np.uint32)
+    words = np.ascontiguousarray(np.concatenate([np.asarray(e, dtype=np.uint32) for e in entries]) if len(entries) else
+                                 np.zeros(0, dtype=np.uint32))
+    ctx = None if contexts is None else np.ascontiguousarray(contexts, dtype=np.uint32)
+    b = _Bytes()
+    ok = _lib.oracle_pack_dictionary(kind, words.ctypes.data, lens.ctypes.data, None if ctx is None else ctx.ctypes.data,
+                                     lens.size, C.byref(b))
+    return _take(b, ok, "pack_dictionary").tobytes()

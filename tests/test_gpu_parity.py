@@ -46,6 +46,29 @@ def test_stream_matches_oracle(device, request, kind, corpus_name):
 
 
 @pytest.mark.parametrize("kind", ALL_KINDS)
+@pytest.mark.parametrize("greedy", [False, True])
+def test_oracle_encoded_stream_decodes_on_the_device(device, small_corpus, kind, greedy):
+    """the stream the ORACLE's encoder restatement writes (oracle/dint_oracle_encode.c:
+    vroom_env/dint_codecs.hpp:110-518 + jobs.hpp:74-95 over the corpus as a .docs file) — not a byte of it from the
+    product's encoder — indexed by the product's host pre-pass and decoded by the HIP kernels: == the gaps."""
+    if greedy and kind == host.MULTI_PACKED:
+        pytest.skip("the reference has no greedy multi-dictionary coder")
+    coll, dict_file = small_corpus.coll, small_corpus.dict_file(kind)
+    ids = host.gaps_to_docids(coll)
+    b = coll.list_bounds()
+    words = host.collection_words([ids[int(b[i]):int(b[i + 1])] for i in range(len(coll.lens))], num_docs=int(ids.max()) + 1)
+    enc, lists, ints = oracle.OracleBuilder(kind, dict_file).encode_collection(words, docs=True, greedy=greedy)
+    assert ints == coll.num_postings
+    d = device.Dictionary(kind, dict_file)
+    for unit_ints in (256, 4096):
+        units, total, n_lists = d.index_stream(enc, unit_ints)
+        assert (total, n_lists) == (ints, lists)
+        out, ends, _ = device.decode_stream(d, enc, units, total)
+        assert np.array_equal(out, coll.gaps)
+        assert int(ends[-1]) == enc.size
+
+
+@pytest.mark.parametrize("kind", ALL_KINDS)
 def test_index_stream_equals_encoder_sidecar(device, small_corpus, kind):
     """The host pre-pass finds the same list boundaries the encoder recorded."""
     enc, units = small_corpus.encoded(kind)
@@ -367,6 +390,25 @@ def test_selection_on_the_device_is_in_dictionary_order(device, small_corpus, ki
         mine = [k for k in keys if k[0] == int(c)]
         assert [key(e) for e in small if int(e["ctx"]) == int(c)] == mine[:100]
     assert host.pack_dictionary(kind, gaps, chosen) == host.build_dictionary(kind, coll)
+
+
+def test_block_context_wraps_like_the_reference(device):
+    """selector::get adds its 1 in uint32_t (statistics_collectors.hpp:23,36): a block holding 0xFFFFFFFF is context 0;
+    0xFFFFFFFE is context 5. The device's counting puts the blocks' n-grams where the oracle's does."""
+    import torch
+
+    gaps = np.full(512, 3, dtype=np.uint32)
+    gaps[7] = 0xFFFFFFFF
+    gaps[256 + 9] = 0xFFFFFFFE
+    starts = np.array([0, 512], dtype=np.uint64)
+    entries, _ = device.count_ngrams(torch.from_numpy(gaps.view(np.int32)).cuda(), starts, multi=True)
+    st = oracle.Stats(True, gaps)
+    st.collect(0, 512)
+    ngram = lambda e: tuple(int(x) for x in gaps[int(e["pos"]):int(e["pos"]) + int(e["len"])])
+    got = {(int(e["ctx"]), ngram(e)): int(e["freq"]) for e in entries}
+    want = {(c, st.ngram(e)): int(e["freq"]) for c in range(st.contexts) for e in st.entries(c)}
+    assert got == want
+    assert {c for c, _ in got} == {0, 5} and got[(0, (0xFFFFFFFF,))] == 1 and got[(5, (0xFFFFFFFE,))] == 1
 
 
 def test_ngram_counts_of_a_tiny_collection(device):
