@@ -62,11 +62,6 @@ namespace dint_dev {
 #ifndef DINT_FF_OPEN
 #define DINT_FF_OPEN 4  // bundles the multi-dictionary schedule keeps open while it packs a chunk (first fit)
 #endif
-#ifndef DINT_LEAN_SEGMENT
-#define DINT_LEAN_SEGMENT 0  // 2: decode_single_kernel's long units through decode_segment_v4 (explicit vector-memory waits, heads and
-                             // tails a tile ahead): measured in round 4 — as fast as decode_segment, no faster (profiles/r04_v4_ab.txt);
-                             // off by default
-#endif
 #ifndef DINT_GATHER_AUX
 #define DINT_GATHER_AUX 0  // cache policy of the metadata / row gathers (L2-resident tables, no reuse in L1)
 #endif
@@ -108,11 +103,6 @@ constexpr uint32_t kClassTableWords = 328 + 24;       // slot classification tab
 constexpr uint32_t kDescWordAt = 328;
 constexpr uint32_t kHotImageWords = kLdsWords - kClassTableWords - kWavesPerBlock * kScratchWords;
 constexpr uint32_t kZeroHalves = 256;                 // longest run codeword, in u16
-// Single-dictionary images carry, right behind the zeros, one bit per codeword: "a COLD codeword whose integers do not fit its
-// 16-byte head" (more than 6: it needs its 32-byte tail too). The slot value alone then says whether to ask for the tail,
-// so decode_segment_v4 requests heads AND tails a tile ahead and a tile has ONE wait for the dictionary, not two.
-constexpr uint32_t kLongBitmapWords = 65536 / 32;
-constexpr uint32_t kLongBitmapWordAt = kZeroHalves / 2;
 // metadata word of a codeword: (size - 1) << 24 | kMetaCold | kMetaSlow | cells << 20 | LDS byte offset
 constexpr uint32_t kMetaCold = 1u << 23;              // the integers come through staging cells (row table)
 constexpr uint32_t kMetaSlow = 1u << 22;              // ... or, with this bit, from gtable through slow_stores
@@ -133,7 +123,6 @@ constexpr uint32_t kMaxUnitInts = 1u << 28;           // byte offsets inside a u
 #include "kernels/wave_basics.inc"
 #include "kernels/tile.inc"
 #include "kernels/segment.inc"
-#include "kernels/segment_v4.inc"
 #include "kernels/bundles.inc"
 
 }  // namespace dint_dev
