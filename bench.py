@@ -72,6 +72,12 @@ def parse_args(argv=None):
                     help="the stream and the output are not allocated next to each other: this much device memory is allocated between "
                          "them and freed again (two big buffers allocated one after the other usually land in the same kind of physical "
                          "stretch, the slow placement of DESIGN.md section 4e). 0: no spacer")
+    ap.add_argument("--multi-rank-distinct", default="auto", choices=["auto", "on", "off"],
+                    help="--gpus N > 1, gov2: `on` = every rank generates, encodes and decodes the SAME workload as a one-GPU run "
+                         "(5e9 distinct postings per GPU: N=1 and N>1 lines differ in the rank count alone); `off` = 1e9 distinct "
+                         "postings per GPU decoded x5 from five device-side copies (the same integers and bytes per step; set-up on "
+                         "a host whose cores the ranks share is 5x shorter); `auto` (default) = on when the container has at least "
+                         "8 CPUs per rank (cgroup quota / affinity), else off. The line says which: distinct_postings_per_gpu, replicate")
     ap.add_argument("--replicate", type=int, default=None,
                     help="device-side copies of the encoded shard at distinct addresses, all decoded in one step")
     ap.add_argument("--universe", type=int, default=None, help="documents")
@@ -84,8 +90,9 @@ def parse_args(argv=None):
                     help="decode time budget of each leg of the CPU baseline sample (0 = skip)")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
                     help="JSON written by tools/pmc_traffic.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS command "
-                         "(HBM counters cannot be read from inside the run). Default: the round's committed measurement, used only "
-                         "if it was taken for the same type and the same integers per launch; otherwise roofline.traffic is null")
+                         "(HBM counters cannot be read from inside the run). Default: the round's committed measurement, attached only "
+                         "if it was taken for the same type, the same integers per launch AND the same build of libdint_hip.so "
+                         "(its lib_sha16 = this process's library); otherwise roofline.traffic is null and the note says why")
     ap.add_argument("--no-verify", action="store_true", help="skip the full bit-exact output check")
     ap.add_argument("--per-launch-schedule", action="store_true",
                     help="decode through dint_decode_units (the bundle schedule rebuilt before every launch, and timed) instead "
@@ -206,6 +213,18 @@ def physical_cores() -> int:
         return len(os.sched_getaffinity(0))
 
 
+def lib_sha16():
+    """first 16 hex digits of the sha256 of the HIP library this process runs (what a traffic file must have been measured on)"""
+    import hashlib
+
+    path = os.environ.get("DINT_HIP_LIB") or os.path.join(ROOT, "dint_amd", "libdint_hip.so")
+    try:
+        with open(path, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def cpu_quota():
     """CPUs' worth of time the container may use per period (cgroup v2 cpu.max, v1 cfs quota), or None: no limit."""
     try:
@@ -262,8 +281,17 @@ def cpu_baseline(kind, dict_file, enc, list_byte_starts, seconds):
 def main():
     args = parse_args()
     w = dict(WORKLOADS[args.workload])
-    if max(args.gpus, int(os.environ.get("WORLD_SIZE", "1"))) > 1 or args.as_rank is not None:
-        w.update(w.get("multi_rank", {}))
+    n_ranks = max(args.gpus, int(os.environ.get("WORLD_SIZE", "1")))
+    if args.as_rank is not None:
+        w.update(w.get("multi_rank", {}))  # (one emulated shard after the other on one GPU: the short set-up)
+    elif n_ranks > 1:
+        # the ranks share the host's cores during set-up (generation + encode): the one-GPU workload as it is when every
+        # rank has at least 8 CPUs to itself, else a fifth of it decoded from five copies (same integers and bytes per step)
+        affinity, quota = len(os.sched_getaffinity(0)), cpu_quota()
+        cpus = affinity if quota is None else min(affinity, quota)
+        distinct = args.multi_rank_distinct == "on" or (args.multi_rank_distinct == "auto" and cpus / n_ranks >= 8)
+        if not distinct:
+            w.update(w.get("multi_rank", {}))
     postings = int(args.postings if args.postings is not None else w["postings"])
     R = max(1, args.replicate if args.replicate is not None else w["replicate"])
     universe = args.universe if args.universe is not None else w["universe"]
@@ -623,7 +651,11 @@ def main():
         if args.traffic_file and os.path.exists(args.traffic_file):
             with open(args.traffic_file) as f:
                 tf = json.load(f)
-            if tf.get("type") == args.type and tf.get("ints_per_launch") == n_ints:
+            lib_now = lib_sha16()
+            if tf.get("type") == args.type and tf.get("ints_per_launch") == n_ints and tf.get("lib_sha16") != lib_now:
+                traffic_note = (f"{os.path.relpath(args.traffic_file, ROOT)} was measured on another build of libdint_hip.so "
+                                f"({tf.get('lib_sha16')}; this process runs {lib_now}): not attached; " + traffic_note)
+            elif tf.get("type") == args.type and tf.get("ints_per_launch") == n_ints:
                 traffic = {"write_gb": tf["write_gb"], "fetch_gb_raw": tf["fetch_gb_raw"],
                            "fetch_gb_corrected": tf["fetch_gb_corrected"],
                            "total_gb": round(tf["write_gb"] + tf["fetch_gb_corrected"], 3),
@@ -656,10 +688,18 @@ def main():
                                  f"would get (lists [{lo},{hi}) of {len(lens_all)}); not a scaling measurement"}
                if args.as_rank is not None else {}),
             "bit_exact": bit_exact,
+            # what one step decodes on every GPU: `distinct_postings_per_gpu` different postings, `replicate` times over (from
+            # that many device-side copies of the stream at distinct addresses); a one-GPU run is 5e9 x 1, a multi-rank run
+            # on a host with few CPUs per rank 1e9 x 5 (--multi-rank-distinct) — the same integers and bytes per step either way
+            "distinct_postings_per_gpu": n_shard,
+            "replicate": R,
             "config": {
+                # (nominal figures: the same text for every rank count but for the count itself; rank 0's exact shard is
+                # distinct_postings_per_gpu)
                 "workload": f"{args.type} decode, DSF-65536-16 dictionary (hot set in LDS), {args.workload}-shaped synthetic "
-                            f"docIDs: universe {universe}, {n_shard} distinct postings encoded per GPU"
-                            + (f", decoded x{R} per step from {R} device-side copies at distinct addresses" if R > 1 else ""),
+                            f"docIDs: universe {universe}, {postings} distinct postings encoded per GPU"
+                            + (f", decoded x{R} per step from {R} device-side copies at distinct addresses" if R > 1 else "")
+                            + f", {shard_world} GPU(s): contiguous list ranges of one collection of {postings * shard_world} postings",
                 "distinct_postings_per_gpu": n_shard,
                 "ints_per_gpu_per_step": n_ints,
                 "lists_per_gpu": int(np.count_nonzero(lens)) * R,

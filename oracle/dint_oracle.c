@@ -698,3 +698,62 @@ uint64_t oracle_and_query_freqs(const oracle_dict* docs_dict, const oracle_dict*
     return and_query_impl(docs_dict, freqs_dict, index, list_offsets, num_docs, terms_in, n_terms, freq_sum ? freq_sum : &dummy,
                           freqs_blocks);
 }
+
+/* ---- a query log on several cores: the honest CPU figure next to the device's batch rate ----------------------------
+ * The reference runs its queries one after the other on one core (src/queries.cpp:15-61). A machine with more cores
+ * answers a LOG of independent queries in parallel: thread k takes the queries k, k + T, k + 2T, ... (interleaved: a
+ * log's heavy queries cluster), every one through the same and_query as above; `passes` times over; the result is the wall
+ * time from the first thread's start to the last thread's end of ONE pass on average. One pthread per share INSIDE this
+ * library: driving oracle_and_query from a Python thread pool measures the interpreter (round 4's 13.75 us per query
+ * on 16 threads against 9 us on one). */
+typedef struct {
+    const oracle_dict* d;
+    const uint8_t* index;
+    const uint64_t* list_offsets;
+    uint64_t num_docs;
+    const uint32_t* terms;
+    const uint64_t* offsets;
+    uint64_t* counts;
+    uint64_t n_queries;
+    uint32_t k, n_threads, passes;
+    double t_first, t_last;
+} query_job;
+
+static void* query_worker(void* arg) {
+    query_job* j = (query_job*)arg;
+    j->t_first = now_sec();
+    for (uint32_t pass = 0; pass != j->passes; ++pass)
+        for (uint64_t q = j->k; q < j->n_queries; q += j->n_threads)
+            j->counts[q] = and_query_impl(j->d, NULL, j->index, j->list_offsets, j->num_docs, j->terms + j->offsets[q],
+                                          (size_t)(j->offsets[q + 1] - j->offsets[q]), NULL, NULL);
+    j->t_last = now_sec();
+    return NULL;
+}
+
+double oracle_and_queries_parallel(const oracle_dict* docs_dict, const uint8_t* index, const uint64_t* list_offsets, uint64_t num_docs,
+                                   const uint32_t* terms, const uint64_t* offsets, uint64_t n_queries, uint32_t n_threads,
+                                   uint32_t passes, uint64_t* counts) {
+    if (n_threads == 0 || passes == 0) return -1.0;
+    query_job* jobs = (query_job*)calloc(n_threads, sizeof *jobs);
+    pthread_t* th = (pthread_t*)calloc(n_threads, sizeof *th);
+    double result = -1.0;
+    if (jobs && th) {
+        uint32_t made = 0;
+        for (uint32_t k = 0; k != n_threads; ++k)
+            jobs[k] = (query_job){docs_dict, index, list_offsets, num_docs, terms, offsets, counts, n_queries, k, n_threads, passes, 0, 0};
+        for (; made != n_threads; ++made)
+            if (pthread_create(&th[made], NULL, query_worker, &jobs[made]) != 0) break;
+        for (uint32_t k = 0; k != made; ++k) pthread_join(th[k], NULL);
+        if (made == n_threads) {
+            double first = jobs[0].t_first, last = jobs[0].t_last;
+            for (uint32_t k = 1; k != n_threads; ++k) {
+                if (jobs[k].t_first < first) first = jobs[k].t_first;
+                if (jobs[k].t_last > last) last = jobs[k].t_last;
+            }
+            result = (last - first) / passes;
+        }
+    }
+    free(jobs);
+    free(th);
+    return result;
+}

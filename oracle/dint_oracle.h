@@ -110,6 +110,13 @@ uint64_t oracle_and_query_freqs(const oracle_dict* docs_dict, const oracle_dict*
                                 const uint64_t* list_offsets, uint64_t num_docs, const uint32_t* terms_in, size_t n_terms,
                                 uint64_t* freq_sum, uint64_t* freqs_blocks);
 
+/* A log of n_queries AND queries (query q: terms[offsets[q] .. offsets[q + 1])) answered by n_threads pthreads inside this
+ * library, query q by thread q % n_threads, `passes` times over; counts[q] = its matches. Returns the wall seconds of one
+ * pass (first thread's start to last thread's end, over passes), negative on failure. */
+double oracle_and_queries_parallel(const oracle_dict* docs_dict, const uint8_t* index, const uint64_t* list_offsets, uint64_t num_docs,
+                                   const uint32_t* terms, const uint64_t* offsets, uint64_t n_queries, uint32_t n_threads,
+                                   uint32_t passes, uint64_t* counts);
+
 /* ---- dictionary construction statistics (dint_oracle_stats.c) ----------------------------- */
 
 /* selector::get (include/dint/statistics_collectors.hpp:21-40): the context of a block of n integers. */

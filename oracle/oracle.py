@@ -53,6 +53,8 @@ def _load():
     lib.oracle_and_query.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_size_t]
     lib.oracle_and_query_freqs.restype = C.c_uint64
     lib.oracle_and_query_freqs.argtypes = [vp, vp, vp, vp, C.c_uint64, vp, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.oracle_and_queries_parallel.restype = C.c_double
+    lib.oracle_and_queries_parallel.argtypes = [vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp]
     lib.oracle_time_stream.restype = C.c_double
     lib.oracle_time_stream.argtypes = [vp, vp, C.c_size_t, C.c_uint64, C.c_double,
                                        C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -215,6 +217,21 @@ class OracleIndex:
         t = np.ascontiguousarray(terms, dtype=np.uint32)
         return int(_lib.oracle_and_query(self.docs_dict._h, self._padded.ctypes.data, self._offs.ctypes.data,
                                          self.num_docs, t.ctypes.data, t.size))
+
+    def and_queries_parallel(self, queries, threads: int, passes: int = 1):
+        """The whole log on `threads` pthreads inside liboracle (query q on thread q % threads) -> (match counts, wall
+        seconds of one pass)."""
+        terms = np.ascontiguousarray(np.concatenate([np.asarray(q, dtype=np.uint32) for q in queries]) if len(queries) else
+                                     np.zeros(0, dtype=np.uint32))
+        offs = np.zeros(len(queries) + 1, dtype=np.uint64)
+        np.cumsum([len(q) for q in queries], out=offs[1:])
+        counts = np.zeros(len(queries), dtype=np.uint64)
+        wall = _lib.oracle_and_queries_parallel(self.docs_dict._h, self._padded.ctypes.data, self._offs.ctypes.data, self.num_docs,
+                                                terms.ctypes.data, offs.ctypes.data, len(queries), threads, passes,
+                                                counts.ctypes.data)
+        if wall < 0:
+            raise RuntimeError("oracle_and_queries_parallel failed")
+        return counts, wall
 
     def and_query_freqs(self, freqs_dict: OracleDict, terms):
         """and_query<true> -> (matches, sum of the freq() of every term at every match, freqs blocks decoded)."""

@@ -118,10 +118,8 @@ def main():
         cpu_counts = np.array([oi.and_query(q) for q in cpu_q[:50]], dtype=np.uint64)
         assert np.array_equal(cpu_counts, counts[:len(cpu_counts)])
         cpu = np.sort(np.array(cpu))
-        # ... and on every CPU the container may use (its cgroup quota: 16 of the box's 256): the query log cut into
-        # contiguous shares, one thread each (the oracle call releases the GIL), wall time of the whole batch
-        import concurrent.futures as cf
-
+        # ... and on every CPU the container may use (its cgroup quota: 16 of the box's 256): the same log answered by that
+        # many pthreads INSIDE liboracle (query q on thread q % threads), three passes, wall time of a pass / queries
         try:
             with open("/sys/fs/cgroup/cpu.max") as f:
                 q_, period_ = f.read().split()[:2]
@@ -129,20 +127,15 @@ def main():
         except (OSError, ValueError):
             quota = None
         n_thr = len(os.sched_getaffinity(0)) if quota is None else max(1, min(len(os.sched_getaffinity(0)), int(quota)))
-        shares = [cpu_q[i::n_thr] for i in range(n_thr)]
-
-        def run_share(share):
-            for q in share:
-                oi.and_query(q)
-
-        walls = []
-        with cf.ThreadPoolExecutor(n_thr) as ex:
-            for _ in range(3):
-                t0 = time.perf_counter()
-                list(ex.map(run_share, shares))
-                walls.append(time.perf_counter() - t0)
-        cpu_all = {"us_per_query": min(walls) * 1e6 / max(1, len(cpu_q)), "threads": n_thr,
-                   "note": "the same queries shared among the threads, wall time of the batch / queries"}
+        par_counts, _ = oi.and_queries_parallel(cpu_q, n_thr, 1)  # (warm: pages touched, threads created once before)
+        assert np.array_equal(par_counts[:len(cpu_counts)], cpu_counts)
+        par_counts, wall = oi.and_queries_parallel(cpu_q, n_thr, 3)
+        one_counts, wall_one = oi.and_queries_parallel(cpu_q, 1, 3)
+        assert np.array_equal(par_counts, one_counts)
+        cpu_all = {"us_per_query": wall * 1e6 / max(1, len(cpu_q)), "threads": n_thr,
+                   "us_per_query_one_thread_same_call": wall_one * 1e6 / max(1, len(cpu_q)),
+                   "note": "oracle_and_queries_parallel: pthreads inside liboracle, query q on thread q % threads; wall time of one "
+                           "pass of the log / queries (round 4 drove the oracle from a Python thread pool and measured the interpreter)"}
         pct = lambda a, p: float(a[min(len(a) - 1, int(p * len(a) / 100))])
         out[name] = {
             "queries": len(qs), "results": int(counts.sum()),

@@ -67,3 +67,16 @@ def test_reference_query_log_on_the_readme_shaped_collection():
             assert (n, fsum) == intersect_freqs(ix.docids, ix.freqs, ix.bounds, q)
         hits += want
     assert hits > 500
+
+
+def test_query_log_on_several_threads_equals_one_by_one(small_corpus):
+    """oracle_and_queries_parallel (pthreads inside liboracle, query q on thread q % threads: the all-cores CPU figure of
+    tests/query_timing.py): the same counts as one query after the other, for any thread count, empty queries included."""
+    kind = host.SINGLE_PACKED
+    ix = get_index(small_corpus, kind)
+    oi = oracle.OracleIndex(oracle.OracleDict(kind, ix.docs_dict), ix.bytes, ix.offsets, _num_docs(ix))
+    qs = reference_queries(len(ix.lens))[:120] + heavy_queries(ix.lens, 40) + [np.zeros(0, dtype=np.uint32)]
+    want = np.array([oi.and_query(q) for q in qs], dtype=np.uint64)
+    for threads in (1, 3, 8):
+        got, wall = oi.and_queries_parallel(qs, threads, passes=2)
+        assert np.array_equal(got, want) and wall > 0

@@ -151,6 +151,33 @@ def test_bench_as_rank_takes_that_ranks_shard():
     assert bad.returncode != 0
 
 
+def test_one_rank_and_two_ranks_decode_the_same_workload_per_gpu():
+    """--multi-rank-distinct on: a two-rank job generates, encodes and decodes per GPU what a one-GPU run does — the two
+    lines' config.workload differ in the rank count alone (and the collection's total, which is the count times the
+    per-GPU postings), `replicate` is 1 in both and the per-GPU distinct postings agree within a list's length. `off`:
+    a fifth... here, the multi-rank variant of the workload — x5 replicas — and the line says so at its top level."""
+    import json
+    import re
+
+    def line_of(extra):
+        r = _stub_bench(extra, {})
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+
+    one = line_of(["--gpus", "1"])
+    two = line_of(["--gpus", "2", "--multi-rank-distinct", "on"])
+    off = line_of(["--gpus", "2", "--multi-rank-distinct", "off"])
+    norm = lambda w: re.sub(r"\d+ GPU\(s\): contiguous list ranges of one collection of \d+ postings", "<ranks>", w)
+    assert one["config"]["workload"] != two["config"]["workload"]
+    assert norm(one["config"]["workload"]) == norm(two["config"]["workload"])
+    assert "1 GPU(s)" in one["config"]["workload"] and "2 GPU(s)" in two["config"]["workload"]
+    assert one["replicate"] == two["replicate"] == 1 and off["replicate"] == 5
+    assert abs(one["distinct_postings_per_gpu"] - two["distinct_postings_per_gpu"]) < 100_000
+    assert one["config"]["ints_per_gpu_per_step"] == one["distinct_postings_per_gpu"]
+    assert off["config"]["ints_per_gpu_per_step"] == 5 * off["distinct_postings_per_gpu"]
+    assert "decoded x5" in off["config"]["workload"] and "decoded x" not in two["config"]["workload"]
+
+
 def test_bench_help_renders():
     """argparse formats every help string with %: an unescaped per cent sign in one of them breaks --help."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
