@@ -33,7 +33,7 @@ ABI_SYMBOLS = (
     "dint_stream_stats_get",
     "dint_decode_block_host", "dint_index_posting_lists", "dint_decode_posting_blocks",
     "dint_list_cache_create", "dint_list_cache_decode", "dint_list_cache_destroy",
-    "dint_block_table_create", "dint_block_table_destroy", "dint_decode_block_table",
+    "dint_block_table_create", "dint_block_table_destroy", "dint_block_table_learn", "dint_block_table_ready", "dint_decode_block_table",
     "dint_query_index_create", "dint_query_index_destroy", "dint_and_queries", "dint_and_queries_freqs", "dint_count_ngrams", "dint_select_ngrams", "dint_last_kernel_clock_mhz",
 )
 
@@ -105,6 +105,8 @@ def _load():
     lib.dint_block_table_destroy.restype = None
     lib.dint_block_table_destroy.argtypes = [vp]
     lib.dint_decode_block_table.argtypes = [vp, vp, vp, sz, vp, vp, vp, sz, vp]
+    lib.dint_block_table_learn.argtypes = [vp, vp, vp, vp, sz, vp]
+    lib.dint_block_table_ready.argtypes = [vp, C.c_int]
     lib.dint_query_index_create.argtypes = [vp, vp, sz, vp, sz, sz, C.POINTER(vp)]
     lib.dint_query_index_destroy.restype = None
     lib.dint_query_index_destroy.argtypes = [vp]
@@ -425,6 +427,18 @@ class BlockTable:
             _lib.dint_block_table_destroy(h)
 
     __del__ = close
+
+    def learn(self, docs_dict, freqs_dict, index_dev, index_bytes, stream=None):
+        """The sizing pass at set-up (dint_block_table_learn): after it the first decode is already the one launch."""
+        import torch
+
+        if stream is None:
+            stream = torch.cuda.current_stream(index_dev.device).cuda_stream
+        _check(_lib.dint_block_table_learn(self._h, docs_dict._h, freqs_dict._h if freqs_dict is not None else None,
+                                           index_dev.data_ptr(), index_bytes, stream), "dint_block_table_learn")
+
+    def ready(self, with_freqs: bool = True) -> bool:
+        return bool(_lib.dint_block_table_ready(self._h, int(with_freqs)))
 
     def decode(self, docs_dict, freqs_dict, index_dev, index_bytes, docids_dev, freqs_dev, stream=None):
         """Enqueue the decode of every block (asynchronous); tensors are CUDA tensors on the dictionaries' device."""

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DINT_ABI_VERSION 4
+#define DINT_ABI_VERSION 5
 
 /* A unit decodes to at most this many integers (the kernels address a unit's output with 32-bit byte
  * offsets); dint_index_stream never cuts larger ones, dint_decode_units skips them. */
@@ -241,8 +241,23 @@ int dint_block_table_create(const dint_dict* docs_dict, const dint_block_ref* bl
                             size_t index_bytes, dint_block_table** out);
 void dint_block_table_destroy(dint_block_table* table);
 
+/* The sizing pass over the index, done at set-up instead of under the caller's first decodes: everything a table learns as
+ * it is used — where each block's docs part ends (nothing in the index says: dict_posting_list.hpp:42-53 records the end of
+ * docs + freqs only), the freqs parts' units, both bundle schedules, how many blocks they left to the unit queue — learnt
+ * here by decoding the index on the device into a scratch output of the table's own (4 B x 2 per posting, released before
+ * the call returns). SYNCHRONOUS (it is set-up): synchronises `stream`. After it the FIRST dint_decode_block_table of the
+ * table is already the one launch. freqs_dict NULL: a table that will decode docIDs only. Optional: a table not taught
+ * learns under its first two decodes, as before. The CONTENT STABILITY rule of dint_decode_block_table starts here. */
+int dint_block_table_learn(dint_block_table* table, const dint_dict* docs_dict, const dint_dict* freqs_dict, const uint8_t* d_index,
+                           size_t index_bytes, void* stream);
+/* 1 when the next complete dint_decode_block_table of this table (with freqs iff with_freqs) takes the one-launch form. */
+int dint_block_table_ready(const dint_block_table* table, int with_freqs);
+
 /* Device: decode every block of the prepared table to docIDs (and, if d_freqs is not NULL, term
- * frequencies). ASYNCHRONOUS: enqueues on `stream` and returns. Full blocks go through the DINT kernels —
+ * frequencies). ASYNCHRONOUS: enqueues on `stream` and returns — except that the ONE decode that builds a table's kept
+ * schedules (the second complete decode of a table not taught by dint_block_table_learn, or the first after a decode with a
+ * smaller out_capacity invalidated them) reads a 4-byte count back and synchronises `stream` (and the table's side stream)
+ * once before it returns: do not capture that call into a graph; call dint_block_table_learn at set-up to have none. Full blocks go through the DINT kernels —
  * the docID prefix sums are formed in the expansion, one wave scan per block, the gaps never reach memory;
  * freq = value + 1 is added where the values are stored — blocks shorter than 256 through the
  * binary-interpolative decoder (whose code is the prefix sums already). A table learns as it is used: its first decode
@@ -348,7 +363,9 @@ int dint_last_kernel_ms(const dint_dict* dict, float* ms);
  * per-launch kernel time from: the events of the timed launches themselves. */
 int dint_recent_kernel_ms(const dint_dict* dict, float* ms, size_t max_n, size_t* n);
 /* The shader clock the most recent decode kernel ran at, MHz: cycles counted by the launch's first wavefront
- * (s_memtime at both ends) over the kernel's duration from its event pair. (Boxes of a pool differ.) */
+ * (s_memtime at both ends) over the kernel's duration from its event pair. (Boxes of a pool differ.) The count is read from
+ * where that launch's counters live — a block table's launches keep theirs in the table: call while it exists — and is 0 for a
+ * launch that recorded none (the small launch behind an in-index decode for the blocks that fit no tile). */
 int dint_last_kernel_clock_mhz(const dint_dict* dict, float* mhz);
 
 /* What a vroom stream is made of, by the dictionary's device layout (host pre-pass, like

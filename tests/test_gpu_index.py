@@ -97,6 +97,45 @@ def test_prepared_block_table_decodes_asynchronously(device, small_corpus, kind)
 
 
 @pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
+@pytest.mark.parametrize("with_freqs", [True, False])
+def test_a_taught_table_decodes_in_one_launch_from_its_first_decode(device, small_corpus, kind, with_freqs):
+    """dint_block_table_learn: the sizing pass over the index at set-up — where the docs parts end, the freqs parts' units, both
+    bundle schedules — so that the caller's FIRST decode is already the one launch (dint_block_table_ready), and bit-exact;
+    an untaught table gets there under its first two decodes, as before."""
+    import torch
+
+    ix = get_index(small_corpus, kind)
+    blocks, total = device.index_posting_lists(ix.bytes, ix.offsets)
+    dd, fd = device.Dictionary(kind, ix.docs_dict), device.Dictionary(kind, ix.freqs_dict)
+    dev = torch.device("cuda", 0)
+    padded = np.concatenate([ix.bytes, np.zeros(16, np.uint8)])
+    index_dev = torch.from_numpy(padded).to(dev)
+    taught, plain = device.BlockTable(dd, blocks, padded.size), device.BlockTable(dd, blocks, padded.size)
+    assert not taught.ready(with_freqs) and not plain.ready(with_freqs)
+    taught.learn(dd, fd if with_freqs else None, index_dev, padded.size)
+    assert taught.ready(with_freqs) and (with_freqs or not taught.ready(True))
+    for table, passes in ((taught, 1), (plain, 3)):
+        for _ in range(passes):
+            docids_dev = torch.full((total,), -1, dtype=torch.int32, device=dev)
+            freqs_dev = torch.full((total,), -1, dtype=torch.int32, device=dev) if with_freqs else None
+            table.decode(dd, fd if with_freqs else None, index_dev, padded.size, docids_dev, freqs_dev)
+            torch.cuda.synchronize()
+            assert np.array_equal(docids_dev.cpu().numpy().view(np.uint32), ix.docids)
+            if with_freqs:
+                assert np.array_equal(freqs_dev.cpu().numpy().view(np.uint32), ix.freqs)
+    assert plain.ready(with_freqs)
+    # a docs-only table taught without freqs learns the freqs side under later decodes
+    if not with_freqs:
+        for _ in range(3):
+            docids_dev = torch.empty(total, dtype=torch.int32, device=dev)
+            freqs_dev = torch.empty(total, dtype=torch.int32, device=dev)
+            taught.decode(dd, fd, index_dev, padded.size, docids_dev, freqs_dev)
+            torch.cuda.synchronize()
+            assert np.array_equal(freqs_dev.cpu().numpy().view(np.uint32), ix.freqs)
+            assert np.array_equal(docids_dev.cpu().numpy().view(np.uint32), ix.docids)
+
+
+@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
 def test_block_table_side_streams_are_joined_to_the_callers_stream(device, small_corpus, kind):
     """From its second decode on a table runs the freqs launch and the short blocks' decoder on streams of its own. What
     the caller puts on ITS stream around a call must still be ordered with them: the poison written before a call is there

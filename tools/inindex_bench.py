@@ -28,7 +28,22 @@ for typ in ("single_packed_dint", "multi_packed_dint"):
     padded = np.concatenate([idx, np.zeros(16, dtype=np.uint8)])
     index_dev = torch.from_numpy(padded).to(dev)
     table = device.BlockTable(D, blocks, padded.size)
-    r = {"bits_per_posting": round(idx.size * 8 / total, 3), "blocks": int(len(blocks)), "short_blocks": int((blocks["n"] < 256).sum())}
+    # the sizing pass at set-up (dint_block_table_learn), then the FIRST decode a caller makes, timed on the stream: already
+    # the one launch. (An untaught table: its first two decodes are the learning ones — `untaught_first_three_ms`.)
+    first = {}
+    probe_d, probe_f = torch.empty(total, dtype=torch.int32, device=dev), torch.empty(total, dtype=torch.int32, device=dev)
+    def once(tab):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); tab.decode(D, F, index_dev, padded.size, probe_d, probe_f); e1.record(); torch.cuda.synchronize()
+        return round(e0.elapsed_time(e1), 4)
+    untaught = device.BlockTable(D, blocks, padded.size)
+    first["untaught_first_three_ms"] = [once(untaught) for _ in range(3)]
+    del untaught
+    t0 = time.perf_counter(); table.learn(D, F, index_dev, padded.size); first["learn_wall_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+    first["ready_after_learn"] = bool(table.ready(True))
+    first["taught_first_decode_ms"] = once(table)
+    first["taught_next_decodes_ms"] = [once(table) for _ in range(3)]
+    r = {"first_decode": first, "bits_per_posting": round(idx.size * 8 / total, 3), "blocks": int(len(blocks)), "short_blocks": int((blocks["n"] < 256).sum())}
     # placement: the decode's time depends on where the driver puts the buffers it writes, relative to what it
     # reads — a few candidate pairs of output buffers, the fastest stays (bench.py --placement-trials does the same)
     def timed(dd_, ff_):
