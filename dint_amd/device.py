@@ -33,7 +33,7 @@ ABI_SYMBOLS = (
     "dint_stream_stats_get",
     "dint_decode_block_host", "dint_index_posting_lists", "dint_decode_posting_blocks",
     "dint_list_cache_create", "dint_list_cache_decode", "dint_list_cache_destroy",
-    "dint_block_table_create", "dint_block_table_destroy", "dint_block_table_learn", "dint_block_table_ready", "dint_decode_block_table",
+    "dint_block_table_create", "dint_block_table_destroy", "dint_block_table_learn", "dint_block_table_ready", "dint_block_table_info_get", "dint_decode_block_table",
     "dint_query_index_create", "dint_query_index_destroy", "dint_and_queries", "dint_and_queries_freqs", "dint_count_ngrams", "dint_select_ngrams", "dint_last_kernel_clock_mhz",
 )
 
@@ -49,6 +49,12 @@ class DictInfo(C.Structure):
         ("entries", C.c_uint32), ("hot_entries", C.c_uint32), ("lds_bytes", C.c_uint32),
         ("table_words", C.c_uint32), ("compute_units", C.c_uint32),
     ]
+
+
+class BlockTableInfo(C.Structure):  # dint_block_table_info
+    _fields_ = [("n_blocks", C.c_uint64), ("n_short_blocks", C.c_uint64)] + [(k, C.c_uint32) for k in (
+        "complete_decodes", "spans_exact", "freqs_units_ready", "docs_schedule", "freqs_schedule", "docs_queue_items",
+        "freqs_queue_items", "short_block_tickets")]
 
 
 class StreamStats(C.Structure):
@@ -107,6 +113,7 @@ def _load():
     lib.dint_decode_block_table.argtypes = [vp, vp, vp, sz, vp, vp, vp, sz, vp]
     lib.dint_block_table_learn.argtypes = [vp, vp, vp, vp, sz, vp]
     lib.dint_block_table_ready.argtypes = [vp, C.c_int]
+    lib.dint_block_table_info_get.argtypes = [vp, C.POINTER(BlockTableInfo)]
     lib.dint_query_index_create.argtypes = [vp, vp, sz, vp, sz, sz, C.POINTER(vp)]
     lib.dint_query_index_destroy.restype = None
     lib.dint_query_index_destroy.argtypes = [vp]
@@ -439,6 +446,11 @@ class BlockTable:
 
     def ready(self, with_freqs: bool = True) -> bool:
         return bool(_lib.dint_block_table_ready(self._h, int(with_freqs)))
+
+    def info(self) -> dict:
+        i = BlockTableInfo()
+        _check(_lib.dint_block_table_info_get(self._h, C.byref(i)), "dint_block_table_info_get")
+        return {k: int(getattr(i, k)) for k, _ in BlockTableInfo._fields_}
 
     def decode(self, docs_dict, freqs_dict, index_dev, index_bytes, docids_dev, freqs_dev, stream=None):
         """Enqueue the decode of every block (asynchronous); tensors are CUDA tensors on the dictionaries' device."""

@@ -252,6 +252,17 @@ int dint_block_table_learn(dint_block_table* table, const dint_dict* docs_dict, 
                            size_t index_bytes, void* stream);
 /* 1 when the next complete dint_decode_block_table of this table (with freqs iff with_freqs) takes the one-launch form. */
 int dint_block_table_ready(const dint_block_table* table, int with_freqs);
+/* What a table has learnt so far. */
+typedef struct dint_block_table_info {
+    uint64_t n_blocks, n_short_blocks;   /* blocks; those of fewer than 256 postings (binary-interpolative) */
+    uint32_t complete_decodes;           /* decodes that covered every block (learning ones included) */
+    uint32_t spans_exact;                /* 1: where every docs part ends is known */
+    uint32_t freqs_units_ready;          /* 1: the freqs parts' units are built */
+    uint32_t docs_schedule, freqs_schedule;        /* 1: the bundle schedule is kept and its work-item count read back */
+    uint32_t docs_queue_items, freqs_queue_items;  /* full blocks that fit no tile (the unit queue's: a small second launch) */
+    uint32_t short_block_tickets;        /* tickets the short blocks are dealt in inside the docs launch (0: a launch of their own) */
+} dint_block_table_info;
+int dint_block_table_info_get(const dint_block_table* table, dint_block_table_info* info);
 
 /* Device: decode every block of the prepared table to docIDs (and, if d_freqs is not NULL, term
  * frequencies). ASYNCHRONOUS: enqueues on `stream` and returns — except that the ONE decode that builds a table's kept

@@ -41,6 +41,7 @@ for typ in ("single_packed_dint", "multi_packed_dint"):
     del untaught
     t0 = time.perf_counter(); table.learn(D, F, index_dev, padded.size); first["learn_wall_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
     first["ready_after_learn"] = bool(table.ready(True))
+    first["table"] = table.info()
     first["taught_first_decode_ms"] = once(table)
     first["taught_next_decodes_ms"] = [once(table) for _ in range(3)]
     r = {"first_decode": first, "bits_per_posting": round(idx.size * 8 / total, 3), "blocks": int(len(blocks)), "short_blocks": int((blocks["n"] < 256).sum())}
