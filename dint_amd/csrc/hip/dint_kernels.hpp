@@ -62,6 +62,9 @@ namespace dint_dev {
 #ifndef DINT_FF_OPEN
 #define DINT_FF_OPEN 4  // bundles the multi-dictionary schedule keeps open while it packs a chunk (first fit)
 #endif
+#ifndef DINT_MAX_STRAGGLERS
+#define DINT_MAX_STRAGGLERS 4096
+#endif
 #ifndef DINT_GATHER_AUX
 #define DINT_GATHER_AUX 0  // cache policy of the metadata / row gathers (L2-resident tables, no reuse in L1)
 #endif
