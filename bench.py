@@ -729,6 +729,9 @@ def main():
                 "frac_first_allocation": (round(algo_bytes / (first_alloc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                                           if first_alloc_ms else round(achieved / HBM_PEAK_GBS, 4)),
                 "kernel_ms_first_allocation": first_alloc_ms if first_alloc_ms else round(k_mean, 4),
+                "first_allocation_note": "the first CANDIDATE pair of the set-up: the first copy of the stream and the first output buffer, "
+                                         "allocated behind the uploaded pieces, the expected gaps and a spacer (--apart-gb) — not the "
+                                         "process's very first device allocation",
                 "traffic": traffic,
                 "traffic_note": traffic_note,
                 "kernel": KERNEL_BY_TYPE[args.type],

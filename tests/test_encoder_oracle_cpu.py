@@ -378,3 +378,34 @@ def test_tools_argument_errors(tmp_path):
     r = subprocess.run([os.path.join(BIN, "dint_encode"), "single_packed_dint", str(tmp_path / "x.bin"), "--dict", str(tmp_path / "x.docs")],
                        capture_output=True, text=True)
     assert r.returncode == 1 and "unsupported file format" in r.stderr
+
+
+def test_committed_encoder_vectors():
+    """tests/golden/encoder_vectors.json (make_encoder_vectors.py): the bytes the oracle's encoder emitted for the KAT
+    dictionaries' gap sequences and a few small posting lists when the file was made — a regression pin (not reference
+    outputs): the oracle still emits them, and so does the product."""
+    import hashlib
+
+    with open(os.path.join(ROOT, "tests", "golden", "encoder_vectors.json")) as f:
+        vec = json.load(f)
+    builders = {k: oracle.OracleBuilder(k, kat.DICT_FILES[k]) for k in KINDS}
+    gaps_of = {(w, name): expect for w in ("single_cases", "multi_cases") for name, _b, _o, _n, expect in kat.cases(w)}
+    assert len(vec["lists"]) > 50 and len(vec["posting_lists"]) == 8
+
+    def same(payload: bytes, v) -> bool:
+        return len(payload) == v["bytes"] and (payload.hex() == v["payload"] if "payload" in v else
+                                               hashlib.sha256(payload).hexdigest() == v["payload_sha256"])
+
+    for v in vec["lists"]:
+        gaps = gaps_of[(v["which"], v["case"])]
+        assert same(builders[v["kind"]].encode_list(gaps, greedy=v["greedy"]).tobytes(), v), v["case"]
+        enc, _ = host.encode_vroom(v["kind"], kat.DICT_FILES[v["kind"]], host.Collection(gaps, np.array([gaps.size], dtype=np.uint32)),
+                                   unit_ints=0, greedy=v["greedy"])
+        hdr = len(oracle.vbyte_encode(gaps.size)) + len(oracle.vbyte_encode(int(gaps.sum(dtype=np.uint64)) & 0xFFFFFFFF))
+        assert same(enc[hdr:].tobytes(), v), v["case"]
+    for v in vec["posting_lists"]:
+        d, fr = np.array(v["docids"], dtype=np.uint32), np.array(v["freqs"], dtype=np.uint32)
+        b = builders[v["kind"]]
+        assert oracle.posting_list_write(b, b, d, fr).tobytes().hex() == v["bytes"]
+        idx, offs = host.build_index(v["kind"], kat.DICT_FILES[v["kind"]], kat.DICT_FILES[v["kind"]], d, fr, np.array([d.size], dtype=np.uint32))
+        assert idx.tobytes().hex() == v["bytes"]
