@@ -231,3 +231,49 @@ def test_list_cache_serves_the_block_coder_call(small_corpus):
         with pytest.raises(device.DintError):
             cache.decode(1, 3)
         cache.close()
+
+
+@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
+def test_a_written_collection_through_every_tool(tmp_path, kind):
+    """The chain a user of the reference runs, tool by tool, on a written .docs / .freqs pair (BASELINE config 5 end to end):
+    dint_build_dict -> dint_encode -> dint_decode --check (the gaps) ; dint_create_freq_index -> dint_queries and / and_freq
+    on a query log from stdin: the totals are the oracle's and_query over the same index, the stats line carries the
+    reference's keys (src/queries.cpp:45-59)."""
+    import oracle
+    from queries import reference_queries
+
+    coll = host.synth_collection(400_000, universe=150_000, seed=41)
+    docids = host.gaps_to_docids(coll)
+    freqs = host.synth_freqs(coll.num_postings, 9)
+    b = coll.list_bounds()
+    base = str(tmp_path / "c")
+    host.write_collection(base, [docids[int(b[i]):int(b[i + 1])] for i in range(len(coll.lens))],
+                          [freqs[int(b[i]):int(b[i + 1])] for i in range(len(coll.lens))], num_docs=150_000)
+    t = TYPES[kind]
+    suffix = {host.SINGLE_PACKED: "single_packed", host.MULTI_PACKED: "multi_packed"}[kind]
+    bin_ = lambda name: os.path.join(ROOT, "dint_amd", "bin", name)
+    run = lambda *a, **kw: subprocess.run(list(a), cwd=tmp_path, capture_output=True, text=True, timeout=900, **kw)
+    r = run(bin_("dint_build_dict"), t, base, "--threads", "4")
+    assert r.returncode == 0, r.stderr
+    dict_docs = str(tmp_path / f"dict.c.docs.{suffix}.DSF-65536-16")
+    r = run(bin_("dint_encode"), t, base + ".docs", "--dict", dict_docs, "--out", str(tmp_path / "docs.enc"), "--threads", "4")
+    assert r.returncode == 0, r.stderr
+    coll.gaps.tofile(tmp_path / "gaps.bin")
+    r = run(bin_("dint_decode"), t, str(tmp_path / "docs.enc"), "--dict", dict_docs, "--check", str(tmp_path / "gaps.bin"))
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["bit_exact"] == "true", r.stderr
+    r = run(bin_("dint_create_freq_index"), t, base, str(tmp_path / "c.index"), "--threads", "4")
+    assert r.returncode == 0, r.stderr
+    qs = [q for q in reference_queries(len(coll.lens))[:120]]
+    log = "\n".join(" ".join(str(int(x)) for x in q) for q in qs) + "\n"
+    r = run(bin_("dint_queries"), t, "and:and_freq:wand", str(tmp_path / "c.index"), "--runs", "3", "--batch", input=log)
+    assert r.returncode == 0, r.stderr
+    assert "Unsupported query type: wand" in r.stderr  # src/queries.cpp:108-110
+    f = host.read_index_file(str(tmp_path / "c.index"))
+    oi = oracle.OracleIndex(oracle.OracleDict(kind, f["docs_dict"]), f["index"], f["offsets"], f["num_docs"])
+    want = sum(oi.and_query(q) for q in qs)
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 4 and int(lines[0]) == 3 * want and int(lines[2]) == 3 * want
+    for text, name in ((lines[1], "and"), (lines[3], "and_freq")):
+        line = json.loads(text)
+        assert line["type"] == t and line["query"] == name and line["avg"] > 0 and line["q50"] <= line["q95"]
+        assert set(("type", "query", "avg", "q50", "q90", "q95")) <= set(line) and line["batch_us_per_query"] > 0
