@@ -162,6 +162,71 @@ __device__ __forceinline__ void and_round_tail(const round_tail& t) {
         t.host_counts[q] = __hip_atomic_load(&t.counts[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The same for a BATCH (a thread per candidate slot, a workgroup per page): the probe of round r, the release of its claims
+// and the block-max search of round r + 1 in ONE launch — until round 5 the batch path ran them as two (and_probe_release_kernel,
+// and_search_kernel): a launch per round less, of three. The two rounds' claim flags / ranks / touched lists alternate
+// between two sets, as in and_round_tail. Behind the last round: the survivors counted per query and handed to the host by
+// the workgroup that finishes last (t.done: zero at launch).
+__global__ void and_round_tail_kernel(round_tail t) {
+    const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < *t.n_touched) t.needed[t.touched[i]] = 0;
+    uint32_t gb = kDeadCandidate;
+    bool alive = false;
+    if (i < t.n_slots) {
+        const uint32_t c = t.cand[i];
+        if (c != kDeadCandidate) {
+            const uint32_t q = t.page_query[i / kPageSlots];
+            alive = true;
+            if (t.term_blocks[q] != 0) {
+                const uint32_t b = t.target[i];
+                const uint32_t n = t.blocks[b].n;
+                const uint32_t* page = t.probe + uint64_t(t.rank[b]) * kPageSlots;
+                const uint32_t pos = lower_bound_u32(page, n, c);
+                alive = pos != n && page[pos] == c;
+            }
+            if (alive && t.next_blocks) {
+                const uint32_t nb = t.next_blocks[q];
+                if (nb) {
+                    const uint32_t fb = t.next_first[q];
+                    const uint32_t pos = lower_bound_u32(t.block_max + fb, nb, c);
+                    if (pos == nb) {
+                        alive = false;  // next_geq past the last block: m_universe, dict_posting_list.hpp:128-131
+                    } else {
+                        gb = fb + pos;
+                        t.target[i] = gb;
+                    }
+                }
+            }
+            if (!alive) t.cand[i] = kDeadCandidate;
+        }
+    }
+    if (t.next_blocks) {  // (uniform) the next round's claims: one per run of candidates that fall into the same block
+        const uint32_t prev = __shfl_up(gb, 1);
+        const bool lead = gb != kDeadCandidate && ((threadIdx.x & 63u) == 0 || prev != gb);
+        if (lead && atomicExch(&t.next_needed[gb], 1u) == 0u) {
+            const uint32_t k = atomicAdd(t.next_n_touched, 1u);
+            t.next_touched[k] = gb;
+            t.next_rank[gb] = k;
+        }
+        return;
+    }
+    const int n = __syncthreads_count(alive);
+    if (threadIdx.x == 0 && n) atomicAdd(&t.counts[t.page_query[i / kPageSlots]], (unsigned long long)n);
+    if (!t.host_counts) return;  // (uniform)
+    __shared__ uint32_t last;
+    if (gridDim.x != 1) {
+        if (threadIdx.x == 0) {
+            __threadfence();
+            last = atomicAdd(t.done, 1u) == gridDim.x - 1 ? 1u : 0u;
+        }
+        __syncthreads();
+        if (!last) return;
+        __threadfence();
+    }
+    for (uint32_t q = threadIdx.x; q < t.n_queries; q += blockDim.x)
+        t.host_counts[q] = __hip_atomic_load(&t.counts[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Round step A: block-max search. term_first/term_blocks give, per query, the block range of
 // this round's list (term_blocks == 0: the query has no such term and its candidates pass).
 // Touched blocks are appended once to `touched`, and rank[block] is their position there.

@@ -248,7 +248,7 @@ def test_a_written_collection_through_every_tool(tmp_path, kind):
     b = coll.list_bounds()
     base = str(tmp_path / "c")
     host.write_collection(base, [docids[int(b[i]):int(b[i + 1])] for i in range(len(coll.lens))],
-                          [freqs[int(b[i]):int(b[i + 1])] for i in range(len(coll.lens))], num_docs=150_000)
+                          [freqs[int(b[i]):int(b[i + 1])] for i in range(len(coll.lens))], num_docs=int(docids.max()) + 1)
     t = TYPES[kind]
     suffix = {host.SINGLE_PACKED: "single_packed", host.MULTI_PACKED: "multi_packed"}[kind]
     bin_ = lambda name: os.path.join(ROOT, "dint_amd", "bin", name)
