@@ -111,9 +111,9 @@ constexpr uint32_t kMetaCold = 1u << 23;              // the integers come throu
 constexpr uint32_t kMetaSlow = 1u << 22;              // ... or, with this bit, from gtable through slow_stores
 constexpr uint32_t kMetaOffMask = (1u << 20) - 2;     // hot: byte offset of the integers (u16 each: even) in the LDS image; else 0
                                                       // bits 20-21: staging cells a cold codeword takes (1: up to 6 integers, 2: up to 14, 3)
-constexpr uint32_t kMetaPacked8 = 1u;                // a COLD codeword of 7..12 integers, all below 256: its 16-byte head holds them all, a byte each
-                                                      // (two staging cells, no tail request) — 6.2 % of the bench stream's codewords are such
-                                                      // (cold, eight integers), every one a 32-byte request less
+constexpr uint32_t kMetaPacked8 = 1u;                // a COLD codeword of eight integers, all below 256: its 16-byte head holds them all, a byte each
+                                                      // (two staging cells, no tail request) — 6.2 % of the bench stream's codewords are such,
+                                                      // every one a 32-byte request less
 constexpr uint32_t kMetaException = 1u << 20;         // what the two exception markers (slot values 0 and 1) look up: one integer, one
                                                       // staging cell — the literal that follows the marker in the stream goes there
 constexpr uint32_t kQueueShards = 8;                  // dynamic unit queue: one counter per shard
