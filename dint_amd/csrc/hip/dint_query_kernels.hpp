@@ -121,28 +121,31 @@ __device__ __forceinline__ void and_round_tail(const round_tail& t) {
     for (uint32_t k = threadIdx.x; k < nt; k += blockDim.x) t.needed[t.touched[k]] = 0;
     for (uint64_t i = threadIdx.x; i < t.n_slots; i += blockDim.x) {
         uint32_t gb = kDeadCandidate;
+        // (what a candidate needs is asked for in as few dependent trips as its data allow: {candidate, its query, its target
+        // block} -> {the query's block counts in this round and the next} -> {the target's size and page} -> the probe -> the
+        // next round's block maxima. K-ary searches — 15 pivots a step, 2 trips for a block instead of 8 — were measured:
+        // 29.0 against 27.4 us a query, the one CU's load issue is what they cost)
         const uint32_t c = t.cand[i];
+        const uint32_t q = t.page_query[i / kPageSlots];
+        const uint32_t b_raw = t.target[i];  // (only meaningful where this round has a term for q: masked below)
         if (c != kDeadCandidate) {
-            const uint32_t q = t.page_query[i / kPageSlots];
+            const uint32_t tb = t.term_blocks[q];
+            uint32_t nb = 0, fb = 0;
+            if (t.next_blocks) nb = t.next_blocks[q], fb = t.next_first[q];
             bool alive = true;
-            if (t.term_blocks[q] != 0) {
-                const uint32_t b = t.target[i];
-                const uint32_t n = t.blocks[b].n;
-                const uint32_t* page = t.probe + uint64_t(t.rank[b]) * kPageSlots;
+            if (tb != 0) {
+                const uint32_t n = t.blocks[b_raw].n;
+                const uint32_t* page = t.probe + uint64_t(t.rank[b_raw]) * kPageSlots;
                 const uint32_t pos = lower_bound_u32(page, n, c);
                 alive = pos != n && page[pos] == c;
             }
-            if (alive && t.next_blocks) {
-                const uint32_t nb = t.next_blocks[q];
-                if (nb) {
-                    const uint32_t fb = t.next_first[q];
-                    const uint32_t pos = lower_bound_u32(t.block_max + fb, nb, c);
-                    if (pos == nb) {
-                        alive = false;
-                    } else {
-                        gb = fb + pos;
-                        t.target[i] = gb;
-                    }
+            if (alive && nb) {
+                const uint32_t pos = lower_bound_u32(t.block_max + fb, nb, c);
+                if (pos == nb) {
+                    alive = false;
+                } else {
+                    gb = fb + pos;
+                    t.target[i] = gb;
                 }
             }
             if (!alive) t.cand[i] = kDeadCandidate;

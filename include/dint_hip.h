@@ -93,7 +93,9 @@ typedef enum dint_option {
                                       /* by the launch's size                                                                   */
     DINT_OPT_INDEX_PAIR = 7,          /* 1 (default): once a table's schedules are known, docs parts, short blocks and freqs     */
                                       /* parts of a decode are ONE launch; 0: a launch each                                      */
-    DINT_OPT_COUNT_ = 8
+    DINT_OPT_QUERY_FUSED_COPY = 8,    /* 1 (default): the one-launch query form's workgroup fetches the call's inputs from the   */
+                                      /* host's pinned memory itself; 0: a copy on the stream in front of the launch            */
+    DINT_OPT_COUNT_ = 9
 } dint_option;
 int dint_set_option(int option, long long value);
 int dint_get_option(int option, long long* value);

@@ -31,6 +31,7 @@ def main():
     args.forms = [("round_per_launch_no_fusing", {"query_fused_pages": 0}),
                   ("whole_query_in_one_launch_up_to_1_page", {"query_fused_pages": 1}),
                   ("whole_query_in_one_launch_up_to_4_pages", {"query_fused_pages": 4}),
+                  ("one_launch_inputs_copied_on_the_stream", {"query_fused_copy": 0}),
                   ("three_launches_per_decode", {"query_lean_pages": 0}),
                   ("one_launch_per_decode", {"query_tail_pages": 0}),
                   ("round_tail_up_to_4_pages", {"query_tail_pages": 4}),
@@ -63,12 +64,24 @@ def main():
     for name, qs in workloads.items():
         counts = qi.and_queries(qs)  # warm-up (and the first, untimed pass)
         pages = [min(-(-int(coll.lens[t]) // 256) for t in q) for q in qs if len(q)]
-        t_batch = []
-        for _ in range(args.runs):
+        # the batch call as a C++ caller makes it: the log parsed (packed) beforehand, like the single calls below and the
+        # oracle's parallel leg; `gpu_batch_from_python_lists` is the same through and_queries(), which packs the lists first
+        b_terms = np.ascontiguousarray(np.concatenate([np.asarray(q, dtype=np.uint32) for q in qs]), dtype=np.uint32)
+        b_offs = np.zeros(len(qs) + 1, dtype=np.uint64)
+        np.cumsum([len(q) for q in qs], out=b_offs[1:])
+        b_counts = np.zeros(len(qs), dtype=np.uint64)
+        b_stream = torch.cuda.current_stream().cuda_stream
+        qi.and_queries_packed(b_terms, b_offs, b_counts, b_stream)
+        assert np.array_equal(b_counts, counts)
+        t_batch, t_lists = [], []
+        for _ in range(max(args.runs, 5)):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            qi.and_queries(qs)
+            qi.and_queries_packed(b_terms, b_offs, b_counts, b_stream)
             t_batch.append(time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            qi.and_queries(qs)
+            t_lists.append(time.perf_counter() - t0)
         batch_forms = {}
         for form, env in ([("three_launches_per_decode", {"query_lean_pages": 0}),
                            ("one_launch_per_decode", {"query_lean_pages": 1000000000})] if args.forms else []):
@@ -140,6 +153,7 @@ def main():
         out[name] = {
             "queries": len(qs), "results": int(counts.sum()),
             "gpu_batch_us_per_query": min(t_batch) * 1e6 / len(qs),
+            "gpu_batch_from_python_lists_us_per_query": min(t_lists) * 1e6 / len(qs),
             "gpu_single": {"avg": float(single.mean()), "q50": pct(single, 50), "q90": pct(single, 90), "q95": pct(single, 95)},
             "gpu_single_avg_by_form": forms,
             "gpu_batch_us_per_query_by_form": batch_forms,

@@ -118,13 +118,17 @@ def test_both_page_decode_forms(device, small_corpus, kind, lean_pages):
     qi.close()
 
 
-@pytest.mark.parametrize("fused_pages", ["0", "1", "4"])
+@pytest.mark.parametrize("fused_pages", ["0", "1", "4", "4, inputs copied on the stream"])
 @pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
 def test_whole_query_in_one_launch(device, small_corpus, kind, fused_pages):
     """A query of a few candidate pages runs as ONE launch of one workgroup that walks the whole chain — candidates, every
     round's pages, every round's tail (query_fused_body); the option query_fused_pages moves the switch (0: never — the
     round-per-launch form). Single queries and the freqs variant (whose counting half takes the same path), all forms
-    equal to the plain intersection."""
+    equal to the plain intersection. The one workgroup fetches the call's inputs from pinned host memory itself
+    (query_fused_copy = 0: a copy on the stream in front of the launch, as the other forms have it)."""
+    if "," in fused_pages:
+        device.set_option("query_fused_copy", 0)
+        fused_pages = fused_pages.split(",")[0]
     device.set_option("query_fused_pages", int(fused_pages))
     device.set_option("query_tail_pages", 4)
     ix = get_index(small_corpus, kind)

@@ -19,6 +19,7 @@ ap.add_argument("--unit-ints", type=int, default=8192)
 ap.add_argument("--rounds", type=int, default=6)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--json", default=None)
+ap.add_argument("--table", action="store_true", help="decode through a prepared unit table (dint_unit_table_create / dint_decode_unit_table)")
 ap.add_argument("libs", nargs="+")
 args = ap.parse_args()
 
@@ -37,6 +38,7 @@ stream = torch.cuda.current_stream(dev).cuda_stream
 vp, sz = C.c_void_p, C.c_size_t
 
 builds = []
+tables = {}
 for spec in args.libs:
     name, path = spec.split("=", 1)
     lib = C.CDLL(os.path.abspath(path))
@@ -46,12 +48,21 @@ for spec in args.libs:
     h = vp()
     buf = (C.c_char * len(dict_file)).from_buffer_copy(dict_file)
     assert lib.dint_dict_create(kind, C.addressof(buf), len(dict_file), 0, C.byref(h)) == 0, name
+    tab = vp()
+    if args.table:
+        lib.dint_unit_table_create.argtypes = [vp, vp, sz, vp, sz, sz, vp, C.POINTER(vp)]
+        lib.dint_decode_unit_table.argtypes = [vp, vp, vp, sz, vp, vp]
+        assert lib.dint_unit_table_create(h, enc_dev.data_ptr(), enc.size, units_dev.data_ptr(), len(units), coll.num_postings, stream, C.byref(tab)) == 0
+    tables[name] = tab
     builds.append((name, lib, h))
 
 
-def launch(lib, h):
-    st = lib.dint_decode_units(h, enc_dev.data_ptr(), enc.size, units_dev.data_ptr(), len(units), out_dev.data_ptr(),
-                               coll.num_postings, end_dev.data_ptr(), stream)
+def launch(lib, h, name=None):
+    if args.table:
+        st = lib.dint_decode_unit_table(h, tables[name], out_dev.data_ptr(), coll.num_postings, end_dev.data_ptr(), stream)
+    else:
+        st = lib.dint_decode_units(h, enc_dev.data_ptr(), enc.size, units_dev.data_ptr(), len(units), out_dev.data_ptr(),
+                                   coll.num_postings, end_dev.data_ptr(), stream)
     assert st == 0, st
     torch.cuda.synchronize(dev)
     ms = C.c_float()
@@ -63,14 +74,14 @@ times = {name: [] for name, _, _ in builds}
 for name, lib, h in builds:  # warm-up + correctness
     out_dev.zero_()
     for _ in range(3):
-        launch(lib, h)
+        launch(lib, h, name)
     ok = bool(np.array_equal(out_dev.cpu().numpy().view(np.uint32), coll.gaps))
     print(f"{name}: bit-exact {ok}", flush=True)
     assert ok or os.environ.get("AB_NO_ASSERT"), name
 for r in range(args.rounds):
     for name, lib, h in builds:
         for _ in range(args.reps):
-            times[name].append(launch(lib, h))
+            times[name].append(launch(lib, h, name))
 algo = 4 * coll.num_postings + enc.size  # (headers included: a slight over-count, the same for every build)
 res = {}
 for name, _, _ in builds:

@@ -16,6 +16,10 @@ __device__ unsigned long long g_prof[kProfSections];
 constexpr uint32_t kProfCus = 8 * 256;
 __device__ unsigned long long g_cu[kProfCus * 4];
 
+// The one-launch query form (query_fused_body): thread 0's clock at its phase boundaries, of the LAST launch.
+__device__ unsigned long long g_qtrace[32];
+#define QTRACE(k) do { if (threadIdx.x == 0 && (k) < 32) g_qtrace[(k)] = __builtin_amdgcn_s_memtime(); } while (0)
+
 struct prof_t {
     uint32_t last = 0, id = 0;
     uint32_t* acc = nullptr;  // kProfSections words in LDS, this wave's
@@ -25,7 +29,7 @@ struct prof_t {
 
 __device__ __forceinline__ void prof_stamp(prof_t& p, uint32_t id) {
     const uint32_t now = uint32_t(__builtin_amdgcn_s_memtime());
-    if (p.lane == 0) __hip_atomic_fetch_add(p.acc + p.id, now - p.last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (p.acc && p.lane == 0) __hip_atomic_fetch_add(p.acc + p.id, now - p.last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     p.last = now;
     p.id = id;
     if (id == 14) ++p.items;  // (the queue's draw: one work item)
