@@ -124,6 +124,8 @@ constexpr uint32_t kChunkCounterLineAt = 1;           // ... which begin this ma
 // on the 1e9-posting run — 1.496 against 1.478 ms, no gain: its tickets are asked for a work item ahead and are few)
 constexpr uint32_t kQueueLines = kQueueShards + 1 + kChunkShards;  // a launch's counters: unit-queue shards | the clock's line | chunk counters
 constexpr uint32_t kClockWordAt = 16;                 // in the chunk counter's line: shader-clock cycles of the launch's first wave (u64)
+constexpr uint32_t kChunkDryWordAt = 24;              // ... a bit per chunk counter that a wave has found dry (next_open_counter)
+constexpr uint32_t kUnitDryWordAt = 25;               // ... and per unit-queue shard
 constexpr uint32_t kMaxUnitInts = 1u << 28;           // byte offsets inside a unit's output stay 32-bit
 
 #include "kernels/wave_basics.inc"
