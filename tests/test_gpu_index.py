@@ -20,6 +20,12 @@ def device():
     return dev
 
 
+@pytest.fixture(autouse=True)
+def _options_back_to_default(device):
+    yield
+    device.reset_options()
+
+
 @pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.RECTANGULAR, host.MULTI_PACKED])
 @pytest.mark.parametrize("corpus_name", ["small_corpus", "dense_corpus", "sparse_corpus"])
 def test_posting_lists_match_oracle(device, request, kind, corpus_name):
@@ -255,18 +261,26 @@ def test_short_blocks_inside_the_docs_launch_or_in_their_own(device, small_corpu
 
 
 @pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
-def test_blocks_that_fit_no_tile_take_the_second_launch(device, small_corpus, kind):
+def test_blocks_that_fit_no_tile(device, small_corpus, kind):
     """A full block whose 256 postings are nearly all exceptions is more than 504 bytes and fits no tile: the bundle schedule
     leaves it to the unit queue, and once a prepared table's schedules are known such stragglers go through a small second
     launch of the general kernel while everything else runs the kernels compiled without the queue (one launch for docs +
-    short blocks + freqs). Three lists of 700 gaps of 70 000 and more each — 32-bit literals, six bytes a posting — among an
-    ordinary collection; five decodes (the pair launch from the third), against the encoder's input and the oracle's walk."""
+    short blocks + freqs). Lists of 700 postings among an ordinary
+    collection: gaps of 70 000 and more (32-bit literals, six bytes a posting); literals alternating with the collection's
+    own small gaps (hot and cold dictionary entries between exceptions); runs of consecutive docIDs (run codewords) between
+    literals. Five decodes (the pair launch from the third), against the encoder's input and the oracle's walk."""
     import torch
 
     coll = small_corpus.coll
     r = np.random.default_rng(99)
-    extra = [r.integers(70_000, 400_000, 700, dtype=np.uint64).astype(np.uint32) for _ in range(3)]
-    where = [5, len(coll.lens) // 2, len(coll.lens) - 3]   # the stragglers' lists among the others
+    extra = [r.integers(70_000, 400_000, 700, dtype=np.uint64).astype(np.uint32) for _ in range(2)]
+    alt = r.integers(70_000, 400_000, 700, dtype=np.uint64).astype(np.uint32)
+    alt[1::2] = coll.gaps[1000:1000 + 350]                 # every other gap one of the corpus's own
+    runs = r.integers(1_000, 60_000, 700, dtype=np.uint64).astype(np.uint32)  # 16-bit literals ...
+    for at in range(0, 700, 50):
+        runs[at:at + 17] = 0                                # ... and runs of consecutive docIDs
+    extra += [alt, runs]
+    where = [5, len(coll.lens) // 3, len(coll.lens) // 2, len(coll.lens) - 3]   # the stragglers' lists among the others
     b = coll.list_bounds()
     gaps_parts, lens = [], []
     for i in range(len(coll.lens)):
@@ -284,7 +298,7 @@ def test_blocks_that_fit_no_tile_take_the_second_launch(device, small_corpus, ki
     idx, offs = host.build_index(kind, docs_dict, freqs_dict, docids, freqs, big.lens)
     blocks, total = device.index_posting_lists(idx, offs)
     spans = np.diff(np.r_[blocks["in_off"], idx.size].astype(np.int64))
-    assert ((blocks["n"] == 256) & (spans > 1200)).sum() >= 6, "no block too long for a tile in this index"
+    assert ((blocks["n"] == 256) & (spans > 1200)).sum() >= 4 and ((blocks["n"] == 256) & (spans > 520)).sum() >= 8, "no block too long for a tile in this index"
     dd, fd = device.Dictionary(kind, docs_dict), device.Dictionary(kind, freqs_dict)
     dev = torch.device("cuda", 0)
     padded = np.concatenate([idx, np.zeros(16, np.uint8)])
