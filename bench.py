@@ -734,7 +734,11 @@ def main():
                                          "process's very first device allocation",
                 "traffic": traffic,
                 "traffic_note": traffic_note,
-                "kernel": KERNEL_BY_TYPE[args.type],
+                # (a prepared multi-dictionary table of block-granular units: the kernel compiled without the unit queue, and behind
+                # it, inside the same event pair, the general kernel for the units that fit no tile — about one in a hundred)
+                "kernel": ("decode_multi_bundles_kernel (+ decode_multi_kernel: the units that fit no tile)"
+                           if args.type == "multi_packed_dint" and unit_table is not None and args.unit_ints <= 256
+                           else KERNEL_BY_TYPE[args.type]),
                 "kernel_ms": round(k_mean, 4),
                 "kernel_ms_min_median_max": [round(float(kernel_ms.min()), 4), round(float(np.median(kernel_ms)), 4),
                                              round(float(kernel_ms.max()), 4)],

@@ -17,12 +17,17 @@ needle = sys.argv[6] if len(sys.argv) > 6 else "decode_"
 
 
 def mean_counter(d, name):
-    vals = []
+    """per STEP: a step may be more than one dispatch (the multi-dictionary table: the bundles-only kernel, then the general
+    kernel for the units that fit no tile) — everything that matches, over the dispatches of the kernel that ran most often"""
+    total, per_kernel = 0.0, {}
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             if needle in row["Kernel_Name"] and row["Counter_Name"] == name:
-                vals.append(float(row["Counter_Value"]))
-    return sum(vals) / len(vals), len(vals)
+                total += float(row["Counter_Value"])
+                k = row["Kernel_Name"].split("(")[0]
+                per_kernel[k] = per_kernel.get(k, 0) + 1
+    steps = max(per_kernel.values())
+    return total / steps, steps
 
 
 fetch_kb, nf = mean_counter(fetch_dir, "FETCH_SIZE")
