@@ -280,6 +280,9 @@ int dint_block_table_info_get(const dint_block_table* table, dint_block_table_in
  * that — and with those options off — the freqs launch and the short blocks' decoder run on streams the table owns,
  * beside the docs launch, forked from and joined to `stream` inside the call; to the caller everything is ordered on
  * `stream` either way (dint_set_option(DINT_OPT_INDEX_CONCURRENT, 0): one stream, one launch after the other).
+ * ONE STREAM AT A TIME: a table's decodes share its launch counters (two sets, taken in turn: the one-launch decode clears
+ * the set of the decode after it instead of a fill per call) — successive decodes of one table must be ordered on the GPU
+ * (the same stream, or streams the caller orders); two tables over one index are independent.
  * CONTENT STABILITY: what the table learns in its first complete decode (exact byte spans, the freqs parts' units, both
  * bundle schedules — which bake in the blocks' selector bytes of a multi-dictionary index) is kept and keyed by the
  * dictionaries, the index POINTER and its size, not by the bytes: while the table lives, the index at d_index must keep
