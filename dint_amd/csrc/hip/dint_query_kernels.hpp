@@ -113,6 +113,7 @@ struct round_tail {
     unsigned long long* counts;
     unsigned long long* host_counts;  // nullable (pinned host memory, as the device sees it)
     uint32_t n_queries;
+    uint32_t q_first;                 // and_round_tail (one workgroup): the queries [q_first, q_first + n_queries) are handed over
 };
 
 // (every thread of one workgroup; n_slots is a multiple of 256, so wavefronts stay whole inside the loop)
@@ -161,7 +162,7 @@ __device__ __forceinline__ void and_round_tail(const round_tail& t) {
     }
     if (t.next_blocks || !t.host_counts) return;
     __syncthreads();
-    for (uint32_t q = threadIdx.x; q < t.n_queries; q += blockDim.x)
+    for (uint32_t q = t.q_first + threadIdx.x; q < t.q_first + t.n_queries; q += blockDim.x)
         t.host_counts[q] = __hip_atomic_load(&t.counts[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 

@@ -95,7 +95,9 @@ typedef enum dint_option {
                                       /* parts of a decode are ONE launch; 0: a launch each                                      */
     DINT_OPT_QUERY_FUSED_COPY = 8,    /* 1 (default): the one-launch query form's workgroup fetches the call's inputs from the   */
                                       /* host's pinned memory itself; 0: a copy on the stream in front of the launch            */
-    DINT_OPT_COUNT_ = 9
+    DINT_OPT_QUERY_BATCH_FUSED = 9,   /* 1 (default): a call whose queries all have few candidate pages runs as ONE launch, a      */
+                                      /* workgroup per query; 0: the round-per-launch batch form                                */
+    DINT_OPT_COUNT_ = 10
 } dint_option;
 int dint_set_option(int option, long long value);
 int dint_get_option(int option, long long* value);

@@ -83,15 +83,17 @@ def main():
             qi.and_queries(qs)
             t_lists.append(time.perf_counter() - t0)
         batch_forms = {}
-        for form, env in ([("three_launches_per_decode", {"query_lean_pages": 0}),
-                           ("one_launch_per_decode", {"query_lean_pages": 1000000000})] if args.forms else []):
+        for form, env in ([("three_launches_per_decode", {"query_lean_pages": 0, "query_batch_fused": 0}),
+                           ("one_launch_per_decode", {"query_lean_pages": 1000000000, "query_batch_fused": 0}),
+                           ("a_workgroup_per_query", {"query_batch_fused": 1})] if args.forms else []):
             for k, v in env.items():
                 device.set_option(k, v)
-            qi.and_queries(qs)
+            qi.and_queries_packed(b_terms, b_offs, b_counts, b_stream)
+            assert np.array_equal(b_counts, counts)
             ts = []
             for _ in range(args.runs):
                 t0 = time.perf_counter()
-                qi.and_queries(qs)
+                qi.and_queries_packed(b_terms, b_offs, b_counts, b_stream)
                 ts.append(time.perf_counter() - t0)
             batch_forms[form] = min(ts) * 1e6 / len(qs)
             device.reset_options()

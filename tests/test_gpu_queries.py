@@ -50,6 +50,33 @@ def test_batch_matches_oracle(device, request, kind, corpus_name):
     qi.close()
 
 
+@pytest.mark.parametrize("batch_fused", [1, 0])
+@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
+@pytest.mark.parametrize("corpus_name", ["small_corpus", "sparse_corpus"])
+def test_a_call_of_small_queries(device, request, kind, corpus_name, batch_fused):
+    """A call whose queries all have at most 16 candidate pages is ONE launch, a workgroup per query walking the query's whole
+    chain (query_batch_body: per-workgroup claim sets, per-query stretches of the page buffers); query_batch_fused = 0 is the
+    round-per-launch batch form. The reference's log restricted to such queries — more queries than workgroups, so a
+    workgroup walks several and finds the claims the one before released — then a mixed call (the other form), a single
+    query, and the small call again: the forms leave nothing behind for each other."""
+    device.set_option("query_batch_fused", batch_fused)
+    corpus = request.getfixturevalue(corpus_name)
+    ix = get_index(corpus, kind)
+    qi = _query_index(device, ix, kind)
+    every = reference_queries(len(ix.lens)) + heavy_queries(ix.lens, 60, seed=3)
+    small = [q for q in every if len(set(q)) >= 2 and min(int(ix.lens[t]) for t in q) <= 16 * 256]
+    assert len(small) >= 250, "this corpus has too few lists of at most 16 blocks"
+    small = (small * 3)[:900] + [[small[0][0]] * 3, [], small[1][:1]]   # (+ a repeated term, an empty query, a single term)
+    assert len(small) > 600
+    want = np.array([intersect(ix.docids, ix.bounds, q) for q in small], dtype=np.uint64)
+    assert np.array_equal(qi.and_queries(small), want) and int(want.sum()) > 100
+    mixed = every[:200]
+    assert np.array_equal(qi.and_queries(mixed), np.array([intersect(ix.docids, ix.bounds, q) for q in mixed], dtype=np.uint64))
+    assert int(qi.and_queries([small[5]])[0]) == int(want[5])
+    assert np.array_equal(qi.and_queries(small), want)
+    qi.close()
+
+
 def test_one_query_at_a_time_and_workspace_reuse(device, small_corpus):
     """op_perftest runs the queries one by one (src/queries.cpp:15-61)."""
     kind = host.SINGLE_PACKED
