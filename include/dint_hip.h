@@ -323,10 +323,13 @@ void dint_query_index_destroy(dint_query_index* qi);
 /* counts[q] = number of documents that contain every term of query q (duplicate terms count
  * once, queries.hpp:28-31; an empty query counts 0, :38). terms/query_offsets/counts are HOST
  * arrays: query q is terms[query_offsets[q] .. query_offsets[q+1]). A term >= n_lists is
- * DINT_ERR_ARG. The call enqueues on `stream` and returns after synchronising it: one copy in, then one launch
- * per term for a query of a few pages, three per round for a batch. Which form a call
- * takes is moved, for tests and measurements, by dint_set_option: DINT_OPT_QUERY_LEAN_PAGES, DINT_OPT_QUERY_TAIL_PAGES,
- * DINT_OPT_QUERY_FUSED_PAGES. */
+ * DINT_ERR_ARG. The call enqueues on `stream` and returns after synchronising it: ONE launch for a single query of a
+ * page or two of candidates and for a call whose queries all have at most 16 candidate pages (a workgroup per query); a
+ * round per launch for a single query of a few pages; one copy in and two launches per round for a batch of larger
+ * queries; a mixed call is split into its small and its other queries. Which form a call takes is moved,
+ * for tests and measurements, by dint_set_option: DINT_OPT_QUERY_LEAN_PAGES, DINT_OPT_QUERY_TAIL_PAGES,
+ * DINT_OPT_QUERY_FUSED_PAGES, DINT_OPT_QUERY_FUSED_COPY, DINT_OPT_QUERY_BATCH_FUSED. The batch form's per-workgroup claim
+ * tables take up to 3 GB of device memory (24 bytes per index block and workgroup), allocated at the first such call. */
 int dint_and_queries(dint_query_index* qi, const uint32_t* terms, const uint64_t* query_offsets,
                      size_t n_queries, uint64_t* counts, void* stream);
 
