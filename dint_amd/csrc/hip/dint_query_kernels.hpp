@@ -80,6 +80,45 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* a, uint32_t 
     return lo;
 }
 
+// Claims: a round's searches name the blocks that must be decoded, each ONCE — whoever claims a block first appends it to the
+// touched list, and its place there (its page in the probe buffer) is what every candidate of the block looks up afterwards.
+// Two forms. Dense (hash_mask == 0): a flag and a rank per block of the INDEX (`needed`, `rank`: n_blocks words each) — the
+// forms in which one set serves the whole call. Hashed (hash_mask = capacity - 1): `needed` holds block + 1 at the block's
+// slot of an open-addressing table, `rank` the place — a table per WORKGROUP for the workgroup-per-query batch form, sized
+// for a query's rounds (at most 4096 touched blocks), not for the index. The keys are written and read at the L2 (atomics):
+// a workgroup walks query after query over the same table, and this CU's L1 may still hold a line of the query before.
+__device__ __forceinline__ uint32_t claim_slot(uint32_t gb, uint32_t hash_mask) { return ((gb * 2654435761u) >> 9) & hash_mask; }
+__device__ __forceinline__ void claim_block(uint32_t* needed, uint32_t* rank, uint32_t* touched, uint32_t* n_touched, uint32_t hash_mask,
+                                            uint32_t gb) {
+    if (hash_mask == 0) {
+        if (atomicExch(&needed[gb], 1u) == 0u) {
+            const uint32_t k = atomicAdd(n_touched, 1u);
+            touched[k] = gb;
+            rank[gb] = k;
+        }
+        return;
+    }
+    for (uint32_t h = claim_slot(gb, hash_mask);; h = (h + 1u) & hash_mask) {
+        const uint32_t old = atomicCAS(&needed[h], 0u, gb + 1u);
+        if (old == 0u) {
+            const uint32_t k = atomicAdd(n_touched, 1u);
+            touched[k] = gb;
+            __hip_atomic_store(&rank[h], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (old == gb + 1u) return;
+    }
+}
+// the place of a claimed block in the touched list (a later phase than its claim: a barrier lies between)
+__device__ __forceinline__ uint32_t claimed_rank(const uint32_t* needed, const uint32_t* rank, uint32_t hash_mask, uint32_t gb) {
+    if (hash_mask == 0) return rank[gb];
+    for (uint32_t h = claim_slot(gb, hash_mask);; h = (h + 1u) & hash_mask) {
+        const uint32_t key = __hip_atomic_load(&needed[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (key == gb + 1u) return __hip_atomic_load(&rank[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (key == 0u) return 0u;  // (not claimed: no caller asks)
+    }
+}
+
 // A whole round behind its decode, in the decode's own launch (few candidates — a single query: a launch less is a
 // tenth of what the caller waits): the workgroup of decode_*_query_kernel that finishes last probes every candidate in
 // the pages just decoded (and_probe_release_kernel), and either searches the NEXT round's list for the survivors
@@ -114,12 +153,16 @@ struct round_tail {
     unsigned long long* host_counts;  // nullable (pinned host memory, as the device sees it)
     uint32_t n_queries;
     uint32_t q_first;                 // and_round_tail (one workgroup): the queries [q_first, q_first + n_queries) are handed over
+    uint32_t hash_mask;               // and_round_tail: 0, or the claim tables are hashed ones of this capacity - 1 (claim_block)
 };
 
 // (every thread of one workgroup; n_slots is a multiple of 256, so wavefronts stay whole inside the loop)
 __device__ __forceinline__ void and_round_tail(const round_tail& t) {
     const uint32_t nt = *t.n_touched;
-    for (uint32_t k = threadIdx.x; k < nt; k += blockDim.x) t.needed[t.touched[k]] = 0;
+    // (release of this round's claims: dense flags right away — the probes below read ranks, not flags; a hashed table holds
+    // the ranks' keys and is cleared behind the probes, see the end)
+    if (t.hash_mask == 0)
+        for (uint32_t k = threadIdx.x; k < nt; k += blockDim.x) t.needed[t.touched[k]] = 0;
     for (uint64_t i = threadIdx.x; i < t.n_slots; i += blockDim.x) {
         uint32_t gb = kDeadCandidate;
         // (what a candidate needs is asked for in as few dependent trips as its data allow: {candidate, its query, its target
@@ -136,7 +179,7 @@ __device__ __forceinline__ void and_round_tail(const round_tail& t) {
             bool alive = true;
             if (tb != 0) {
                 const uint32_t n = t.blocks[b_raw].n;
-                const uint32_t* page = t.probe + uint64_t(t.rank[b_raw]) * kPageSlots;
+                const uint32_t* page = t.probe + uint64_t(claimed_rank(t.needed, t.rank, t.hash_mask, b_raw)) * kPageSlots;
                 const uint32_t pos = lower_bound_u32(page, n, c);
                 alive = pos != n && page[pos] == c;
             }
@@ -154,11 +197,11 @@ __device__ __forceinline__ void and_round_tail(const round_tail& t) {
         }
         const uint32_t prev = __shfl_up(gb, 1);
         const bool lead = gb != kDeadCandidate && ((threadIdx.x & 63u) == 0 || prev != gb);
-        if (lead && atomicExch(&t.next_needed[gb], 1u) == 0u) {
-            const uint32_t k = atomicAdd(t.next_n_touched, 1u);
-            t.next_touched[k] = gb;
-            t.next_rank[gb] = k;
-        }
+        if (lead) claim_block(t.next_needed, t.next_rank, t.next_touched, t.next_n_touched, t.hash_mask, gb);
+    }
+    if (t.hash_mask != 0 && nt != 0) {  // every probe has read its rank: this round's table is cleared for the round after next
+        __syncthreads();
+        for (uint32_t h = threadIdx.x; h <= t.hash_mask; h += blockDim.x) t.needed[h] = 0;
     }
     if (t.next_blocks || !t.host_counts) return;
     __syncthreads();

@@ -328,8 +328,8 @@ void dint_query_index_destroy(dint_query_index* qi);
  * round per launch for a single query of a few pages; one copy in and two launches per round for a batch of larger
  * queries; a mixed call is split into its small and its other queries. Which form a call takes is moved,
  * for tests and measurements, by dint_set_option: DINT_OPT_QUERY_LEAN_PAGES, DINT_OPT_QUERY_TAIL_PAGES,
- * DINT_OPT_QUERY_FUSED_PAGES, DINT_OPT_QUERY_FUSED_COPY, DINT_OPT_QUERY_BATCH_FUSED. The batch form's per-workgroup claim
- * tables take up to 3 GB of device memory (24 bytes per index block and workgroup), allocated at the first such call. */
+ * DINT_OPT_QUERY_FUSED_PAGES, DINT_OPT_QUERY_FUSED_COPY, DINT_OPT_QUERY_BATCH_FUSED. The batch form keeps two hashed
+ * claim tables per workgroup (160 KB each workgroup, 40 MB in all, whatever the index's size), allocated at the first such call. */
 int dint_and_queries(dint_query_index* qi, const uint32_t* terms, const uint64_t* query_offsets,
                      size_t n_queries, uint64_t* counts, void* stream);
 
