@@ -12,7 +12,7 @@ are partitioned statically across ranks, the dictionary is replicated, and
 there is no data-path collective: the only collectives are the dictionary
 broadcast during set-up and the max-over-ranks of the elapsed time. The two big
 buffers (the encoded stream, the output) are chosen during set-up among
---placement-trials (4) candidates each, ranked by the library's own call for that
+--placement-trials (6) candidates each, ranked by the library's own call for that
 (dint_unit_table_rank_outputs): the kernel's time depends by 10-17 % on where
 the driver puts the pair; what the process's FIRST
 allocation reaches is reported next to it (value_first_allocation,
@@ -61,8 +61,8 @@ def parse_args(argv=None):
                     help="set-up generates, encodes and uploads the rank's shard in pieces of about this many postings (host memory: "
                          "one piece at a time)")
     ap.add_argument("--postings", type=float, default=None, help="postings encoded per GPU (weak scaling: fixed per GPU)")
-    ap.add_argument("--placement-trials", type=int, default=4,
-                    help="N (default 4) candidate output buffers, ranked by the library (dint_unit_table_rank_outputs), then N candidate "
+    ap.add_argument("--placement-trials", type=int, default=6,
+                    help="N (default 6; until round 5: 4 — on one of that round's boxes the first three candidate outputs were all the slow kind) candidate output buffers, ranked by the library (dint_unit_table_rank_outputs), then N candidate "
                          "copies of the stream, allocated during set-up; the pair the decode kernel runs fastest on is kept (the kernel's "
                          "time differs by 10-17 %% with WHERE the driver puts the two buffers: DESIGN.md section 4e). 1: the process's "
                          "first allocation, no selection — the fast level in nine fresh processes in a row on some boxes "
