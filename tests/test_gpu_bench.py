@@ -26,10 +26,10 @@ def test_bench_line_contract(extra):
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["bit_exact"] is True and d["value"] > 0 and d["higher_is_better"] is True and d["dtype"] == "u32"
     assert "workload" in d["config"] and "model" not in d["config"]
-    # by default the pair of big buffers is chosen among four candidates each (the library's dint_unit_table_rank_outputs);
+    # by default the pair of big buffers is chosen among six candidates each (the library's dint_unit_table_rank_outputs);
     # the line says so, carries every candidate's kernel time and what the process's first allocation reached
     trials = d["config"]["placement_trial_kernel_ms"]
-    assert "candidate output buffers" in d["config"]["placement"] and len(trials["output_buffers"]) == 4 and len(trials["stream_buffers"]) == 4
+    assert "candidate output buffers" in d["config"]["placement"] and len(trials["output_buffers"]) == 6 and len(trials["stream_buffers"]) == 6
     assert d["roofline"]["kernel_ms_first_allocation"] == trials["output_buffers"][0] and d["value_first_allocation"] > 0
     assert d["config"]["ints_per_gpu_per_step"] >= 6_000_000 * 0.9 and d["config"]["distinct_postings_per_gpu"] * 2 == d["config"]["ints_per_gpu_per_step"]
     rf = d["roofline"]
