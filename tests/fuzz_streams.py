@@ -224,7 +224,7 @@ def random_slots(r, D, d, n, narrow=False, profile="uniform"):
     ids_out, lits_out = [], []
     left = n
     while left > 0:
-        guess = max(4, min(left, 400))
+        guess = max(4, min(left, 4000))
         if profile == "cold16" and 16 in D.by_size[d] and D.by_size[d][16][-1] < limit:
             c = D.by_size[d][16]
             c = c[c < limit]
@@ -351,6 +351,8 @@ def make_stream(r, D, n_lists, max_n=3000, profiles=STREAM_PROFILES, cut_p=0.05)
         n = int(r.integers(1, 40)) if u < 0.35 else int(r.integers(1, 600)) if u < 0.8 else int(r.integers(1, max_n + 1))
         if r.random() < 0.15:
             n = int(r.choice([1, 15, 16, 17, 255, 256, 257, 511, 512, 513, 1024]))
+        if li % 97 == 50:  # a few long lists: many tiles, tiles of more than 2048 integers (runs), units of any length
+            n = int(r.integers(20_000, 120_000))
         header = vbyte(n) + vbyte(int(r.integers(0, 1 << int(r.integers(1, 33)))))
         profile = profiles[int(r.integers(0, len(profiles)))]
         payload_at = pos + len(header)

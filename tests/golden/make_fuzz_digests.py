@@ -11,8 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 import fuzz_streams as F  # noqa: E402
 
-VROOM = (14, 240)   # dictionaries per kind, lists per dictionary: 3 x 14 x 240 = 10 080 lists
-INDEX = (6, 120)    # 3 x 6 x 120 = 2 160 posting lists
+VROOM = (24, 400)   # dictionaries per kind, lists per dictionary: 3 x 24 x 400 = 28 800 lists
+INDEX = (10, 200)   # 3 x 10 x 200 = 6 000 posting lists
 
 if __name__ == "__main__":
     out = {"vroom_plan": list(VROOM), "index_plan": list(INDEX), "vroom": {}, "index": {}}

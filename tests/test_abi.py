@@ -76,3 +76,52 @@ def test_unit_struct_layout_matches_the_header():
 
     assert host.UNIT_DTYPE.itemsize == 24
     assert [host.UNIT_DTYPE.fields[n][1] for n in ("in_off", "out_off", "n", "list")] == [0, 8, 16, 20]
+
+
+def test_dictionary_files_no_builder_writes_are_rejected():
+    """Outside the decoders' domain (tests/fuzz_streams.py): an entry of more than 16 integers, reserved codewords that are not
+    builder::init()'s, a table without its 16 leading zeros, a context without its reserved codewords. The reference decodes
+    such a file to whatever its 64-byte copy finds behind the tables or the previous list left in the buffer
+    (single_dictionary.hpp:230-238, rectangular_dictionary.hpp:206-213); here: DINT_ERR_FORMAT, before any device is touched."""
+    import struct
+
+    import numpy as np
+
+    import fuzz_streams as F
+    from dint_amd import device
+
+    lib = device._lib
+    no_gpu = device.device_count() == 0
+
+    def status(kind, file):
+        h = C.c_void_p()
+        buf = (C.c_char * len(file)).from_buffer_copy(file)
+        st = lib.dint_dict_create(kind, buf, len(file), 0, C.byref(h))
+        if st == 0:
+            lib.dint_dict_destroy(h)
+        return st
+
+    ok = -4 if no_gpu else 0  # a well-formed file gets as far as the device
+    r = np.random.default_rng(1)
+    good = {k: F.make_dictionary(r, k, 40, size_profile="any").file for k in (F.RECT, F.SINGLE, F.MULTI)}
+    for k, f in good.items():
+        assert status(k, f) == ok
+    # single packed: header 3 words, then offsets
+    f = bytearray(good[F.SINGLE])
+    bad = bytearray(f); struct.pack_into("<I", bad, 12 + 4 * 20, (16 << 24) | 16); assert status(F.SINGLE, bytes(bad)) == -2  # 17 integers
+    bad = bytearray(f); struct.pack_into("<I", bad, 12 + 4 * 3, (127 << 24) | 4); assert status(F.SINGLE, bytes(bad)) == -2   # a run off offset 0
+    bad = bytearray(f); struct.pack_into("<I", bad, 12 + 4 * 0, 1 << 24); assert status(F.SINGLE, bytes(bad)) == -2           # a marker of 2 integers
+    bad = bytearray(f); struct.pack_into("<I", bad, 12 + 4 * 40 + 4 * 5, 9); assert status(F.SINGLE, bytes(bad)) == -2        # table[5] != 0
+    bad = bytearray(f); struct.pack_into("<I", bad, 12 + 4 * 30, (3 << 24) | 0xFFFFF0); assert status(F.SINGLE, bytes(bad)) == -2  # past the table
+    assert status(F.SINGLE, struct.pack("<3I", 3, 3, 16) + bytes(4 * 3 + 64)) == -2                                        # fewer than 7 codewords
+    # rectangular: 1 word, then rows of 17
+    f = good[F.RECT]
+    bad = bytearray(f); struct.pack_into("<I", bad, 4 + 68 * 9 + 64, 17); assert status(F.RECT, bytes(bad)) == -2
+    bad = bytearray(f); struct.pack_into("<I", bad, 4 + 68 * 9 + 64, 0); assert status(F.RECT, bytes(bad)) == -2
+    bad = bytearray(f); struct.pack_into("<I", bad, 4 + 68 * 4 + 64, 32); assert status(F.RECT, bytes(bad)) == -2           # run 64 resized
+    bad = bytearray(f); struct.pack_into("<I", bad, 4 + 68 * 6 + 8, 1); assert status(F.RECT, bytes(bad)) == -2             # a run row with a non-zero word
+    assert status(F.RECT, struct.pack("<I", 0)) == ok                                                                     # no rows: init()'s alone
+    # multi: a context without its reserved codewords
+    f = bytearray(good[F.MULTI])
+    n_off = struct.unpack_from("<I", f, 8)[0]
+    bad = bytearray(f); struct.pack_into("<I", bad, 16 + 4 * 5, n_off - 3); assert status(F.MULTI, bytes(bad)) == -2

@@ -1,7 +1,7 @@
 """Differential fuzzing on the GPU: the HIP decode path (C ABI) against the generator's substitution — the same cases
 tests/test_fuzz_cpu.py pins against the C oracle and the naive Python decoder — random dictionary files for the three
 formats x random decoder-legal slot streams NO ENCODER EMITS (vroom_env/dint_codecs.hpp:45-100, :536-612;
-include/dint/dint_codecs.hpp:21-46 accept any slot sequence): 10 080 vroom lists cut into random units, 2 160 posting
+include/dint/dint_codecs.hpp:21-46 accept any slot sequence): 28 800 vroom lists cut into random units, 6 000 posting
 lists (full blocks of random slots, short blocks interpolative with and without the stored sum), AND queries over them.
 Integers, docIDs, freqs AND end offsets, bit for bit."""
 import json
