@@ -17,8 +17,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "dint_kernels.hpp"

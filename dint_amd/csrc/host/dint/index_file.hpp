@@ -70,8 +70,18 @@ inline index_file_view view_index_file(void const* data, size_t bytes) {
     std::memcpy(&v.header, data, sizeof v.header);
     if (std::memcmp(v.header.magic, "DINTIDX1", 8) != 0) throw std::runtime_error("not a DINT index file");
     auto const& h = v.header;
-    size_t need = sizeof h + (h.n_lists + 1) * 8 + pad8(h.docs_dict_bytes) + pad8(h.freqs_dict_bytes) + h.index_bytes;
-    if (h.n_lists > bytes / 8 || need > bytes) throw std::runtime_error("index file truncated");
+    // every section against what is LEFT of the file (no sum of header fields that a hostile value could wrap)
+    size_t left = bytes - sizeof h;
+    auto take = [&](uint64_t n) {
+        if (n > left) throw std::runtime_error("index file truncated");
+        left -= size_t(n);
+    };
+    if (h.n_lists >= (uint64_t(1) << 60)) throw std::runtime_error("index file truncated");
+    take((h.n_lists + 1) * 8);
+    if (h.docs_dict_bytes > left || h.freqs_dict_bytes > left) throw std::runtime_error("index file truncated");
+    take(pad8(size_t(h.docs_dict_bytes)));
+    take(pad8(size_t(h.freqs_dict_bytes)));
+    take(h.index_bytes);
     auto p = static_cast<uint8_t const*>(data) + sizeof h;
     v.offsets = reinterpret_cast<uint64_t const*>(p);
     p += (h.n_lists + 1) * 8;
@@ -81,6 +91,8 @@ inline index_file_view view_index_file(void const* data, size_t bytes) {
     p += pad8(h.freqs_dict_bytes);
     v.index = p;
     if (v.offsets[h.n_lists] != h.index_bytes) throw std::runtime_error("index file: offsets do not end at the index's size");
+    for (uint64_t i = 0; i != h.n_lists; ++i)
+        if (v.offsets[i] > v.offsets[i + 1]) throw std::runtime_error("index file: list offsets decrease");
     return v;
 }
 

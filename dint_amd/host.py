@@ -361,19 +361,26 @@ INDEX_FILE_HEADER = np.dtype([("magic", "S8"), ("kind", "<u4"), ("coder", "<u4")
 def read_index_file(path: str) -> dict:
     """The container `dint_create_freq_index` writes (dint/index_file.hpp)."""
     raw = np.fromfile(path, dtype=np.uint8)
+    if raw.size < INDEX_FILE_HEADER.itemsize:
+        raise ValueError("index file truncated")
     h = raw[:INDEX_FILE_HEADER.itemsize].view(INDEX_FILE_HEADER)[0]
     if h["magic"] != b"DINTIDX1":
         raise ValueError("not a DINT index file")
     pad8 = lambda n: (int(n) + 7) & ~7
     p = INDEX_FILE_HEADER.itemsize
     n = int(h["n_lists"])
+    sizes = [8 * (n + 1), pad8(h["docs_dict_bytes"]), pad8(h["freqs_dict_bytes"]), int(h["index_bytes"])]
+    if sum(sizes) > raw.size - p:  # (Python integers: no wrap)
+        raise ValueError("index file truncated")
     offsets = raw[p:p + 8 * (n + 1)].view("<u8").copy()
-    p += 8 * (n + 1)
+    p += sizes[0]
     docs_dict = raw[p:p + int(h["docs_dict_bytes"])].tobytes()
-    p += pad8(h["docs_dict_bytes"])
+    p += sizes[1]
     freqs_dict = raw[p:p + int(h["freqs_dict_bytes"])].tobytes()
-    p += pad8(h["freqs_dict_bytes"])
+    p += sizes[2]
     index = raw[p:p + int(h["index_bytes"])].copy()
+    if int(offsets[-1]) != int(h["index_bytes"]) or (np.diff(offsets.astype(np.int64)) < 0).any():
+        raise ValueError("index file: list offsets decrease or do not end at the index's size")
     return {"kind": int(h["kind"]), "coder": int(h["coder"]), "num_docs": int(h["num_docs"]), "offsets": offsets,
             "docs_dict": docs_dict, "freqs_dict": freqs_dict, "index": index}
 

@@ -79,7 +79,22 @@ int main(int argc, char** argv) {
         const uint64_t n_lists = offsets.size() / 8 - 1;
         const double elapsed_secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - tick).count();
         std::cerr << type << " collection built in " << elapsed_secs << " seconds" << std::endl;
-        const uint64_t postings = (docs.n_words() - 2 - n_lists);  // the .docs words minus record 0 minus one length word a list
+        // the postings actually indexed: the lengths the lists' own headers carry (a .docs file may hold empty records, which
+        // the reader skips — their length words are no postings — or a truncated tail: binary_collection.hpp:131-146)
+        uint64_t postings = 0;
+        {
+            auto const* offs = static_cast<uint64_t const*>(offsets.data());
+            auto const* bytes = static_cast<uint8_t const*>(index.data());
+            for (uint64_t i = 0; i != n_lists; ++i) {
+                uint64_t n = 0;
+                unsigned shift = 0;
+                for (uint8_t const* p = bytes + offs[i];; ++p, shift += 7) {  // TightVariableByte: the LAST byte has bit 7 set
+                    n += uint64_t(*p & 127u) << shift;
+                    if (*p & 128u) break;
+                }
+                postings += n;
+            }
+        }
         std::cout << "{\"type\": \"" << type << "\", \"worker_threads\": " << threads << ", \"construction_time\": " << elapsed_secs
                   << ", \"sequences\": " << n_lists << ", \"postings\": " << postings << ", \"num_docs\": " << num_docs
                   << ", \"lists_bytes\": " << index.size() << ", \"docs_dict_bytes\": " << docs_dict.size()

@@ -70,6 +70,11 @@ int main(int argc, char** argv) {
             for (uint32_t t : q)
                 if (t >= n_lists) throw std::runtime_error("query term " + std::to_string(t) + " is not a list of this index");
 
+        std::string device_name = "unknown";
+        {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, 0) == hipSuccess) device_name = prop.gcnArchName;  // e.g. gfx950:sramecc+:xnack-
+        }
         dint_dict *docs_dict = nullptr, *freqs_dict = nullptr;
         dint_ok(dint_dict_create(kind, v.docs_dict, size_t(v.header.docs_dict_bytes), 0, &docs_dict), "dint_dict_create(docs)");
         dint_ok(dint_dict_create(kind, v.freqs_dict, size_t(v.header.freqs_dict_bytes), 0, &freqs_dict), "dint_dict_create(freqs)");
@@ -100,7 +105,7 @@ int main(int argc, char** argv) {
             }
             const bool with_freqs = t == "and_freq";
             std::vector<double> query_times;
-            uint64_t total = 0;
+            uint64_t total = 0, total_one_run = 0;
             for (size_t run = 0; run != runs; ++run) {  // op_perftest
                 for (auto const& q : queries) {
                     const uint64_t offs[2] = {0, q.size()};
@@ -109,6 +114,7 @@ int main(int argc, char** argv) {
                     if (with_freqs) dint_ok(dint_and_queries_freqs(qi, freqs_dict, q.data(), offs, 1, &results, &fsum, &fblocks, nullptr), "dint_and_queries_freqs");
                     else dint_ok(dint_and_queries(qi, q.data(), offs, 1, &results, nullptr), "dint_and_queries");
                     total += results;
+                    if (run == 0) total_one_run += results;
                     if (run != 0) query_times.push_back(now_us() - tick);  // first run is not timed
                 }
             }
@@ -130,6 +136,12 @@ int main(int argc, char** argv) {
                     if (run != 0) best = std::min(best, now_us() - tick);
                 }
                 batch_us = best / double(queries.size());
+                // the batch call and the one-query calls answer the same log
+                uint64_t batch_total = 0;
+                for (uint64_t c : counts) batch_total += c;
+                if (batch_total != total_one_run)
+                    throw std::runtime_error("the batch call counted " + std::to_string(batch_total) + " results, the one-query calls " +
+                                             std::to_string(total_one_run));
             }
             if (query_times.empty()) continue;
             std::sort(query_times.begin(), query_times.end());
@@ -139,7 +151,7 @@ int main(int argc, char** argv) {
             std::cout << "{\"type\": \"" << type << "\", \"query\": \"" << t << "\", \"avg\": " << avg << ", \"q50\": " << q50
                       << ", \"q90\": " << q90 << ", \"q95\": " << q95;
             if (batch_us >= 0) std::cout << ", \"batch_us_per_query\": " << batch_us;
-            std::cout << ", \"device\": \"gfx950\"}" << std::endl;
+            std::cout << ", \"device\": \"" << device_name << "\"}" << std::endl;
         }
         dint_query_index_destroy(qi);
         dint_free(blocks);

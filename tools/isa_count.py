@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 kernel = {"multi": "decode_multi_kernel", "single": "decode_single_kernel"}.get((sys.argv[1:2] or ["single"])[0], (sys.argv[1:2] or ["single"])[0])
 dump = sys.argv[sys.argv.index("--dump") + 1] if "--dump" in sys.argv else None
 os.makedirs("/tmp/isa", exist_ok=True)
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", "-DDINT_MARKS",
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", "-DDINT_MARKS", *os.environ.get("ISA_FLAGS", "").split(),
                 f"-I{ROOT}/include", f"-I{ROOT}/dint_amd/csrc/hip", "-save-temps", "-c",
                 f"{ROOT}/dint_amd/csrc/hip/dint_hip.hip", "-o", "/tmp/isa/x.o"], check=True, cwd="/tmp/isa")
 text = open("/tmp/isa/dint_hip-hip-amdgcn-amd-amdhsa-gfx950.s").read()
