@@ -43,6 +43,18 @@ WORKLOADS = {
     # device-side copies at distinct addresses — the same integers and bytes per step and GPU.
     "gov2": dict(universe=25_000_000, postings=5.0e9, replicate=1, multi_rank=dict(postings=1.0e9, replicate=5)),
     "clueweb": dict(universe=50_000_000, postings=1.25e9, replicate=1),
+    # Workload-sensitivity rows (round 6, DESIGN.md section 4e: where the headline's roofline fraction holds and where not) —
+    # secondary lines, 2e9 (freqs: 1e9) postings per GPU:
+    # the docs generator turned up to the space the reference publishes for Gov2 docIDs (README.md:112-113: 5.94 bits per integer;
+    # the default setting lands at 4.5): shorter clusters, flatter gap distributions
+    "gov2-bpi59": dict(universe=25_000_000, postings=2.0e9, replicate=1,
+                       synth=dict(stay_cluster=0.78, p_cluster_min=0.38, p_cluster_max=0.88)),
+    # an exception-heavy stream: lists of at most 500 k postings in a universe of 2e9 documents — most gaps are in no dictionary
+    "gov2-exceptions": dict(universe=2_000_000_000, postings=2.0e9, replicate=1, synth=dict(max_len=500_000)),
+    # a .freqs-shaped stream (vroom_env/encode.cpp:160-164, jobs.hpp:74-84: the values are freq - 1, no prefix sum, the lists of
+    # the docs file): per list a geometric law whose parameter is drawn in [0.17, 0.67) — mostly zeros in long runs for the
+    # lists drawn high, the README's 3.05 bits per integer over all (README.md:114)
+    "gov2-freqs": dict(universe=25_000_000, postings=1.0e9, replicate=1, values="freqs", freq_p=(0.17, 0.5)),
 }
 KERNEL_BY_TYPE = {"single_rect_dint": "decode_single_kernel", "single_packed_dint": "decode_single_kernel",
                   "multi_packed_dint": "decode_multi_kernel"}
@@ -68,6 +80,17 @@ def parse_args(argv=None):
                          "first allocation, no selection — the fast level in nine fresh processes in a row on some boxes "
                          "(profiles/r04_first_allocation.txt), the slow one on another (profiles/r04_bench_first_allocation_slow_box.json); "
                          "the line reports the first allocation's time either way (value_first_allocation, roofline.frac_first_allocation)")
+    ap.add_argument("--place-by-probe", action="store_true",
+                    help="placement by the library's SAMPLED probe (dint_probe_placement) instead of full-size candidates: three copies of "
+                         "the stream (an eighth of the output each) allocated at three points of the set-up — with the uploaded pieces, "
+                         "in front of the output, behind it — are each decoded against the ONE output buffer over an evenly spread "
+                         "sample of the unit table (--probe-ints integers, four launches), the fastest copy stays, the others are freed: "
+                         "tens of milliseconds and a quarter of the working set in trial memory, against --placement-trials 6's twelve "
+                         "full-size buffers. Use with --placement-trials 1")
+    ap.add_argument("--probe-ints", type=float, default=4.0e8, help="integers the placement probe's sample decodes per launch")
+    ap.add_argument("--probe-eval", action="store_true",
+                    help="with --placement-trials N > 1: run the sampled probe over the same candidates as well and report both "
+                         "rankings (config.placement_probe_eval): does the sample see what the full-size launches see?")
     ap.add_argument("--apart-gb", type=float, default=24.0,
                     help="the stream and the output are not allocated next to each other: this much device memory is allocated between "
                          "them and freed again (two big buffers allocated one after the other usually land in the same kind of physical "
@@ -349,7 +372,7 @@ def main():
 
     # ---- set-up (untimed): collection shard, dictionary, encode, upload ----------
     t0 = time.time()
-    p = host.synth_params(universe=universe, seed=args.seed)
+    p = host.synth_params(universe=universe, seed=args.seed, **w.get("synth", {}))
     # The collection is `world * postings` postings; list lengths are drawn once
     # (same on every rank) and contiguous list ranges balanced by postings are
     # handed to the ranks.
@@ -369,6 +392,12 @@ def main():
 
     def piece(i):
         a, b = cuts[i], cuts[i + 1]
+        if w.get("values") == "freqs":
+            # freq - 1 of every posting of the lists [a, b): a function of the seed and the piece's first list alone
+            r = np.random.default_rng([args.seed, lo + a])
+            p_lo, p_span = w["freq_p"]
+            p_list = np.repeat(p_lo + p_span * r.random(b - a), lens[a:b])
+            return host.Collection((r.geometric(p_list) - 1).astype(np.uint32), lens[a:b])
         return host.Collection(host.synth_gaps(p, lens[a:b], first_list_id=lo + a, threads=threads), lens[a:b])
 
     coll0 = piece(0)
@@ -463,7 +492,8 @@ def main():
     # the stream, then a few candidate copies of the stream for the output buffer that won, two launches each; the
     # fastest pair stays, the others are freed before the timed region.
     trials = max(1, args.placement_trials) if dev.type == "cuda" and not os.environ.get("DINT_BENCH_STUB") else 1
-    enc_dev = allocate_stream() if (R > 1 or trials > 1) else enc_one  # (one copy, no candidates: the uploaded stream itself)
+    by_probe = bool(args.place_by_probe) and dev.type == "cuda" and not os.environ.get("DINT_BENCH_STUB") and hasattr(device, "probe_placement")
+    enc_dev = allocate_stream() if (R > 1 or trials > 1 or by_probe) else enc_one  # (one copy, no candidates: the uploaded stream itself)
     # the output is allocated APART from the stream: a spacer between the two allocations, freed right away
     spacer = None
     if dev.type == "cuda" and args.apart_gb > 0:
@@ -477,6 +507,38 @@ def main():
     out_dev = allocate_output()
     del spacer
     placement_ms = None
+    probe_report = None
+    if by_probe:
+        # three copies of the stream, allocated at three points of the set-up: with the uploaded pieces (enc_one: R == 1 only),
+        # in front of the output (enc_dev), behind the output
+        cands = ([enc_one] if R == 1 else []) + [enc_dev]
+        try:
+            cands.append(allocate_stream())
+        except RuntimeError:
+            pass
+        torch.cuda.synchronize(dev)
+        t_probe = time.perf_counter()
+        pm = device.probe_placement(d, cands, units_dev, n_units, [out_dev], int(args.probe_ints))[:, 0]
+        probe_s = time.perf_counter() - t_probe
+        # (what the full-size launch reaches on the set-up's first pair — the stream copy in front of the output — and on every
+        # candidate: two launches each, for the report only)
+        full = []
+        for e in cands:
+            ms2 = []
+            for _ in range(2):
+                d.decode_units(e, units_dev, n_units, out_dev)
+                torch.cuda.synchronize(dev)
+                ms2.append(d.last_kernel_ms())
+            full.append(round(min(ms2), 4))
+        keep = int(np.argmin(pm))
+        probe_report = {"stream_copies": len(cands), "sample_ints": int(args.probe_ints), "sampled_kernel_ms": [round(float(x), 4) for x in pm],
+                        "full_size_kernel_ms_of_the_same_copies": full, "kept": keep, "probe_seconds": round(probe_s, 3),
+                        "first_pair": (1 if R == 1 else 0),
+                        "trial_memory_over_working_set": round((len(cands) - 1) * enc_bytes_one * R / (enc_bytes_one * R + 4 * n_ints), 3)}
+        log(rank, f"placement probe: {probe_report}")
+        enc_dev = cands[keep]
+        del cands
+        torch.cuda.empty_cache()
 
     def rank_candidates(e, outs):
         # the library's own call for this (include/dint_hip.h: dint_unit_table_rank_outputs): every candidate decoded three
@@ -505,14 +567,21 @@ def main():
                 break
         return out
 
+    probe_eval = None
     if trials > 1:
         outs = candidates(out_dev, allocate_output)
         ms_out = rank_candidates(enc_dev, outs)
+        if args.probe_eval and hasattr(device, "probe_placement"):
+            probe_eval = {"sample_ints": int(args.probe_ints),
+                          "output_buffers_sampled_ms": [round(float(x), 4) for x in device.probe_placement(d, [enc_dev], units_dev, n_units, outs, int(args.probe_ints))[0]]}
         out_dev = outs[int(np.argmin(ms_out))]
         del outs
         torch.cuda.empty_cache()
         encs = candidates(enc_dev, allocate_stream)
         ms_enc = [min(ms_out)] + [rank_candidates(e, [out_dev])[0] for e in encs[1:]]
+        if probe_eval is not None:
+            probe_eval["stream_buffers_sampled_ms"] = [round(float(x), 4) for x in device.probe_placement(d, encs, units_dev, n_units, [out_dev], int(args.probe_ints))[:, 0]]
+            probe_eval["output_buffers_full_ms"], probe_eval["stream_buffers_full_ms"] = ms_out, ms_enc
         enc_dev = encs[int(np.argmin(ms_enc))]
         del encs
         torch.cuda.empty_cache()
@@ -571,6 +640,8 @@ def main():
     ends = end_dev.cpu().numpy().view(np.uint64)
     payload_bytes = int((ends - units_all["in_off"]).sum())
     first_alloc_ms = placement_ms["output_buffers"][0] if placement_ms else None
+    if probe_report is not None:
+        first_alloc_ms = probe_report["full_size_kernel_ms_of_the_same_copies"][probe_report["first_pair"]]
     bit_exact = None
     if not args.no_verify:
         bit_exact = True
@@ -697,7 +768,9 @@ def main():
                 # (nominal figures: the same text for every rank count but for the count itself; rank 0's exact shard is
                 # distinct_postings_per_gpu)
                 "workload": f"{args.type} decode, DSF-65536-16 dictionary (hot set in LDS), {args.workload}-shaped synthetic "
-                            f"docIDs: universe {universe}, {postings} distinct postings encoded per GPU"
+                            + ("term frequencies minus one (a .freqs stream: no prefix sum)" if w.get("values") == "freqs" else "docIDs")
+                            + f": universe {universe}, {postings} distinct postings encoded per GPU"
+                            + (f", generator settings {w['synth']}" if w.get("synth") else "")
                             + (f", decoded x{R} per step from {R} device-side copies at distinct addresses" if R > 1 else "")
                             + f", {shard_world} GPU(s): contiguous list ranges of one collection of {postings * shard_world} postings",
                 "distinct_postings_per_gpu": n_shard,
@@ -709,9 +782,14 @@ def main():
                 "schedule": "prepared unit table (set-up)" if unit_table is not None else "per launch (timed)",
                 "placement": (f"fastest of {len(placement_ms['output_buffers'])} candidate output buffers, then of "
                               f"{len(placement_ms['stream_buffers'])} candidate stream buffers, chosen during set-up"
-                              if placement_ms else "first allocation"
+                              if placement_ms else
+                              (f"sampled probe (dint_probe_placement): the fastest of {probe_report['stream_copies']} copies of the stream "
+                               f"against the one output buffer, chosen during set-up in {probe_report['probe_seconds']} s") if probe_report
+                              else "first allocation"
                               + (f" (output allocated {args.apart_gb:g} GB apart from the stream)" if args.apart_gb > 0 else "")),
                 "placement_trial_kernel_ms": placement_ms,
+                "placement_probe": probe_report,
+                "placement_probe_eval": probe_eval,
                 "bits_per_int": round(bpi, 3),
                 **stream,
                 "hot_codewords_in_lds": int(info.hot_entries),

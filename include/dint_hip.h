@@ -9,9 +9,20 @@
  * reference-side binding.
  *
  * Threading: a dint_dict is immutable after creation and may be used from
- * several host threads with distinct streams. One dint_dict lives on one
- * device; multi-GPU = one dint_dict per device (the dictionary is replicated,
- * posting lists are partitioned, there is no data-path collective).
+ * several host threads with distinct streams (its launch bookkeeping — queue
+ * slots, timing events — sits behind the handle's own `launch_mutex`). One
+ * dint_dict lives on one device; multi-GPU = one dint_dict per device (the
+ * dictionary is replicated, posting lists are partitioned, there is no
+ * data-path collective). A dint_query_index may be called from several host
+ * threads, each with its own stream: its calls SERIALISE on the handle's own
+ * lock (`dint_query_index::mutex`, taken inside dint_and_queries /
+ * dint_and_queries_freqs for the whole call — the handle's workspaces are one
+ * set); two query indexes, or two dint_block_tables over one index and one
+ * pair of dictionaries, share nothing mutable and run side by side. A
+ * dint_block_table (and a dint_unit_table) belongs to one caller at a time:
+ * its decodes are ordered on the stream they are enqueued on
+ * (tests/test_gpu_queries.py::test_one_query_index_under_two_host_threads,
+ * tests/test_gpu_index.py::test_two_block_tables_over_one_index_on_two_threads).
  *
  * All functions return DINT_OK (0) or a negative dint_status; none throws.
  */
@@ -25,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DINT_ABI_VERSION 5
+#define DINT_ABI_VERSION 6
 
 /* A unit decodes to at most this many integers (the kernels address a unit's output with 32-bit byte
  * offsets); dint_index_stream never cuts larger ones, dint_decode_units skips them. */
@@ -170,6 +181,19 @@ int dint_decode_unit_table(const dint_dict* dict, dint_unit_table* table, uint32
  * Replaces: nothing in the reference. */
 int dint_unit_table_rank_outputs(const dint_dict* dict, dint_unit_table* table, uint32_t* const* d_outs, size_t n_outs,
                                  size_t out_capacity, void* stream, float* kernel_ms, size_t* fastest);
+/* The same question for the price of a SAMPLE (round 6): which (stream copy, output buffer) pair do the decode kernels run
+ * fastest on? Every candidate pair — n_encs copies of ONE encoded stream at different addresses, n_outs output buffers —
+ * decodes the same evenly spread sample of the unit table (runs of 4 units, about `sample_ints` integers in all, 0: the
+ * smallest launch that fills the device; the units keep their own places in stream and output, so the sample touches all of
+ * both buffers) four times; kernel_ms[i * n_outs + j] = the fastest of the last three launches' kernel times on copy i and
+ * output j. The slow / fast level of a pair is a property of where the driver put the two buffers and
+ * shows in a sample as it does in the full decode (profiles/r06_placement_probe.txt); the stream is the small buffer of the
+ * two (an eighth of the output), so a caller tries a few COPIES of it — allocated at different points of its set-up — against
+ * the one output buffer it has: INTEGRATION.md section 6. Synchronises `stream`; the outputs hold the sample's integers.
+ * Replaces: nothing in the reference. */
+int dint_probe_placement(const dint_dict* dict, const uint8_t* const* d_encs, size_t n_encs, size_t enc_bytes,
+                         const dint_unit* d_units, size_t n_units, uint32_t* const* d_outs, size_t n_outs, size_t out_capacity,
+                         uint64_t sample_ints, void* stream, float* kernel_ms);
 
 /* Host-pointer convenience with the reference's call shape: decode ONE
  * sequence of n integers starting at in[0]; *consumed = bytes read. Uploads,

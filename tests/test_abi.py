@@ -28,7 +28,7 @@ def test_python_binding_lists_the_same_symbols():
     from dint_amd import device
 
     assert sorted(device.ABI_SYMBOLS) == declared_functions("dint_hip.h")
-    assert device.abi_version() == 5
+    assert device.abi_version() == 6
 
 
 def test_options_are_an_api_not_the_environment():

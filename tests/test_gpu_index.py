@@ -375,3 +375,52 @@ def test_blocks_the_expansion_leaves_as_gaps_become_docids_on_the_spot(device, k
     for i in range(len(lists)):
         dl, fl = oracle.posting_list_decode(od, of, idx, int(offs[i]))
         assert np.array_equal(dl, lists[i])
+
+
+def test_two_block_tables_over_one_index_on_two_threads(device, small_corpus):
+    """Two prepared block tables over ONE resident index and ONE pair of dictionaries, decoded from two host threads on a
+    stream each for a few seconds (one taught, one learning under its first decodes): a table's decodes are ordered on its own
+    stream, nothing but the immutable dictionaries and the index is shared (include/dint_hip.h, threading)."""
+    import threading
+    import time
+
+    import torch
+
+    kind = host.SINGLE_PACKED
+    ix = get_index(small_corpus, kind)
+    blocks, total = device.index_posting_lists(ix.bytes, ix.offsets)
+    dd, fd = device.Dictionary(kind, ix.docs_dict), device.Dictionary(kind, ix.freqs_dict)
+    dev = torch.device("cuda", 0)
+    padded = np.concatenate([ix.bytes, np.zeros(16, np.uint8)])
+    index_dev = torch.from_numpy(padded).to(dev)
+    tables = [device.BlockTable(dd, blocks, padded.size), device.BlockTable(dd, blocks, padded.size)]
+    tables[0].learn(dd, fd, index_dev, padded.size)
+    torch.cuda.synchronize()
+    want_d = torch.from_numpy(ix.docids.view(np.int32)).to(dev)
+    want_f = torch.from_numpy(ix.freqs.view(np.int32)).to(dev)
+    errors, rounds = [], [0, 0]
+    stop_at = time.monotonic() + 3.0
+
+    def worker(k):
+        try:
+            stream = torch.cuda.Stream(dev)
+            with torch.cuda.stream(stream):
+                while time.monotonic() < stop_at:
+                    docids_dev = torch.full((total,), -1, dtype=torch.int32, device=dev)
+                    with_freqs = rounds[k] % 3 != 2
+                    freqs_dev = torch.full((total,), -1, dtype=torch.int32, device=dev) if with_freqs else None
+                    tables[k].decode(dd, fd if with_freqs else None, index_dev, padded.size, docids_dev, freqs_dev, stream=stream.cuda_stream)
+                    stream.synchronize()
+                    assert torch.equal(docids_dev, want_d), ("docids", k, rounds[k])
+                    assert not with_freqs or torch.equal(freqs_dev, want_f), ("freqs", k, rounds[k])
+                    rounds[k] += 1
+        except BaseException as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert min(rounds) >= 10, rounds

@@ -310,3 +310,71 @@ def test_reference_query_log_on_the_readme_shaped_collection(device, kind):
     for i in range(0, len(qs), 11):
         assert int(qi.and_queries([qs[i]])[0]) == oi.and_query(qs[i]) == int(want[i])
     qi.close()
+
+
+def test_one_query_index_under_two_host_threads(device, small_corpus):
+    """SURVEY §8b "Threading": one dint_query_index, two host threads, a stream each, calls of every form interleaved for a
+    few seconds — single light queries (one launch), single heavy ones (a round per launch), batches of small queries (a
+    workgroup per query), mixed batches (split calls), and_query<true> calls — every result against plain set intersection.
+    The calls of one handle serialise on the handle's own lock (include/dint_hip.h); nothing else is shared."""
+    import threading
+    import time
+
+    import torch
+
+    kind = host.SINGLE_PACKED
+    ix = get_index(small_corpus, kind)
+    dd, fd = device.Dictionary(kind, ix.docs_dict), device.Dictionary(kind, ix.freqs_dict)
+    qi = device.QueryIndex(dd, ix.bytes, ix.offsets)
+    light = reference_queries(len(ix.lens))[:200]
+    heavy = heavy_queries(ix.lens, 40, seed=11)
+    want_light = np.array([intersect(ix.docids, ix.bounds, q) for q in light], dtype=np.uint64)
+    want_heavy = np.array([intersect(ix.docids, ix.bounds, q) for q in heavy], dtype=np.uint64)
+    want_fsum = [intersect_freqs(ix.docids, ix.freqs, ix.bounds, q) for q in heavy[:12]]
+    errors, calls = [], [0, 0]
+    stop_at = time.monotonic() + 4.0
+
+    def worker(k):
+        try:
+            stream = torch.cuda.Stream(torch.device("cuda", 0))
+            r = np.random.default_rng(100 + k)
+            terms_l, offs_l = device._pack_queries(light)
+            terms_m, offs_m = device._pack_queries(light[:60] + heavy)
+            while time.monotonic() < stop_at:
+                form = int(r.integers(0, 5))
+                if form == 0:    # one light query
+                    i = int(r.integers(0, len(light)))
+                    t, o = device._pack_queries([light[i]])
+                    c = np.zeros(1, dtype=np.uint64)
+                    qi.and_queries_packed(t, o, c, stream.cuda_stream)
+                    assert int(c[0]) == int(want_light[i]), ("light", i)
+                elif form == 1:  # one heavy query
+                    i = int(r.integers(0, len(heavy)))
+                    t, o = device._pack_queries([heavy[i]])
+                    c = np.zeros(1, dtype=np.uint64)
+                    qi.and_queries_packed(t, o, c, stream.cuda_stream)
+                    assert int(c[0]) == int(want_heavy[i]), ("heavy", i)
+                elif form == 2:  # the light log as one batch
+                    c = np.zeros(len(light), dtype=np.uint64)
+                    qi.and_queries_packed(terms_l, offs_l, c, stream.cuda_stream)
+                    assert np.array_equal(c, want_light), "batch"
+                elif form == 3:  # a mixed batch
+                    c = np.zeros(60 + len(heavy), dtype=np.uint64)
+                    qi.and_queries_packed(terms_m, offs_m, c, stream.cuda_stream)
+                    assert np.array_equal(c, np.r_[want_light[:60], want_heavy]), "mixed"
+                else:            # and_query<true>
+                    with torch.cuda.stream(stream):
+                        counts, sums, _ = qi.and_queries_with_freqs(fd, heavy[:12])
+                    assert [(int(a), int(b)) for a, b in zip(counts, sums)] == want_fsum, "freqs"
+                calls[k] += 1
+        except BaseException as e:  # noqa: BLE001 (reported by the main thread)
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert min(calls) >= 20, calls
+    qi.close()
