@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Build check for the kernels that issue loads in inline asm (decode_segment_lean): between an asm-issued buffer load
+"""Build check for the kernels that issue loads in inline asm (round 4: decode_segment_lean; round 6: the chunked bundle loop's
+bundle_raw_async — decode_multi_bundles_kernel, the in-index bundle kernels): between an asm-issued buffer load
 and the next asm s_waitcnt, no compiler-generated instruction may read or write the load's destination registers (a
 register copy or a spill there would take the value before it has arrived). Scans the assembly text linearly (the
 blocks of the tile loop are laid out in program order); prints every suspect line. Exit code 1 if any.
@@ -42,7 +43,7 @@ for ln, line in enumerate(body.split("\n"), 1):
         continue
     code = s.split(";")[0]
     if in_asm:
-        if code.startswith("buffer_load"):
+        if code.startswith(("buffer_load", "global_load")):
             dst = code.split()[1].rstrip(",")
             for r in regs(dst):
                 inflight[r] = ln
