@@ -86,6 +86,19 @@ for typ in types:
             b = min(total, a + (1 << 28))
             ok = ok and bool(torch.equal(docs_dev[a:b], exp_d[a:b])) and bool(torch.equal(freqs_dev[a:b], exp_f[a:b]))
         row["bit_exact"] = ok
+        if not ok:  # where: the first differing posting of each output, how many differ, the block it lies in
+            for name, got, want in (("docids", docs_dev, exp_d), ("freqs", freqs_dev, exp_f)):
+                bad = 0; first = None
+                for a in range(0, total, 1 << 28):
+                    b = min(total, a + (1 << 28))
+                    ne = torch.nonzero(got[a:b] != want[a:b])
+                    bad += int(ne.numel())
+                    if first is None and ne.numel():
+                        first = a + int(ne[0])
+                blk = int(np.searchsorted(blocks["out_off"], first, side="right") - 1) if first is not None else None
+                row[f"mismatch_{name}"] = {"count": bad, "first": first, "block": blk,
+                                           "block_in_off": int(blocks["in_off"][blk]) if blk is not None else None,
+                                           "block_n": int(blocks["n"][blk]) if blk is not None else None}
         res["rows"].append(row)
         print(json.dumps(row), flush=True)
         del table, index_dev, docs_dev, freqs_dev, exp_d, exp_f, D, F
