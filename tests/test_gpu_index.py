@@ -424,3 +424,45 @@ def test_two_block_tables_over_one_index_on_two_threads(device, small_corpus):
         t.join()
     assert not errors, errors
     assert min(rounds) >= 10, rounds
+
+
+@pytest.mark.parametrize("kind", [host.SINGLE_PACKED, host.MULTI_PACKED])
+def test_an_index_that_straddles_4_gib(device, small_corpus, kind):
+    """Byte offsets are 64-bit everywhere (dint_block_ref::in_off, the end offsets, the freqs parts' starts): the same small
+    index placed so that its bytes straddle offset 2^32 of a 4.3 GB device buffer — blocks below the line, across it (a docs
+    part below, its freqs part above; a part cut by the line) and above it — decodes to the same docIDs and freqs. Found by
+    tools/inindex_scale.py at 5e9 postings (round 6: an index of 4.32 GB, 48 wrong freqs in the one block on the line)."""
+    import torch
+
+    ix = get_index(small_corpus, kind)
+    blocks, total = device.index_posting_lists(ix.bytes, ix.offsets)
+    dd, fd = device.Dictionary(kind, ix.docs_dict), device.Dictionary(kind, ix.freqs_dict)
+    dev = torch.device("cuda", 0)
+    for cut in (len(ix.bytes) // 2, len(ix.bytes) // 3 + 1, 777):  # bytes of the index below the line
+        shift = (1 << 32) - cut
+        big = torch.zeros(shift + len(ix.bytes) + 16, dtype=torch.uint8, device=dev)
+        big[shift:shift + len(ix.bytes)] = torch.from_numpy(ix.bytes).to(dev)
+        moved = blocks.copy()
+        moved["in_off"] += np.uint64(shift)
+        table = device.BlockTable(dd, moved, big.numel())
+        for taught in (False, True):
+            if taught:
+                table.learn(dd, fd, big, big.numel())
+            for _ in range(3):
+                docids_dev = torch.full((total,), -1, dtype=torch.int32, device=dev)
+                freqs_dev = torch.full((total,), -1, dtype=torch.int32, device=dev)
+                table.decode(dd, fd, big, big.numel(), docids_dev, freqs_dev)
+                torch.cuda.synchronize()
+                assert np.array_equal(docids_dev.cpu().numpy().view(np.uint32), ix.docids), (cut, taught)
+                got_f = freqs_dev.cpu().numpy().view(np.uint32)
+                bad = np.flatnonzero(got_f != ix.freqs)
+                if bad.size:
+                    b = int(np.searchsorted(blocks["out_off"], bad[0], side="right") - 1)
+                    detail = dict(cut=cut, taught=taught, n_bad=int(bad.size), block=b, n=int(blocks["n"][b]), base=hex(big.data_ptr()),
+                                  block_in_off=int(blocks["in_off"][b]), next_in_off=int(blocks["in_off"][b + 1]),
+                                  pos_in_block=(bad[:24] - int(blocks["out_off"][b])).tolist(), got=got_f[bad[:6]].tolist(),
+                                  want=ix.freqs[bad[:6]].tolist(), index_bytes=len(ix.bytes), info=table.info())
+                    print("DETAIL", detail, flush=True)
+                    assert False, detail
+        del table, big
+        torch.cuda.empty_cache()

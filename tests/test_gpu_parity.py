@@ -545,3 +545,39 @@ def test_every_ticket_size_decodes_the_same(device, small_corpus, kind, split):
             assert np.array_equal(docids_dev.cpu().numpy().view(np.uint32), ix.docids), i
             assert np.array_equal(freqs_dev.cpu().numpy().view(np.uint32), ix.freqs), i
         bt.close()
+
+
+@pytest.mark.parametrize("kind", ALL_KINDS)
+def test_a_stream_that_straddles_4_gib(device, small_corpus, kind):
+    """dint_unit::in_off is 64-bit: the same stream placed across offset 2^32 of a 4.3 GB device buffer decodes to the same
+    integers and end offsets (units of 256: the bundle paths; units of 4096: the segment path)."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    d = device.Dictionary(kind, small_corpus.dict_file(kind))
+    enc, _ = small_corpus.encoded(kind)
+    for unit_ints in (256, 4096):
+        units, total, _ = d.index_stream(enc, unit_ints)
+        want, want_ends, _ = device.decode_stream(d, enc, units, total)
+        assert np.array_equal(want, small_corpus.coll.gaps)
+        for cut in (enc.size // 2, 4099):
+            shift = (1 << 32) - cut
+            big = torch.zeros(shift + enc.size + 16, dtype=torch.uint8, device=dev)
+            big[shift:shift + enc.size] = torch.from_numpy(enc).to(dev)
+            moved = units.copy()
+            moved["in_off"] += np.uint64(shift)
+            out_dev = torch.full((total,), -1, dtype=torch.int32, device=dev)
+            end_dev = torch.zeros(len(units), dtype=torch.int64, device=dev)
+            units_dev = device.units_to_device(moved, dev)
+            d.decode_units(big, units_dev, len(moved), out_dev, end_dev)
+            torch.cuda.synchronize()
+            assert np.array_equal(out_dev.cpu().numpy().view(np.uint32), want), (unit_ints, cut)
+            assert np.array_equal(end_dev.cpu().numpy().view(np.uint64), want_ends + np.uint64(shift)), (unit_ints, cut)
+            table = device.UnitTable(d, big, units_dev, len(moved), total)
+            out_dev.fill_(-1)
+            table.decode(out_dev, end_dev)
+            torch.cuda.synchronize()
+            assert np.array_equal(out_dev.cpu().numpy().view(np.uint32), want), (unit_ints, cut, "table")
+            table.close()
+            del big
+            torch.cuda.empty_cache()
