@@ -462,7 +462,6 @@ def test_an_index_that_straddles_4_gib(device, small_corpus, kind):
                                   block_in_off=int(blocks["in_off"][b]), next_in_off=int(blocks["in_off"][b + 1]),
                                   pos_in_block=(bad[:24] - int(blocks["out_off"][b])).tolist(), got=got_f[bad[:6]].tolist(),
                                   want=ix.freqs[bad[:6]].tolist(), index_bytes=len(ix.bytes), info=table.info())
-                    print("DETAIL", detail, flush=True)
                     assert False, detail
         del table, big
         torch.cuda.empty_cache()
