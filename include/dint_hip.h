@@ -108,7 +108,9 @@ typedef enum dint_option {
                                       /* host's pinned memory itself; 0: a copy on the stream in front of the launch            */
     DINT_OPT_QUERY_BATCH_FUSED = 9,   /* 1 (default): a call whose queries all have few candidate pages runs as ONE launch, a      */
                                       /* workgroup per query; 0: the round-per-launch batch form                                */
-    DINT_OPT_COUNT_ = 10
+    DINT_OPT_SPLIT_UNITS = 10,        /* 1 (default): a prepared multi-dictionary unit table cuts the units that fit no tile in two */
+                                      /* records each (a second launch of the bundles kernel); 0: the general kernel decodes them */
+    DINT_OPT_COUNT_ = 11
 } dint_option;
 int dint_set_option(int option, long long value);
 int dint_get_option(int option, long long* value);

@@ -75,6 +75,33 @@ def test_vroom_case(device, case):
         assert np.array_equal(out, S.expect)
         last = np.r_[units["list"][1:] != units["list"][:-1], True]
         assert np.array_equal(ends[last], S.ends[np.r_[S.units["list"][1:] != S.units["list"][:-1], True]])
+    # a PREPARED table of block-granular units (multi-dictionary streams: the units that fit no tile are cut in two records
+    # each when the table is made, split_units_kernel — and, the option off, decoded by the general kernel)
+    if D.kind == F.MULTI:
+        import torch
+
+        dev = torch.device("cuda", 0)
+        units, _, _ = d.index_stream(S.enc, 256)
+        enc_dev = torch.from_numpy(np.ascontiguousarray(S.enc)).to(dev)
+        units_dev = device.units_to_device(units, dev)
+        want_ends = None
+        for split in (1, 0):
+            device.set_option("split_units", split)
+            table = device.UnitTable(d, enc_dev, units_dev, len(units), total)
+            out_dev = torch.full((total + 64,), -1, dtype=torch.int32, device=dev)
+            end_dev = torch.zeros(len(units), dtype=torch.int64, device=dev)
+            for _ in range(2):
+                table.decode(out_dev[:total], end_dev)
+            torch.cuda.synchronize()
+            got = out_dev.cpu().numpy().view(np.uint32)
+            assert np.array_equal(got[:total], S.expect) and (got[total:] == 0xFFFFFFFF).all(), split
+            ends = end_dev.cpu().numpy().view(np.uint64)
+            if want_ends is None:
+                want_ends = ends.copy()
+            assert np.array_equal(ends, want_ends)
+            table.close()
+        last = np.r_[units["list"][1:] != units["list"][:-1], True]
+        assert np.array_equal(want_ends[last], S.ends[np.r_[S.units["list"][1:] != S.units["list"][:-1], True]])
     # the one-list call (Coder::decode's shape) on a sample
     for off, n, first in S.lists[::40]:
         got, used = d.decode_list(S.enc, off, n)

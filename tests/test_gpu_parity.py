@@ -581,3 +581,43 @@ def test_a_stream_that_straddles_4_gib(device, small_corpus, kind):
             table.close()
             del big
             torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("corpus_name", ["small_corpus", "sparse_corpus"])
+def test_units_that_fit_no_tile_are_cut_in_two(device, request, corpus_name):
+    """A prepared multi-dictionary table of block-granular units: the blocks of more than 63 lanes of stream (8-bit blocks with
+    many literals — the sparse corpus is full of them) are cut at a codeword boundary into two bundle records each when the
+    table is made (split_units_kernel) and decoded by a second launch of the bundles kernel; with the option off the general
+    kernel decodes them. Same integers, same end offsets, nothing written past the last integer."""
+    import torch
+
+    corpus = request.getfixturevalue(corpus_name)
+    kind = host.MULTI_PACKED
+    enc, _ = corpus.encoded(kind)
+    d = device.Dictionary(kind, corpus.dict_file(kind))
+    units, total, _ = d.index_stream(enc, 256)
+    dev = torch.device("cuda", 0)
+    enc_dev = torch.from_numpy(enc).to(dev)
+    units_dev = device.units_to_device(units, dev)
+    results = []
+    try:
+        for split in (1, 0):
+            device.set_option("split_units", split)
+            table = device.UnitTable(d, enc_dev, units_dev, len(units), total)
+            out_dev = torch.full((total + 64,), -1, dtype=torch.int32, device=dev)
+            end_dev = torch.zeros(len(units), dtype=torch.int64, device=dev)
+            for _ in range(2):
+                table.decode(out_dev[:total], end_dev)
+            torch.cuda.synchronize()
+            got = out_dev.cpu().numpy().view(np.uint32)
+            assert np.array_equal(got[:total], corpus.coll.gaps) and (got[total:] == 0xFFFFFFFF).all()
+            results.append(end_dev.cpu().numpy().view(np.uint64).copy())
+            table.close()
+    finally:
+        device.reset_options()
+    assert np.array_equal(results[0], results[1])
+    # (how many units the walk had to cut: the spans of the stream say)
+    nxt = np.r_[units["in_off"][1:], enc.size].astype(np.int64)
+    span = nxt - units["in_off"].astype(np.int64) - 1
+    narrow = enc[units["in_off"].astype(np.int64)] >= 6
+    assert int(np.count_nonzero((narrow & (span > 252)) | (~narrow & (span > 504)))) > (0 if corpus_name == "small_corpus" else 20)
