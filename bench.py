@@ -813,8 +813,9 @@ def main():
                 "traffic": traffic,
                 "traffic_note": traffic_note,
                 # (a prepared multi-dictionary table of block-granular units: the kernel compiled without the unit queue, and behind
-                # it, inside the same event pair, the general kernel for the units that fit no tile — about one in a hundred)
-                "kernel": ("decode_multi_bundles_kernel (+ decode_multi_kernel: the units that fit no tile)"
+                # it, inside the same event pair, the same kernel again over the units that fit no tile — about one in a hundred,
+                # cut in two records each when the table was prepared — and the general kernel for the few that could not be cut)
+                "kernel": ("decode_multi_bundles_kernel (+ a second launch of it over the units that fit no tile, cut in two)"
                            if args.type == "multi_packed_dint" and unit_table is not None and args.unit_ints <= 256
                            else KERNEL_BY_TYPE[args.type]),
                 "kernel_ms": round(k_mean, 4),

@@ -8,7 +8,7 @@ bench = json.load(open(os.path.join(out, "bench.json")))
 ints = ints_per_step
 agg = collections.defaultdict(lambda: [0.0, 0])
 kernel = None
-per_kernel = collections.defaultdict(int)
+durations = collections.defaultdict(list)
 for f in sorted(glob.glob(os.path.join(out, "sq*", "**", "*counter_collection.csv"), recursive=True)):
     for row in csv.DictReader(open(f)):
         if not row["Kernel_Name"].startswith(("dint_dev::decode_single_kernel", "dint_dev::decode_multi_kernel", "dint_dev::decode_multi_bundles_kernel")):
@@ -16,11 +16,11 @@ for f in sorted(glob.glob(os.path.join(out, "sq*", "**", "*counter_collection.cs
         kernel = row["Kernel_Name"].split("(")[0] if kernel is None or "bundles" in row["Kernel_Name"] else kernel
         a = agg[row["Counter_Name"]]
         a[0] += float(row["Counter_Value"])
-        per_kernel[(row["Counter_Name"], row["Kernel_Name"].split("(")[0])] += 1
-# (a step may be two dispatches — the bundles-only kernel, then the general one for the units that fit no tile: a counter's
-# total over everything, per dispatch of the kernel that ran most often)
-for (counter, _), n in per_kernel.items():
-    agg[counter][1] = max(agg[counter][1], n)
+        durations[row["Counter_Name"]].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+# (a step may be several dispatches — the bundles kernel over the table, the same kernel over the cut units, the general one for
+# what is left: a counter's total over everything, per STEP = per dispatch that lasts at least half as long as the longest one)
+for counter, ds in durations.items():
+    agg[counter][1] = sum(1 for x in ds if 2 * x >= max(ds))
 print(f"kernel {kernel}: {ints:.4g} integers per launch ({bench['metric']})")
 for k in sorted(agg):
     v, n = agg[k]

@@ -17,16 +17,16 @@ needle = sys.argv[6] if len(sys.argv) > 6 else "decode_"
 
 
 def mean_counter(d, name):
-    """per STEP: a step may be more than one dispatch (the multi-dictionary table: the bundles-only kernel, then the general
-    kernel for the units that fit no tile) — everything that matches, over the dispatches of the kernel that ran most often"""
-    total, per_kernel = 0.0, {}
+    """per STEP: a step may be more than one dispatch (the multi-dictionary table: the bundles kernel over the table, the same
+    kernel again over the cut units, the general kernel for what is left) — everything that matches, over the number of steps =
+    the dispatches that last at least half as long as the longest one (a step's main launch)"""
+    total, durations = 0.0, []
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             if needle in row["Kernel_Name"] and row["Counter_Name"] == name:
                 total += float(row["Counter_Value"])
-                k = row["Kernel_Name"].split("(")[0]
-                per_kernel[k] = per_kernel.get(k, 0) + 1
-    steps = max(per_kernel.values())
+                durations.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    steps = sum(1 for x in durations if 2 * x >= max(durations))
     return total / steps, steps
 
 
