@@ -19,6 +19,7 @@ pytestmark = pytest.mark.gpu
 GOLDEN = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_digests.json")))
 VROOM = F.plan(*GOLDEN["vroom_plan"])
 INDEX = F.index_plan(*GOLDEN["index_plan"])
+assert all(str(c[0]) in GOLDEN["vroom"] for c in VROOM) and all(str(c[0]) in GOLDEN["index"] for c in INDEX)
 
 
 @pytest.fixture(scope="module")
@@ -55,7 +56,8 @@ def _decode_with_canary(device, d, enc, units, total):
 @pytest.mark.parametrize("case", VROOM, ids=lambda c: f"seed{c[0]}")
 def test_vroom_case(device, case):
     D, S = F.build_case(case)
-    assert F.digest(D, S) == GOLDEN["vroom"][str(case[0])]["digest"]
+    pinned = GOLDEN["vroom"].get(str(case[0]))  # (tests/fuzz_soak.py runs this function over seeds of its own: nothing pinned)
+    assert pinned is None or F.digest(D, S) == pinned["digest"]
     d = device.Dictionary(D.kind, D.file)
     total = len(S.expect)
     # the generator's own units: cut at random slot (multi: block) boundaries, odd addresses, lists of one integer
@@ -126,7 +128,8 @@ def test_index_case(device, case):
     import torch
 
     Dd, Df, X = F.build_index_case(case)
-    assert F.index_digest(Dd, Df, X) == GOLDEN["index"][str(case[0])]["digest"]
+    pinned = GOLDEN["index"].get(str(case[0]))
+    assert pinned is None or F.index_digest(Dd, Df, X) == pinned["digest"]
     dd, fd = device.Dictionary(Dd.kind, Dd.file), device.Dictionary(Df.kind, Df.file)
     blocks, total = device.index_posting_lists(X.index, X.offsets)
     assert total == len(X.docids) and int(blocks["n"].sum()) == total
@@ -169,3 +172,21 @@ def test_index_case(device, case):
         n, fsum, _ = oi.and_query_freqs(of, qs[i])
         assert (n, fsum) == (int(counts[i]), int(sums[i])) and n == oi.and_query(qs[i])
     qi.close()
+
+
+def test_a_multi_file_with_small_contexts_fills_the_lds_image(device):
+    """choose_hot_set (hip_dictionary.inc): what the dictionaries that fit whole leave of their even quota goes to the
+    others — three reserved-only contexts beside three full ones must not leave half the image empty — and the hot / cold
+    border, now at a different codeword in every context, decodes like the generator says."""
+    r = np.random.default_rng(60606)
+    shape = dict(m_entries=65536, value_profile=("mixed", "tiny", "mixed"), size_profile="pow2",
+                 context_entries=[7, 65536, 7, 65536, 7, 40000])
+    D = F.make_dictionary(r, F.MULTI, **shape)
+    S = F.make_stream(r, D, 300)
+    full = F.make_dictionary(np.random.default_rng(60607), F.SINGLE, m_entries=65536, value_profile="mixed", size_profile="pow2")
+    d, s = device.Dictionary(D.kind, D.file), device.Dictionary(full.kind, full.file)
+    assert d.info().lds_bytes >= 0.95 * s.info().lds_bytes, (d.info().lds_bytes, s.info().lds_bytes)
+    out, ends = _decode_with_canary(device, d, S.enc, S.units, len(S.expect))
+    assert np.array_equal(out, S.expect) and np.array_equal(ends, S.ends)
+    st = d.stream_stats(S.enc)
+    assert 0 < st.hot_codewords < st.codewords  # (both sides of the border are exercised)
