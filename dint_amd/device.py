@@ -159,7 +159,7 @@ while _lib.dint_option_name(_i):
 
 def set_option(name: str, value: int) -> None:
     """dint_set_option: a process-wide switch for tests and measurements ("bundles", "index_concurrent",
-    "query_lean_pages", "query_tail_pages", "query_fused_pages")."""
+    "query_lean_pages", "query_tail_pages", "query_fused_pages", ... : device.OPTIONS lists them)."""
     _check(_lib.dint_set_option(OPTIONS[name], int(value)), f"dint_set_option({name})")
 
 

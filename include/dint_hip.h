@@ -110,7 +110,10 @@ typedef enum dint_option {
                                       /* workgroup per query; 0: the round-per-launch batch form                                */
     DINT_OPT_SPLIT_UNITS = 10,        /* 1 (default): a prepared multi-dictionary unit table cuts the units that fit no tile in two */
                                       /* records each (a second launch of the bundles kernel); 0: the general kernel decodes them */
-    DINT_OPT_COUNT_ = 11
+    DINT_OPT_REFINE_UNITS = 11,       /* 1 (default): a prepared multi-dictionary unit table whose units hold several 256-integer  */
+                                      /* blocks (at most 131072 integers each) finds the blocks once and decodes a table of      */
+                                      /* blocks; 0: the units as they came (a wavefront decodes a unit's blocks one after another) */
+    DINT_OPT_COUNT_ = 12
 } dint_option;
 int dint_set_option(int option, long long value);
 int dint_get_option(int option, long long* value);
@@ -164,6 +167,13 @@ int dint_decode_units(const dint_dict* dict, const uint8_t* d_enc, size_t enc_by
  * collection, not of a decode). The handle borrows `dict`, `d_enc` and `d_units`: they must outlive it and keep
  * their contents. `out_capacity` is the smallest output capacity later decodes may pass (the schedule's bounds
  * checks are made against it). Synchronises `stream`.
+ * A multi-dictionary table whose units hold SEVERAL 256-integer blocks (at most 131072 integers each) is refined here: blocks
+ * carry no length, so a unit of several is one wavefront's sequential work (242 G ints/s on the bench stream), where a table of
+ * blocks packs three blocks into a tile (472-526 G). A lane per unit walks the unit's codewords once and the handle keeps a
+ * unit record per block (24 bytes per 256 integers, + 22 bytes of schedule); decodes then run over the blocks, and d_end_off
+ * still has one entry per unit of the CALLER's table. DINT_OPT_REFINE_UNITS = 0: the units as they came. Results are identical
+ * either way. (Decodes of ONE table are ordered on one stream: its counters and, refined, its per-block end offsets are the
+ * table's own.)
  * Replaces: nothing in the reference (its decode loop is sequential); it is the set-up half of
  * dint_decode_units, i.e. of vroom_env/decode.cpp:139-150. */
 typedef struct dint_unit_table dint_unit_table;

@@ -37,12 +37,12 @@ def test_options_are_an_api_not_the_environment():
     from dint_amd import device
 
     assert set(device.OPTIONS) == {"bundles", "index_concurrent", "query_lean_pages", "query_tail_pages", "query_fused_pages",
-                                   "index_inline_tails", "chunk_split", "index_pair", "query_fused_copy", "query_batch_fused", "split_units"}
+                                   "index_inline_tails", "chunk_split", "index_pair", "query_fused_copy", "query_batch_fused", "split_units", "refine_units"}
     device.reset_options()
     defaults = {k: device.get_option(k) for k in device.OPTIONS}
     assert defaults == {"bundles": 1, "index_concurrent": 1, "query_lean_pages": -1, "query_tail_pages": 4,
                         "query_fused_pages": 2, "index_inline_tails": 1, "chunk_split": -1, "index_pair": 1, "query_fused_copy": 1, "query_batch_fused": 1,
-                        "split_units": 1}
+                        "split_units": 1, "refine_units": 1}
     with device.options(query_fused_pages=0, query_tail_pages=16):
         assert device.get_option("query_fused_pages") == 0 and device.get_option("query_tail_pages") == 16
     assert {k: device.get_option(k) for k in device.OPTIONS} == defaults

@@ -104,6 +104,21 @@ def test_vroom_case(device, case):
             table.close()
         last = np.r_[units["list"][1:] != units["list"][:-1], True]
         assert np.array_equal(want_ends[last], S.ends[np.r_[S.units["list"][1:] != S.units["list"][:-1], True]])
+        # ... and of the generator's own units, several blocks each: the table finds the blocks once (refine_units_kernel)
+        # and decodes a table of blocks — or, the option off, the units as they came
+        own_dev = device.units_to_device(S.units, dev)
+        for refine in (1, 0):
+            device.set_option("refine_units", refine)
+            table = device.UnitTable(d, enc_dev, own_dev, len(S.units), total)
+            out_dev = torch.full((total + 64,), -1, dtype=torch.int32, device=dev)
+            end_dev = torch.zeros(len(S.units), dtype=torch.int64, device=dev)
+            table.decode(out_dev[:total])  # (no end offsets asked for)
+            table.decode(out_dev[:total], end_dev)
+            torch.cuda.synchronize()
+            got = out_dev.cpu().numpy().view(np.uint32)
+            assert np.array_equal(got[:total], S.expect) and (got[total:] == 0xFFFFFFFF).all(), refine
+            assert np.array_equal(end_dev.cpu().numpy().view(np.uint64), S.ends), refine
+            table.close()
     # the one-list call (Coder::decode's shape) on a sample
     for off, n, first in S.lists[::40]:
         got, used = d.decode_list(S.enc, off, n)
