@@ -816,7 +816,9 @@ def main():
                 # it, inside the same event pair, the same kernel again over the units that fit no tile — about one in a hundred,
                 # cut in two records each when the table was prepared — and the general kernel for the few that could not be cut)
                 "kernel": ("decode_multi_bundles_kernel (+ a second launch of it over the units that fit no tile, cut in two)"
-                           if args.type == "multi_packed_dint" and unit_table is not None and args.unit_ints <= 256
+                           # (units of several blocks: the prepared table finds the blocks itself, once — DINT_OPT_REFINE_UNITS —
+                           # unless a unit holds more than 131072 integers)
+                           if args.type == "multi_packed_dint" and unit_table is not None and args.unit_ints <= 131072
                            else KERNEL_BY_TYPE[args.type]),
                 "kernel_ms": round(k_mean, 4),
                 "kernel_ms_min_median_max": [round(float(kernel_ms.min()), 4), round(float(np.median(kernel_ms)), 4),
